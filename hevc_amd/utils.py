@@ -1,0 +1,113 @@
+"""Encoder / GPU detection and HDR10 signalling strings.
+
+Mirror of the reference's core/utils.py: `has_nvenc` (core/utils.py:9-15), `detect_gpu_type`
+(core/utils.py:17-26), `build_hdr_metadata` (core/utils.py:29-70).  `has_mi355x` is the new
+selection hook: the analogue of `has_nvenc` for the native path.
+"""
+from __future__ import annotations
+
+import logging
+import shutil
+import subprocess
+from dataclasses import dataclass
+from functools import lru_cache
+from typing import List, Optional, Tuple
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_MASTER_DISPLAY = 'G(13250,34500)B(7500,3000)R(34000,16000)WP(15635,16450)L(10000000,50)'
+DEFAULT_MAX_CLL = '1000,400'
+
+
+def has_ffmpeg() -> bool:
+    return shutil.which('ffmpeg') is not None
+
+
+def has_nvenc() -> bool:
+    """True iff the ffmpeg on PATH lists hevc_nvenc (core/utils.py:9-15)."""
+    try:
+        out = subprocess.run(['ffmpeg', '-hide_banner', '-encoders'],
+                             capture_output=True, text=True, check=True, encoding='utf-8')
+    except Exception:
+        return False
+    return 'hevc_nvenc' in out.stdout
+
+
+def has_libx265() -> bool:
+    try:
+        out = subprocess.run(['ffmpeg', '-hide_banner', '-encoders'],
+                             capture_output=True, text=True, check=True, encoding='utf-8')
+    except Exception:
+        return False
+    return 'libx265' in out.stdout
+
+
+@lru_cache(maxsize=1)
+def detect_gpu_type() -> str:
+    """Lower-cased NVIDIA GPU name, or 'unknown' (core/utils.py:17-26).  Cached like the reference."""
+    try:
+        out = subprocess.run(['nvidia-smi', '--query-gpu=name', '--format=csv,noheader'],
+                             capture_output=True, text=True, check=True, encoding='utf-8')
+        return out.stdout.strip().lower()
+    except Exception:
+        return 'unknown'
+
+
+@lru_cache(maxsize=1)
+def mi355x_device_count() -> int:
+    """Number of gfx950 devices the native library can open; 0 when the library or the GPU is absent."""
+    try:
+        from . import _lib
+        return max(0, int(_lib.load().mihevc_device_count()))
+    except Exception as exc:
+        logger.debug('libmihevc unavailable: %s', exc)
+        return 0
+
+
+def has_mi355x() -> bool:
+    return mi355x_device_count() > 0
+
+
+def build_hdr_metadata(master_display: str, max_cll: str, use_nvenc: bool, fps: float = 30.0) -> List[str]:
+    """HDR10 argv fragment: `-metadata` pairs + colour flags for NVENC, one `-x265-params` string for
+    libx265.  Empty inputs fall back to the reference's P3-D65 1000-nit defaults."""
+    md = (master_display or '').strip() or DEFAULT_MASTER_DISPLAY
+    cll = (max_cll or '').strip() or DEFAULT_MAX_CLL
+    if use_nvenc:
+        out: List[str] = []
+        for key, val in (('color_primaries', 'bt2020'), ('color_trc', 'smpte2084'), ('colorspace', 'bt2020nc'),
+                         ('master_display', md), ('max_cll', cll)):
+            out += ['-metadata:s:v:0', f'{key}={val}']
+        return out + ['-color_primaries', 'bt2020', '-color_trc', 'smpte2084', '-colorspace', 'bt2020nc']
+    fields = ['hdr10=1', 'colorprim=bt2020', 'transfer=smpte2084', 'colormatrix=bt2020nc',
+              f'master-display={md}', f'max-cll={cll}', 'hrd=1', 'aud=1', 'chromaloc=0', 'repeat-headers=1']
+    return ['-x265-params', ':'.join(fields)]
+
+
+@dataclass
+class MasteringDisplay:
+    """Parsed `G(x,y)B(x,y)R(x,y)WP(x,y)L(max,min)` in SEI units (0.00002 chroma, 0.0001 cd/m2)."""
+    g: Tuple[int, int]
+    b: Tuple[int, int]
+    r: Tuple[int, int]
+    wp: Tuple[int, int]
+    lum: Tuple[int, int]
+
+
+def parse_master_display(text: Optional[str]) -> MasteringDisplay:
+    import re
+    text = (text or '').strip() or DEFAULT_MASTER_DISPLAY
+    m = re.fullmatch(r'G\((\d+),(\d+)\)B\((\d+),(\d+)\)R\((\d+),(\d+)\)WP\((\d+),(\d+)\)L\((\d+),(\d+)\)', text)
+    if not m:
+        return parse_master_display(DEFAULT_MASTER_DISPLAY)
+    v = [int(x) for x in m.groups()]
+    return MasteringDisplay((v[0], v[1]), (v[2], v[3]), (v[4], v[5]), (v[6], v[7]), (v[8], v[9]))
+
+
+def parse_max_cll(text: Optional[str]) -> Tuple[int, int]:
+    text = (text or '').strip() or DEFAULT_MAX_CLL
+    try:
+        a, b = text.split(',')
+        return int(a), int(b)
+    except Exception:
+        return 1000, 400
