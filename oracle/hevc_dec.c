@@ -1,0 +1,1083 @@
+/* oracle/hevc_dec.c — TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * A small HEVC decoder written from ITU-T H.265 clauses 7.3 (syntax), 9.3 (CABAC), 8.3-8.7 (decoding), for the
+ * syntax subset the MI355X encoder can emit: Main / Main10, 4:2:0, one slice per picture, I and P slices with one
+ * reference picture, 2Nx2N (+ intra NxN) CUs, merge / skip / AMVP without temporal candidates, residual coding
+ * without transform-skip, deblocking with default parameters, SAO.  Anything else is reported as an error instead
+ * of being guessed.  It exists because no third-party HEVC decoder is available in this image (SURVEY.md §7 hard
+ * part 4): "encode -> bitstream -> this decoder == encoder reconstruction" is the conformance gate we can run.
+ * The reference (uingei/hevc) has no decoder of its own; it relies on ffmpeg (core/transcoder.py:506).
+ */
+#include "hevc_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+
+#define CLIP3(lo, hi, v) ((v) < (lo) ? (lo) : (v) > (hi) ? (hi) : (v))
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+
+/* ------------------------------------------------------------------ bit reader (RBSP) */
+typedef struct { const uint8_t *p; size_t n, pos; int err; } bitrd;   /* pos in bits */
+static int br_bit(bitrd *b)
+{
+    if (b->pos >= b->n * 8) { b->err = 1; return 0; }
+    int v = (b->p[b->pos >> 3] >> (7 - (b->pos & 7))) & 1;
+    b->pos++;
+    return v;
+}
+static uint32_t br_u(bitrd *b, int n) { uint32_t v = 0; while (n--) v = (v << 1) | (uint32_t)br_bit(b); return v; }
+static uint32_t br_ue(bitrd *b)
+{
+    int z = 0;
+    while (!br_bit(b) && z < 32 && !b->err) z++;
+    return z ? ((1u << z) - 1 + br_u(b, z)) : 0;
+}
+static int32_t br_se(bitrd *b) { uint32_t k = br_ue(b); return (k & 1) ? (int32_t)((k + 1) >> 1) : -(int32_t)(k >> 1); }
+static int br_more_data(const bitrd *b)
+{   /* more_rbsp_data(): something before the last 1 bit */
+    size_t last = b->n * 8;
+    while (last > b->pos) { size_t i = last - 1; if ((b->p[i >> 3] >> (7 - (i & 7))) & 1) break; last--; }
+    return last > b->pos + 1;
+}
+static int br_trailing_ok(bitrd *b)
+{
+    if (!br_bit(b)) return 0;
+    while (b->pos & 7) if (br_bit(b)) return 0;
+    return b->pos == b->n * 8;
+}
+
+/* ------------------------------------------------------------------ CABAC decoder — 9.3.4.3 */
+static const uint8_t kRangeLps[64][4] = {
+    {128, 176, 208, 240}, {128, 167, 197, 227}, {128, 158, 187, 216}, {123, 150, 178, 205}, {116, 142, 169, 195}, {111, 135, 160, 185},
+    {105, 128, 152, 175}, {100, 122, 144, 166}, {95, 116, 137, 158},  {90, 110, 130, 150},  {85, 104, 123, 142},  {81, 99, 117, 135},
+    {77, 94, 111, 128},   {73, 89, 105, 122},   {69, 85, 100, 116},   {66, 80, 95, 110},    {62, 76, 90, 104},    {59, 72, 86, 99},
+    {56, 69, 81, 94},     {53, 65, 77, 89},     {51, 62, 73, 85},     {48, 59, 69, 80},     {46, 56, 66, 76},     {43, 53, 63, 72},
+    {41, 50, 59, 69},     {39, 48, 56, 65},     {37, 45, 54, 62},     {35, 43, 51, 59},     {33, 41, 48, 56},     {32, 39, 46, 53},
+    {30, 37, 43, 50},     {29, 35, 41, 48},     {27, 33, 39, 45},     {26, 31, 37, 43},     {24, 30, 35, 41},     {23, 28, 33, 39},
+    {22, 27, 32, 37},     {21, 26, 30, 35},     {20, 24, 29, 33},     {19, 23, 27, 31},     {18, 22, 26, 30},     {17, 21, 25, 28},
+    {16, 20, 23, 27},     {15, 19, 22, 25},     {14, 18, 21, 24},     {14, 17, 20, 23},     {13, 16, 19, 22},     {12, 15, 18, 21},
+    {12, 14, 17, 20},     {11, 14, 16, 19},     {11, 13, 15, 18},     {10, 12, 15, 17},     {10, 12, 14, 16},     {9, 11, 13, 15},
+    {9, 11, 12, 14},      {8, 10, 12, 14},      {8, 9, 11, 13},       {7, 9, 11, 12},       {7, 9, 10, 12},       {7, 8, 10, 11},
+    {6, 8, 9, 11},        {6, 7, 9, 10},        {6, 7, 8, 9},         {2, 2, 2, 2}};
+static const uint8_t kTransLps[64] = {0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12, 13, 13, 15, 15, 16, 16, 18, 18, 19, 19, 21, 21, 22, 22, 23, 24,
+                                      24, 25, 26, 26, 27, 27, 28, 29, 29, 30, 30, 30, 31, 32, 32, 33, 33, 33, 34, 34, 35, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 63};
+
+/* context table layout (offsets into one array) and initValues — Tables 9-5..9-37; column = initType 0 (I), 1 (P), 2 (B) */
+enum {
+    CX_SAO_MERGE = 0, CX_SAO_TYPE = 1, CX_SPLIT_CU = 2, CX_SKIP = 5, CX_PRED_MODE = 8, CX_PART_MODE = 9, CX_PREV_INTRA = 13,
+    CX_CHROMA_MODE = 14, CX_RQT_ROOT = 15, CX_MERGE_FLAG = 16, CX_MERGE_IDX = 17, CX_MVP = 18, CX_SPLIT_TU = 19, CX_CBF_LUMA = 22,
+    CX_CBF_CHROMA = 24, CX_MVD0 = 29, CX_MVD1 = 30, CX_LAST_X = 31, CX_LAST_Y = 49, CX_CSBF = 67, CX_SIG = 71, CX_G1 = 115,
+    CX_G2 = 139, CX_QP_DELTA = 145, CX_COUNT = 147
+};
+#define CNU 154
+static const uint8_t kInit[3][CX_COUNT] = {
+    { /* I */ 153, 200, 139, 141, 157, CNU, CNU, CNU, CNU, 184, CNU, CNU, CNU, 184, 63, CNU, CNU, CNU, CNU, 153, 138, 138, 111, 141,
+      94, 138, 182, 154, 154, CNU, CNU,
+      110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
+      110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
+      91, 171, 134, 141,
+      111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
+      140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 141, 111,
+      140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
+      138, 153, 136, 167, 152, 152, 154, 154},
+    { /* P */ 153, 185, 107, 139, 126, 197, 185, 201, 149, 154, 139, 154, 154, 154, 152, 79, 110, 122, 168, 124, 138, 94, 153, 111,
+      149, 107, 167, 154, 154, 140, 198,
+      125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
+      125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
+      121, 140, 61, 154,
+      155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
+      170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
+      154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
+      107, 167, 91, 122, 107, 167, 154, 154},
+    { /* B */ 153, 160, 107, 139, 126, 197, 185, 201, 134, 154, 139, 154, 154, 183, 152, 79, 154, 137, 168, 224, 167, 122, 153, 111,
+      149, 92, 167, 154, 154, 169, 198,
+      125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
+      125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
+      121, 140, 61, 154,
+      170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
+      170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
+      154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
+      107, 167, 91, 107, 107, 167, 154, 154}};
+
+typedef struct {
+    const uint8_t *p; size_t n, pos;   /* byte position in the slice data */
+    uint32_t range, offset; int bits_left;
+    uint8_t state[CX_COUNT], mps[CX_COUNT];
+    int err;
+} cabac;
+static int cb_bit(cabac *c)
+{
+    if (c->bits_left == 0) {
+        if (c->pos >= c->n) { c->err = 1; return 0; }
+        c->bits_left = 8;
+    }
+    int v = (c->p[c->pos] >> (c->bits_left - 1)) & 1;
+    if (--c->bits_left == 0) c->pos++;
+    return v;
+}
+static void cb_init(cabac *c, const uint8_t *p, size_t n, int init_type, int qp)
+{
+    memset(c, 0, sizeof *c);
+    c->p = p; c->n = n; c->range = 510;
+    for (int i = 0; i < 9; i++) c->offset = (c->offset << 1) | (uint32_t)cb_bit(c);
+    qp = CLIP3(0, 51, qp);
+    for (int i = 0; i < CX_COUNT; i++) {
+        int iv = kInit[init_type][i];
+        int m = (iv >> 4) * 5 - 45, nn = ((iv & 15) << 3) - 16;
+        int pre = CLIP3(1, 126, ((m * qp) >> 4) + nn);
+        c->mps[i] = pre > 63;
+        c->state[i] = (uint8_t)(c->mps[i] ? pre - 64 : 63 - pre);
+    }
+}
+static int cb_decision(cabac *c, int ctx)
+{
+    uint32_t lps = kRangeLps[c->state[ctx]][(c->range >> 6) & 3];
+    int bin;
+    c->range -= lps;
+    if (c->offset >= c->range) {
+        bin = !c->mps[ctx];
+        c->offset -= c->range; c->range = lps;
+        if (c->state[ctx] == 0) c->mps[ctx] = !c->mps[ctx];
+        c->state[ctx] = kTransLps[c->state[ctx]];
+    } else {
+        bin = c->mps[ctx];
+        if (c->state[ctx] < 62) c->state[ctx]++;
+    }
+    while (c->range < 256) { c->range <<= 1; c->offset = (c->offset << 1) | (uint32_t)cb_bit(c); }
+    return bin;
+}
+static int cb_bypass(cabac *c)
+{
+    c->offset = (c->offset << 1) | (uint32_t)cb_bit(c);
+    if (c->offset >= c->range) { c->offset -= c->range; return 1; }
+    return 0;
+}
+static uint32_t cb_bypass_n(cabac *c, int n) { uint32_t v = 0; while (n--) v = (v << 1) | (uint32_t)cb_bypass(c); return v; }
+static int cb_terminate(cabac *c)
+{
+    c->range -= 2;
+    if (c->offset >= c->range) return 1;
+    while (c->range < 256) { c->range <<= 1; c->offset = (c->offset << 1) | (uint32_t)cb_bit(c); }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ decoder state */
+typedef struct { pix *base[3]; pix *pl[3]; int stride[3]; int poc; } picture;
+
+typedef struct { char name[40]; long long val; } kv;
+
+struct orc_decoder {
+    /* SPS */
+    int have_sps, have_pps, have_vps;
+    int w, h, bit_depth, conf[4], log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, th_inter, th_intra;
+    int sao_on, strong_intra, poc_bits, num_strps, strps_neg[64], strps_delta[64][4], strps_used[64][4], amp, tmvp;
+    /* PPS */
+    int init_qp, sign_hiding, cu_qp_delta, cb_off, cr_off, lf_across, dbk_control, dbk_override_en, pps_dbk_disabled,
+        cabac_init_present, par_mrg_level, transform_skip;
+    /* pictures */
+    picture *pics; int n_pics, cap_pics;
+    picture cur; int cur_valid;
+    orc_cu_rec *cu; uint8_t *depth8; uint8_t *skip8; orc_sao_ctu *sao;
+    /* slice */
+    int slice_type, slice_qp, sao_luma, sao_chroma, max_merge, ref_idx;
+    int poc;
+    cabac cb;
+    char err[256];
+    kv kvs[160]; int n_kv;
+};
+
+static void set_err(orc_decoder *d, const char *fmt, ...)
+{
+    if (d->err[0]) return;
+    va_list ap; va_start(ap, fmt); vsnprintf(d->err, sizeof d->err, fmt, ap); va_end(ap);
+}
+static void put_kv(orc_decoder *d, const char *name, long long v)
+{
+    for (int i = 0; i < d->n_kv; i++) if (!strcmp(d->kvs[i].name, name)) { d->kvs[i].val = v; return; }
+    if (d->n_kv < 160) { snprintf(d->kvs[d->n_kv].name, 40, "%s", name); d->kvs[d->n_kv++].val = v; }
+}
+
+orc_decoder *orc_dec_open(void) { return (orc_decoder *)calloc(1, sizeof(orc_decoder)); }
+const char *orc_dec_error(const orc_decoder *d) { return d->err; }
+int orc_dec_query(const orc_decoder *d, const char *f, long long *v)
+{
+    for (int i = 0; i < d->n_kv; i++) if (!strcmp(d->kvs[i].name, f)) { *v = d->kvs[i].val; return 1; }
+    return 0;
+}
+static void free_pic(picture *p) { for (int i = 0; i < 3; i++) free(p->base[i]); memset(p, 0, sizeof *p); }
+void orc_dec_close(orc_decoder *d)
+{
+    if (!d) return;
+    for (int i = 0; i < d->n_pics; i++) free_pic(&d->pics[i]);
+    free(d->pics); free(d->cu); free(d->depth8); free(d->skip8); free(d->sao);
+    if (d->cur_valid) free_pic(&d->cur);
+    free(d);
+}
+int orc_dec_info(const orc_decoder *d, int *w, int *h, int *bd, int *cw, int *ch)
+{
+    if (!d->have_sps) return -1;
+    *w = d->w; *h = d->h; *bd = d->bit_depth;
+    *cw = d->w - 2 * (d->conf[0] + d->conf[1]); *ch = d->h - 2 * (d->conf[2] + d->conf[3]);
+    return 0;
+}
+int orc_dec_get_frame(const orc_decoder *d, int idx, pix *y, pix *u, pix *v)
+{
+    if (idx < 0 || idx >= d->n_pics) return -1;
+    const picture *p = &d->pics[idx];
+    pix *dst[3] = {y, u, v};
+    for (int c = 0; c < 3; c++) {
+        int w = c ? d->w / 2 : d->w, h = c ? d->h / 2 : d->h;
+        for (int r = 0; r < h; r++) memcpy(dst[c] + (size_t)r * w, p->pl[c] + (size_t)r * p->stride[c], w * sizeof(pix));
+    }
+    return p->poc;
+}
+static void alloc_pic(orc_decoder *d, picture *p)
+{
+    for (int c = 0; c < 3; c++) {
+        int pad = c ? ORC_PAD / 2 : ORC_PAD, w = c ? d->w / 2 : d->w, h = c ? d->h / 2 : d->h;
+        p->stride[c] = w + 2 * pad;
+        p->base[c] = (pix *)calloc((size_t)p->stride[c] * (h + 2 * pad), sizeof(pix));
+        p->pl[c] = p->base[c] + (size_t)pad * p->stride[c] + pad;
+    }
+}
+
+/* ------------------------------------------------------------------ parameter sets — 7.3.2 */
+static void parse_ptl(orc_decoder *d, bitrd *b, const char *pfx)
+{
+    char nm[40];
+    br_u(b, 2);
+    int tier = (int)br_u(b, 1), profile = (int)br_u(b, 5);
+    uint32_t compat = br_u(b, 32);
+    int prog = br_bit(b), inter = br_bit(b), nonpacked = br_bit(b), frameonly = br_bit(b);
+    br_u(b, 32); br_u(b, 11); br_bit(b);
+    int level = (int)br_u(b, 8);
+    snprintf(nm, 40, "%s.profile_idc", pfx); put_kv(d, nm, profile);
+    snprintf(nm, 40, "%s.tier_flag", pfx); put_kv(d, nm, tier);
+    snprintf(nm, 40, "%s.level_idc", pfx); put_kv(d, nm, level);
+    snprintf(nm, 40, "%s.compat", pfx); put_kv(d, nm, compat);
+    snprintf(nm, 40, "%s.progressive", pfx); put_kv(d, nm, prog);
+    snprintf(nm, 40, "%s.frame_only", pfx); put_kv(d, nm, frameonly);
+    (void)inter; (void)nonpacked;
+}
+
+static int parse_vps(orc_decoder *d, bitrd *b)
+{
+    put_kv(d, "vps.id", br_u(b, 4));
+    br_u(b, 2);
+    if (br_u(b, 6) != 0) { set_err(d, "vps: layers"); return -1; }
+    if (br_u(b, 3) != 0) { set_err(d, "vps: sub-layers unsupported"); return -1; }
+    br_bit(b);
+    if (br_u(b, 16) != 0xffff) { set_err(d, "vps: reserved_0xffff"); return -1; }
+    parse_ptl(d, b, "vps");
+    int ordering = br_bit(b); (void)ordering;
+    put_kv(d, "vps.max_dec_pic_buffering_minus1", br_ue(b));
+    put_kv(d, "vps.max_num_reorder", br_ue(b));
+    br_ue(b);
+    br_u(b, 6);
+    if (br_ue(b) != 0) { set_err(d, "vps: layer sets"); return -1; }
+    int timing = br_bit(b);
+    put_kv(d, "vps.timing_info_present", timing);
+    if (timing) {
+        put_kv(d, "vps.num_units_in_tick", br_u(b, 32));
+        put_kv(d, "vps.time_scale", br_u(b, 32));
+        if (br_bit(b)) br_ue(b);
+        if (br_ue(b) != 0) { set_err(d, "vps: hrd"); return -1; }
+    }
+    if (br_bit(b)) { set_err(d, "vps: extension"); return -1; }
+    if (!br_trailing_ok(b) || b->err) { set_err(d, "vps: trailing bits"); return -1; }
+    d->have_vps = 1;
+    return 0;
+}
+
+static int parse_hrd(orc_decoder *d, bitrd *b)
+{
+    int nal = br_bit(b), vcl = br_bit(b), subpic = 0;
+    put_kv(d, "hrd.nal_present", nal);
+    if (nal || vcl) {
+        subpic = br_bit(b);
+        if (subpic) { set_err(d, "hrd: sub-pic"); return -1; }
+        put_kv(d, "hrd.bit_rate_scale", br_u(b, 4));
+        put_kv(d, "hrd.cpb_size_scale", br_u(b, 4));
+        put_kv(d, "hrd.initial_cpb_removal_delay_length_minus1", br_u(b, 5));
+        put_kv(d, "hrd.au_cpb_removal_delay_length_minus1", br_u(b, 5));
+        put_kv(d, "hrd.dpb_output_delay_length_minus1", br_u(b, 5));
+    }
+    int fixed_general = br_bit(b), fixed_cvs = 1, low_delay = 0, cpb_cnt = 0;
+    if (!fixed_general) fixed_cvs = br_bit(b);
+    if (fixed_cvs) br_ue(b); else low_delay = br_bit(b);
+    if (!low_delay) cpb_cnt = (int)br_ue(b);
+    for (int k = 0; k < nal + vcl; k++)
+        for (int i = 0; i <= cpb_cnt; i++) {
+            long long br = br_ue(b), cs = br_ue(b);
+            if (k == 0 && i == 0) { put_kv(d, "hrd.bit_rate_value_minus1", br); put_kv(d, "hrd.cpb_size_value_minus1", cs); }
+            put_kv(d, "hrd.cbr_flag", br_bit(b));
+        }
+    return 0;
+}
+
+static int parse_sps(orc_decoder *d, bitrd *b)
+{
+    br_u(b, 4);
+    if (br_u(b, 3) != 0) { set_err(d, "sps: sub-layers unsupported"); return -1; }
+    br_bit(b);
+    parse_ptl(d, b, "sps");
+    if (br_ue(b) != 0) { set_err(d, "sps: id"); return -1; }
+    if (br_ue(b) != 1) { set_err(d, "sps: chroma_format_idc != 1"); return -1; }
+    d->w = (int)br_ue(b); d->h = (int)br_ue(b);
+    memset(d->conf, 0, sizeof d->conf);
+    if (br_bit(b)) for (int i = 0; i < 4; i++) d->conf[i] = (int)br_ue(b);
+    d->bit_depth = 8 + (int)br_ue(b);
+    if ((int)br_ue(b) + 8 != d->bit_depth) { set_err(d, "sps: chroma bit depth differs"); return -1; }
+    d->poc_bits = 4 + (int)br_ue(b);
+    br_bit(b);
+    put_kv(d, "sps.max_dec_pic_buffering_minus1", br_ue(b));
+    put_kv(d, "sps.max_num_reorder", br_ue(b));
+    br_ue(b);
+    d->log2_min_cb = 3 + (int)br_ue(b);
+    d->log2_ctb = d->log2_min_cb + (int)br_ue(b);
+    d->log2_min_tb = 2 + (int)br_ue(b);
+    d->log2_max_tb = d->log2_min_tb + (int)br_ue(b);
+    d->th_inter = (int)br_ue(b); d->th_intra = (int)br_ue(b);
+    if (br_bit(b)) { set_err(d, "sps: scaling lists"); return -1; }
+    d->amp = br_bit(b);
+    d->sao_on = br_bit(b);
+    if (br_bit(b)) { set_err(d, "sps: pcm"); return -1; }
+    d->num_strps = (int)br_ue(b);
+    if (d->num_strps > 64) { set_err(d, "sps: strps count"); return -1; }
+    for (int i = 0; i < d->num_strps; i++) {
+        if (i && br_bit(b)) { set_err(d, "sps: inter RPS prediction"); return -1; }
+        int neg = (int)br_ue(b), posn = (int)br_ue(b);
+        if (posn || neg > 4) { set_err(d, "sps: rps shape"); return -1; }
+        d->strps_neg[i] = neg;
+        int acc = 0;
+        for (int k = 0; k < neg; k++) { acc -= (int)br_ue(b) + 1; d->strps_delta[i][k] = acc; d->strps_used[i][k] = br_bit(b); }
+    }
+    if (br_bit(b)) { set_err(d, "sps: long-term refs"); return -1; }
+    d->tmvp = br_bit(b);
+    if (d->tmvp) { set_err(d, "sps: temporal mvp"); return -1; }
+    d->strong_intra = br_bit(b);
+    int vui = br_bit(b);
+    put_kv(d, "sps.vui_present", vui);
+    if (vui) {
+        if (br_bit(b)) { int idc = (int)br_u(b, 8); put_kv(d, "vui.aspect_ratio_idc", idc); if (idc == 255) { br_u(b, 16); br_u(b, 16); } }
+        if (br_bit(b)) br_bit(b);
+        int vs = br_bit(b);
+        put_kv(d, "vui.video_signal_type_present", vs);
+        if (vs) {
+            put_kv(d, "vui.video_format", br_u(b, 3));
+            put_kv(d, "vui.full_range", br_bit(b));
+            int cd = br_bit(b);
+            put_kv(d, "vui.colour_description_present", cd);
+            if (cd) { put_kv(d, "vui.colour_primaries", br_u(b, 8)); put_kv(d, "vui.transfer", br_u(b, 8)); put_kv(d, "vui.matrix", br_u(b, 8)); }
+        }
+        int cl = br_bit(b);
+        put_kv(d, "vui.chroma_loc_present", cl);
+        if (cl) { put_kv(d, "vui.chroma_loc_top", br_ue(b)); br_ue(b); }
+        br_bit(b); br_bit(b); br_bit(b);
+        if (br_bit(b)) { br_ue(b); br_ue(b); br_ue(b); br_ue(b); }
+        int ti = br_bit(b);
+        put_kv(d, "vui.timing_info_present", ti);
+        if (ti) {
+            put_kv(d, "vui.num_units_in_tick", br_u(b, 32));
+            put_kv(d, "vui.time_scale", br_u(b, 32));
+            if (br_bit(b)) br_ue(b);
+            int hrd = br_bit(b);
+            put_kv(d, "vui.hrd_present", hrd);
+            if (hrd && parse_hrd(d, b)) return -1;
+        }
+        if (br_bit(b)) { br_bit(b); br_bit(b); br_bit(b); br_ue(b); br_ue(b); br_ue(b); br_ue(b); br_ue(b); }
+    }
+    if (br_bit(b)) { set_err(d, "sps: extension"); return -1; }
+    if (!br_trailing_ok(b) || b->err) { set_err(d, "sps: trailing bits"); return -1; }
+    if (d->log2_ctb != ORC_CTU_LOG2 || d->log2_min_cb != 3 || d->log2_min_tb != 2 || d->log2_max_tb != 5) {
+        set_err(d, "sps: block sizes ctb=%d mincb=%d tb=%d..%d unsupported", d->log2_ctb, d->log2_min_cb, d->log2_min_tb, d->log2_max_tb);
+        return -1;
+    }
+    if ((d->w & 7) || (d->h & 7)) { set_err(d, "sps: size not multiple of MinCb"); return -1; }
+    put_kv(d, "sps.width", d->w); put_kv(d, "sps.height", d->h); put_kv(d, "sps.bit_depth", d->bit_depth);
+    put_kv(d, "sps.sao", d->sao_on); put_kv(d, "sps.strong_intra", d->strong_intra); put_kv(d, "sps.amp", d->amp);
+    put_kv(d, "sps.conf_right", d->conf[1]); put_kv(d, "sps.conf_bottom", d->conf[3]);
+    put_kv(d, "sps.log2_ctb", d->log2_ctb); put_kv(d, "sps.poc_bits", d->poc_bits);
+    d->have_sps = 1;
+    return 0;
+}
+
+static int parse_pps(orc_decoder *d, bitrd *b)
+{
+    if (br_ue(b) || br_ue(b)) { set_err(d, "pps: ids"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: dependent slices"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: output_flag_present"); return -1; }
+    if (br_u(b, 3)) { set_err(d, "pps: extra slice header bits"); return -1; }
+    d->sign_hiding = br_bit(b);
+    d->cabac_init_present = br_bit(b);
+    if (br_ue(b) || br_ue(b)) { set_err(d, "pps: default ref idx counts"); return -1; }
+    d->init_qp = 26 + br_se(b);
+    if (br_bit(b)) { set_err(d, "pps: constrained intra"); return -1; }
+    d->transform_skip = br_bit(b);
+    if (d->transform_skip) { set_err(d, "pps: transform skip"); return -1; }
+    d->cu_qp_delta = br_bit(b);
+    if (d->cu_qp_delta) { set_err(d, "pps: cu_qp_delta"); return -1; }
+    d->cb_off = br_se(b); d->cr_off = br_se(b);
+    if (d->cb_off || d->cr_off) { set_err(d, "pps: chroma qp offsets"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: slice chroma offsets"); return -1; }
+    if (br_bit(b) || br_bit(b)) { set_err(d, "pps: weighted prediction"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: transquant bypass"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: tiles"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: wpp"); return -1; }
+    d->lf_across = br_bit(b);
+    d->dbk_control = br_bit(b);
+    if (d->dbk_control) { set_err(d, "pps: deblocking control"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: scaling list"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: lists modification"); return -1; }
+    d->par_mrg_level = 2 + (int)br_ue(b);
+    if (br_bit(b)) { set_err(d, "pps: slice header ext"); return -1; }
+    if (br_bit(b)) { set_err(d, "pps: extension"); return -1; }
+    if (!br_trailing_ok(b) || b->err) { set_err(d, "pps: trailing bits"); return -1; }
+    put_kv(d, "pps.init_qp", d->init_qp); put_kv(d, "pps.sign_hiding", d->sign_hiding);
+    d->have_pps = 1;
+    return 0;
+}
+
+static int parse_sei(orc_decoder *d, bitrd *b)
+{
+    while (br_more_data(b) && !b->err) {
+        int type = 0, size = 0, v;
+        while ((v = (int)br_u(b, 8)) == 255) type += 255;
+        type += v;
+        while ((v = (int)br_u(b, 8)) == 255) size += 255;
+        size += v;
+        size_t end = b->pos + (size_t)size * 8;
+        char nm[40];
+        snprintf(nm, 40, "sei.%d.size", type); put_kv(d, nm, size);
+        if (type == 137 && size == 24) {
+            const char *n3[3] = {"g", "b", "r"};
+            for (int i = 0; i < 3; i++) {
+                snprintf(nm, 40, "sei.mdcv.%sx", n3[i]); put_kv(d, nm, br_u(b, 16));
+                snprintf(nm, 40, "sei.mdcv.%sy", n3[i]); put_kv(d, nm, br_u(b, 16));
+            }
+            put_kv(d, "sei.mdcv.wpx", br_u(b, 16)); put_kv(d, "sei.mdcv.wpy", br_u(b, 16));
+            put_kv(d, "sei.mdcv.max_lum", br_u(b, 32)); put_kv(d, "sei.mdcv.min_lum", br_u(b, 32));
+        } else if (type == 144 && size == 4) {
+            put_kv(d, "sei.cll.max_cll", br_u(b, 16)); put_kv(d, "sei.cll.max_fall", br_u(b, 16));
+        }
+        b->pos = end;
+    }
+    if (!br_trailing_ok(b) || b->err) { set_err(d, "sei: trailing bits"); return -1; }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ slice data helpers */
+static inline int zorder6(int bx, int by)
+{
+    int z = 0;
+    for (int i = 0; i < 3; i++) z |= ((bx >> i) & 1) << (2 * i) | ((by >> i) & 1) << (2 * i + 1);
+    return z;
+}
+static inline int zaddr(const orc_decoder *d, int x, int y)
+{
+    int wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2;
+    return (((y >> ORC_CTU_LOG2) * wc + (x >> ORC_CTU_LOG2)) << 6) | zorder6((x & 31) >> 2, (y & 31) >> 2);
+}
+/* 6.4.1 z-scan availability of (xn,yn) seen from (xc,yc) */
+static inline int avail_z(const orc_decoder *d, int xc, int yc, int xn, int yn)
+{
+    return xn >= 0 && yn >= 0 && xn < d->w && yn < d->h && zaddr(d, xn, yn) <= zaddr(d, xc, yc);
+}
+static inline orc_cu_rec *cu_at(orc_decoder *d, int x, int y) { return &d->cu[(y >> 3) * (d->w >> 3) + (x >> 3)]; }
+
+/* scan order tables — 6.5.3..6.5.5, generated */
+static uint8_t g_scan[3][4][64][2];   /* [scanIdx][log2 blk size 0..3][pos][x,y] */
+static int g_scan_ready;
+static void build_scans(void)
+{
+    if (g_scan_ready) return;
+    for (int l = 0; l < 4; l++) {
+        int n = 1 << l, i = 0, x = 0, y = 0;
+        for (;;) {                                  /* up-right diagonal */
+            while (y >= 0) { if (x < n && y < n) { g_scan[0][l][i][0] = (uint8_t)x; g_scan[0][l][i][1] = (uint8_t)y; i++; } y--; x++; }
+            y = x; x = 0;
+            if (i >= n * n) break;
+        }
+        i = 0;
+        for (y = 0; y < n; y++) for (x = 0; x < n; x++) { g_scan[1][l][i][0] = (uint8_t)x; g_scan[1][l][i][1] = (uint8_t)y; i++; }
+        i = 0;
+        for (x = 0; x < n; x++) for (y = 0; y < n; y++) { g_scan[2][l][i][0] = (uint8_t)x; g_scan[2][l][i][1] = (uint8_t)y; i++; }
+    }
+    g_scan_ready = 1;
+}
+
+/* 7.3.8.11 + 9.3.4.2.4-.7 residual_coding; writes TransCoeffLevel into lvl (n*n raster), returns 0 / -1 */
+static int residual_coding(orc_decoder *d, int log2n, int c_idx, int scan_idx, int16_t *lvl)
+{
+    cabac *c = &d->cb;
+    int n = 1 << log2n;
+    memset(lvl, 0, sizeof(int16_t) * n * n);
+    /* last position prefixes */
+    int off, shift;
+    if (c_idx == 0) { off = 3 * (log2n - 2) + ((log2n - 1) >> 2); shift = (log2n + 1) >> 2; }
+    else { off = 15; shift = log2n - 2; }
+    int cmax = (log2n << 1) - 1, px = 0, py = 0;
+    while (px < cmax && cb_decision(c, CX_LAST_X + off + (px >> shift))) px++;
+    while (py < cmax && cb_decision(c, CX_LAST_Y + off + (py >> shift))) py++;
+    int lx = px, ly = py;
+    if (px > 3) { int nb = (px >> 1) - 1; lx = (1 << nb) * (2 + (px & 1)) + (int)cb_bypass_n(c, nb); }
+    if (py > 3) { int nb = (py >> 1) - 1; ly = (1 << nb) * (2 + (py & 1)) + (int)cb_bypass_n(c, nb); }
+    if (scan_idx == 2) { int t = lx; lx = ly; ly = t; }
+    if (lx >= n || ly >= n) { set_err(d, "residual: last position out of block"); return -1; }
+    /* locate last sub-block / position */
+    int l2sb = log2n - 2, last_sb = (1 << (2 * l2sb)) - 1, last_pos = 16, xs, ys, xc, yc;
+    do {
+        if (last_pos == 0) { last_pos = 16; last_sb--; }
+        last_pos--;
+        xs = g_scan[scan_idx][l2sb][last_sb][0]; ys = g_scan[scan_idx][l2sb][last_sb][1];
+        xc = (xs << 2) + g_scan[scan_idx][2][last_pos][0]; yc = (ys << 2) + g_scan[scan_idx][2][last_pos][1];
+    } while (xc != lx || yc != ly);
+    uint8_t csbf[8][8];
+    memset(csbf, 0, sizeof csbf);
+    int g1_carry = 1;       /* HM's c1 carried across sub-blocks == spec lastGreater1Ctx logic (9.3.4.2.6) */
+    int nsb = 1 << l2sb;
+    for (int i = last_sb; i >= 0; i--) {
+        xs = g_scan[scan_idx][l2sb][i][0]; ys = g_scan[scan_idx][l2sb][i][1];
+        int infer_dc = 0;
+        int right = xs + 1 < nsb ? csbf[ys][xs + 1] : 0, below = ys + 1 < nsb ? csbf[ys + 1][xs] : 0;
+        if (i < last_sb && i > 0) {
+            csbf[ys][xs] = (uint8_t)cb_decision(c, CX_CSBF + ((right | below) ? 1 : 0) + (c_idx ? 2 : 0));
+            infer_dc = 1;
+        } else csbf[ys][xs] = 1;
+        uint8_t sig[16];
+        memset(sig, 0, 16);
+        int prev_csbf = right + 2 * below;
+        for (int k = (i == last_sb) ? last_pos : 15; k >= 0; k--) {
+            int xp = g_scan[scan_idx][2][k][0], yp = g_scan[scan_idx][2][k][1];
+            xc = (xs << 2) + xp; yc = (ys << 2) + yp;
+            if (i == last_sb && k == last_pos) { sig[k] = 1; continue; }
+            if (!csbf[ys][xs]) continue;
+            if (k == 0 && infer_dc) { sig[0] = 1; continue; }
+            int sc;
+            if (log2n == 2) { static const uint8_t m[16] = {0, 1, 4, 5, 2, 3, 4, 5, 6, 6, 8, 8, 7, 7, 8, 8}; sc = m[(yc << 2) + xc]; }
+            else if (xc + yc == 0) sc = 0;
+            else {
+                if (prev_csbf == 0) sc = (xp + yp == 0) ? 2 : (xp + yp < 3) ? 1 : 0;
+                else if (prev_csbf == 1) sc = yp == 0 ? 2 : yp == 1 ? 1 : 0;
+                else if (prev_csbf == 2) sc = xp == 0 ? 2 : xp == 1 ? 1 : 0;
+                else sc = 2;
+                if (c_idx == 0) { if (xs || ys) sc += 3; sc += log2n == 3 ? (scan_idx == 0 ? 9 : 15) : 21; }
+                else sc += log2n == 3 ? 9 : 12;
+            }
+            sig[k] = (uint8_t)cb_decision(c, CX_SIG + (c_idx ? 27 + sc : sc));
+            if (sig[k]) infer_dc = 0;
+        }
+        int nsig = 0;
+        for (int k = 0; k < 16; k++) nsig += sig[k];
+        if (!nsig) continue;
+        int ctx_set = (i > 0 && c_idx == 0) ? 2 : 0;
+        if (g1_carry == 0) ctx_set++;
+        int c1 = 1, ng1 = 0, last_g1_pos = -1, first_sig = 16, last_sig = -1;
+        uint8_t g1[16], g2[16];
+        memset(g1, 0, 16); memset(g2, 0, 16);
+        for (int k = 15; k >= 0; k--) {
+            if (!sig[k]) continue;
+            if (ng1 < 8) {
+                g1[k] = (uint8_t)cb_decision(c, CX_G1 + ctx_set * 4 + c1 + (c_idx ? 16 : 0));
+                ng1++;
+                if (g1[k]) { c1 = 0; if (last_g1_pos < 0) last_g1_pos = k; }
+                else if (c1 > 0 && c1 < 3) c1++;
+            }
+            if (last_sig < 0) last_sig = k;
+            first_sig = k;
+        }
+        g1_carry = c1;
+        if (last_g1_pos >= 0) g2[last_g1_pos] = (uint8_t)cb_decision(c, CX_G2 + ctx_set + (c_idx ? 4 : 0));
+        int hidden = d->sign_hiding && (last_sig - first_sig > 3);
+        uint32_t signs = 0; int nsigns = 0;
+        for (int k = 15; k >= 0; k--) if (sig[k] && !(hidden && k == first_sig)) nsigns++;
+        signs = cb_bypass_n(c, nsigns) << (32 - nsigns > 31 ? 0 : 32 - nsigns);
+        if (nsigns == 0) signs = 0;
+        int num = 0, sum = 0, rice = 0;
+        for (int k = 15; k >= 0; k--) {
+            if (!sig[k]) continue;
+            int base = 1 + g1[k] + g2[k];
+            int thresh = num < 8 ? (k == last_g1_pos ? 3 : 2) : 1;
+            int a = base;
+            if (base == thresh) {
+                int pfx = 0;
+                while (pfx < 4 && cb_bypass(c)) pfx++;
+                int rem;
+                if (pfx < 4) rem = (pfx << rice) + (int)cb_bypass_n(c, rice);
+                else {
+                    int kk = rice + 1; rem = 4 << rice;
+                    while (cb_bypass(c)) { rem += 1 << kk; kk++; if (kk > 30) { set_err(d, "residual: escape too long"); return -1; } }
+                    rem += (int)cb_bypass_n(c, kk);
+                }
+                a = base + rem;
+                if (a > 3 * (1 << rice)) rice = rice < 4 ? rice + 1 : 4;
+            }
+            int neg;
+            if (hidden && k == first_sig) neg = 0; /* fixed after the loop */
+            else { neg = (int)(signs >> 31); signs <<= 1; }
+            xc = (xs << 2) + g_scan[scan_idx][2][k][0]; yc = (ys << 2) + g_scan[scan_idx][2][k][1];
+            if (a > 32767) a = 32767;
+            lvl[yc * n + xc] = (int16_t)(neg ? -a : a);
+            sum += a; num++;
+        }
+        if (hidden && (sum & 1)) {
+            xc = (xs << 2) + g_scan[scan_idx][2][first_sig][0]; yc = (ys << 2) + g_scan[scan_idx][2][first_sig][1];
+            lvl[yc * n + xc] = (int16_t)-lvl[yc * n + xc];
+        }
+    }
+    return c->err ? -1 : 0;
+}
+
+/* reconstruct one TU: dequant + inverse transform + add to prediction already stored in the picture */
+static void add_residual(orc_decoder *d, int c_idx, int x, int y, int log2n, const int16_t *lvl, int qp, int dst)
+{
+    int n = 1 << log2n, maxv = (1 << d->bit_depth) - 1;
+    int16_t coef[32 * 32], res[32 * 32];
+    orc_dequant(lvl, coef, log2n, qp, d->bit_depth);
+    orc_inv_transform(coef, res, n, log2n, dst, d->bit_depth);
+    pix *p = d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x;
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) { int v = p[j * d->cur.stride[c_idx] + i] + res[j * n + i]; p[j * d->cur.stride[c_idx] + i] = (pix)CLIP3(0, maxv, v); }
+}
+
+static void intra_predict_block(orc_decoder *d, int c_idx, int x, int y, int log2n, int mode)
+{
+    pix ref[129], filt[129];
+    int s = c_idx ? 1 : 0;
+    orc_intra_build_ref(d->cur.pl[c_idx], d->cur.stride[c_idx], x, y, log2n, d->w >> s, d->h >> s, NULL, 0, c_idx, d->bit_depth, ref);
+    orc_intra_filter_ref(ref, filt, log2n, mode, c_idx, d->bit_depth, d->strong_intra);
+    orc_intra_pred(filt, d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x, d->cur.stride[c_idx], log2n, mode, c_idx, d->bit_depth);
+}
+
+static int intra_scan_idx(int log2n_block, int c_idx, int mode)
+{
+    if (log2n_block == 2 || (log2n_block == 3 && c_idx == 0)) {
+        if (mode >= 6 && mode <= 14) return 2;
+        if (mode >= 22 && mode <= 30) return 1;
+    }
+    return 0;
+}
+
+/* 7.3.8.8 transform_tree / 7.3.8.10 transform_unit (for the depths the encoder can produce) */
+static int transform_tree(orc_decoder *d, int x0, int y0, int xb, int yb, int log2n, int depth, int blk,
+                          int intra, int nxn, const uint8_t *luma_modes, int chroma_mode, int pcb, int pcr)
+{
+    cabac *c = &d->cb;
+    int max_depth = intra ? d->th_intra + nxn : d->th_inter;
+    int split;
+    if (log2n <= d->log2_max_tb && log2n > d->log2_min_tb && depth < max_depth && !(nxn && depth == 0))
+        split = cb_decision(c, CX_SPLIT_TU + 5 - log2n);
+    else
+        split = log2n > d->log2_max_tb || (nxn && depth == 0);
+    int cbf_cb = 0, cbf_cr = 0;
+    if (log2n > 2) {
+        if (depth == 0 || pcb) cbf_cb = cb_decision(c, CX_CBF_CHROMA + depth);
+        if (depth == 0 || pcr) cbf_cr = cb_decision(c, CX_CBF_CHROMA + depth);
+    } else { cbf_cb = pcb; cbf_cr = pcr; }
+    if (split) {
+        int h = 1 << (log2n - 1);
+        for (int k = 0; k < 4; k++)
+            if (transform_tree(d, x0 + (k & 1) * h, y0 + (k >> 1) * h, x0, y0, log2n - 1, depth + 1, k, intra, nxn, luma_modes, chroma_mode, cbf_cb, cbf_cr))
+                return -1;
+        return 0;
+    }
+    int cbf_luma = 1;
+    if (intra || depth != 0 || cbf_cb || cbf_cr) cbf_luma = cb_decision(c, CX_CBF_LUMA + (depth == 0 ? 1 : 0));
+    int16_t lvl[32 * 32];
+    orc_cu_rec *r = cu_at(d, x0, y0);
+    int lmode = intra ? luma_modes[nxn ? blk : 0] : 1;
+    /* luma */
+    if (intra) intra_predict_block(d, 0, x0, y0, log2n, lmode);
+    if (cbf_luma) {
+        if (residual_coding(d, log2n, 0, intra ? intra_scan_idx(log2n, 0, lmode) : 0, lvl)) return -1;
+        add_residual(d, 0, x0, y0, log2n, lvl, d->slice_qp, intra && log2n == 2);
+        if (nxn) r->cbf_y4 |= (uint8_t)(1 << blk); else r->flags |= ORC_F_CBF_Y;
+        if (nxn) r->flags |= ORC_F_CBF_Y;
+    }
+    /* chroma: with the luma TU unless luma is 4x4, then once after blkIdx 3 at the parent position */
+    int do_chroma = log2n > 2 || blk == 3;
+    if (do_chroma) {
+        int xc = (log2n > 2 ? x0 : xb) >> 1, yc = (log2n > 2 ? y0 : yb) >> 1, l2c = log2n > 2 ? log2n - 1 : 2;
+        int qpc = orc_chroma_qp(d->slice_qp);
+        for (int ci = 1; ci < 3; ci++) {
+            int cbf = ci == 1 ? cbf_cb : cbf_cr;
+            if (intra) intra_predict_block(d, ci, xc, yc, l2c, chroma_mode);
+            if (cbf) {
+                if (residual_coding(d, l2c, ci, intra ? intra_scan_idx(l2c, ci, chroma_mode) : 0, lvl)) return -1;
+                add_residual(d, ci, xc, yc, l2c, lvl, qpc, 0);
+                cu_at(d, log2n > 2 ? x0 : xb, log2n > 2 ? y0 : yb)->flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
+            }
+        }
+    }
+    return 0;
+}
+
+/* spec-literal motion compensation with coordinate clamping — 8.5.3.3.3.1 */
+static const int8_t kLT[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+static const int8_t kCT[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+static void mc_block(orc_decoder *d, const picture *ref, int c_idx, int x, int y, int n, int mvx, int mvy)
+{
+    int chroma = c_idx != 0, taps = chroma ? 4 : 8, half = chroma ? 1 : 3;
+    int w = chroma ? d->w / 2 : d->w, h = chroma ? d->h / 2 : d->h;
+    int fx = chroma ? mvx & 7 : mvx & 3, fy = chroma ? mvy & 7 : mvy & 3;
+    int xi = x + (chroma ? mvx >> 3 : mvx >> 2), yi = y + (chroma ? mvy >> 3 : mvy >> 2);
+    int shift1 = d->bit_depth - 8 < 4 ? d->bit_depth - 8 : 4, shift3 = 14 - d->bit_depth, maxv = (1 << d->bit_depth) - 1;
+    const pix *rp = ref->pl[c_idx]; int rs = ref->stride[c_idx];
+    pix *dp = d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x;
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            int v;
+#define RS(xx, yy) rp[(size_t)CLIP3(0, h - 1, (yy)) * rs + CLIP3(0, w - 1, (xx))]
+#define TAP(f, k) (chroma ? kCT[f][k] : kLT[f][k])
+            if (!fx && !fy) v = RS(xi + i, yi + j) << shift3;
+            else if (!fy) { int a = 0; for (int k = 0; k < taps; k++) a += TAP(fx, k) * RS(xi + i + k - half, yi + j); v = a >> shift1; }
+            else if (!fx) { int a = 0; for (int k = 0; k < taps; k++) a += TAP(fy, k) * RS(xi + i, yi + j + k - half); v = a >> shift1; }
+            else {
+                int a = 0;
+                for (int r = 0; r < taps; r++) {
+                    int t = 0;
+                    for (int k = 0; k < taps; k++) t += TAP(fx, k) * RS(xi + i + k - half, yi + j + r - half);
+                    a += TAP(fy, r) * (t >> shift1);
+                }
+                v = a >> 6;
+            }
+#undef RS
+#undef TAP
+            v = (v + (1 << (shift3 - 1))) >> shift3;
+            dp[j * d->cur.stride[c_idx] + i] = (pix)CLIP3(0, maxv, v);
+        }
+}
+
+typedef struct { int ok, mvx, mvy; } mvcand;
+static mvcand nb_motion(orc_decoder *d, int xc, int yc, int xn, int yn)
+{
+    mvcand m = {0, 0, 0};
+    if (!avail_z(d, xc, yc, xn, yn)) return m;
+    const orc_cu_rec *r = cu_at(d, xn, yn);
+    if (!(r->flags & ORC_F_INTER)) return m;
+    m.ok = 1; m.mvx = r->mvx; m.mvy = r->mvy;
+    return m;
+}
+/* 8.5.3.2.2-.5 merge candidates (spatial + zero; P slices, one reference) */
+static void merge_list(orc_decoder *d, int x, int y, int n, mvcand out[5])
+{
+    mvcand a1 = nb_motion(d, x, y, x - 1, y + n - 1), b1 = nb_motion(d, x, y, x + n - 1, y - 1);
+    mvcand b0 = nb_motion(d, x, y, x + n, y - 1), a0 = nb_motion(d, x, y, x - 1, y + n), b2 = nb_motion(d, x, y, x - 1, y - 1);
+    /* pruning compares against the neighbour's raw availability, not its post-pruning flag (8.5.3.2.3) */
+#define SAME(p, q) ((p).ok && (q).ok && (p).mvx == (q).mvx && (p).mvy == (q).mvy)
+    int fa1 = a1.ok, fb1 = b1.ok && !SAME(b1, a1), fb0 = b0.ok && !SAME(b0, b1), fa0 = a0.ok && !SAME(a0, a1);
+    int fb2 = b2.ok && !SAME(b2, a1) && !SAME(b2, b1) && (fa0 + fa1 + fb0 + fb1 != 4);
+#undef SAME
+    a1.ok = fa1; b1.ok = fb1; b0.ok = fb0; a0.ok = fa0; b2.ok = fb2;
+    int k = 0;
+    mvcand order[5] = {a1, b1, b0, a0, b2};
+    for (int i = 0; i < 5 && k < d->max_merge; i++) if (order[i].ok) out[k++] = order[i];
+    while (k < 5) { out[k].ok = 1; out[k].mvx = 0; out[k].mvy = 0; k++; }
+}
+/* 8.5.3.2.6-.7 AMVP candidates (spatial; one reference so no scaling) */
+static void amvp_list(orc_decoder *d, int x, int y, int n, mvcand out[2])
+{
+    mvcand a0 = nb_motion(d, x, y, x - 1, y + n), a1 = nb_motion(d, x, y, x - 1, y + n - 1);
+    mvcand b0 = nb_motion(d, x, y, x + n, y - 1), b1 = nb_motion(d, x, y, x + n - 1, y - 1), b2 = nb_motion(d, x, y, x - 1, y - 1);
+    int scaled = a0.ok || a1.ok;   /* 6.4.2 availability already excludes intra neighbours */
+    mvcand a = a0.ok ? a0 : a1, b = b0.ok ? b0 : b1.ok ? b1 : b2;
+    if (!scaled && b.ok) a = b;
+    int k = 0;
+    if (a.ok) out[k++] = a;
+    if (b.ok && !(a.ok && a.mvx == b.mvx && a.mvy == b.mvy)) out[k++] = b;
+    while (k < 2) { out[k].ok = 1; out[k].mvx = 0; out[k].mvy = 0; k++; }
+}
+
+static int read_mvd(cabac *c, int *dx, int *dy)
+{
+    int g0x = cb_decision(c, CX_MVD0), g0y = cb_decision(c, CX_MVD0), g1x = 0, g1y = 0;
+    if (g0x) g1x = cb_decision(c, CX_MVD1);
+    if (g0y) g1y = cb_decision(c, CX_MVD1);
+    int v[2] = {0, 0}, g0[2] = {g0x, g0y}, g1[2] = {g1x, g1y};
+    for (int i = 0; i < 2; i++) {
+        if (!g0[i]) continue;
+        int a = 1;
+        if (g1[i]) { int k = 1, r = 0; while (cb_bypass(c)) { r += 1 << k; k++; if (k > 20) return -1; } r += (int)cb_bypass_n(c, k); a = r + 2; }
+        v[i] = cb_bypass(c) ? -a : a;
+    }
+    *dx = v[0]; *dy = v[1];
+    return 0;
+}
+
+static int coding_unit(orc_decoder *d, int x0, int y0, int log2n)
+{
+    cabac *c = &d->cb;
+    int n = 1 << log2n, w8 = d->w >> 3;
+    int skip = 0, intra = d->slice_type == 2, nxn = 0, merge = 0, merge_idx = 0;
+    orc_cu_rec rec;
+    memset(&rec, 0, sizeof rec);
+    rec.log2_size = (uint8_t)log2n; rec.qp = (uint8_t)d->slice_qp;
+    if (d->slice_type != 2) {
+        int l = avail_z(d, x0, y0, x0 - 1, y0) && d->skip8[(y0 >> 3) * w8 + ((x0 - 1) >> 3)];
+        int a = avail_z(d, x0, y0, x0, y0 - 1) && d->skip8[((y0 - 1) >> 3) * w8 + (x0 >> 3)];
+        skip = cb_decision(c, CX_SKIP + l + a);
+    }
+    const picture *ref = NULL;
+    if (d->slice_type != 2) {
+        for (int i = 0; i < d->n_pics; i++) if (d->pics[i].poc == d->poc - 1) ref = &d->pics[i];
+        if (!ref) { set_err(d, "P slice without its reference picture (poc %d)", d->poc - 1); return -1; }
+    }
+    uint8_t lmodes[4] = {1, 1, 1, 1};
+    int chroma_mode = 1;
+    if (skip) {
+        merge = 1;
+        if (d->max_merge > 1) { while (merge_idx < d->max_merge - 1 && (merge_idx == 0 ? cb_decision(c, CX_MERGE_IDX) : cb_bypass(c))) merge_idx++; }
+    } else {
+        if (d->slice_type != 2) intra = cb_decision(c, CX_PRED_MODE);
+        if (!intra || log2n == d->log2_min_cb) {
+            int bin = cb_decision(c, CX_PART_MODE);
+            if (intra) nxn = !bin;
+            else if (!bin) { set_err(d, "inter part_mode != 2Nx2N unsupported"); return -1; }
+        }
+        if (intra) {
+            int parts = nxn ? 4 : 1, pn = nxn ? n / 2 : n;
+            int prev[4], mpm_idx[4], rem[4];
+            for (int k = 0; k < parts; k++) prev[k] = cb_decision(c, CX_PREV_INTRA);
+            for (int k = 0; k < parts; k++) {
+                mpm_idx[k] = rem[k] = 0;
+                if (prev[k]) { if (cb_bypass(c)) mpm_idx[k] = 1 + cb_bypass(c); }
+                else rem[k] = (int)cb_bypass_n(c, 5);
+            }
+            int cm = 4;
+            for (int k = 0; k < parts; k++) {
+                int xp = x0 + (k & 1) * pn, yp = y0 + (k >> 1) * pn;
+                /* 8.4.2 */
+                int ca = 1, cbm = 1;
+                if (avail_z(d, xp, yp, xp - 1, yp)) {
+                    const orc_cu_rec *r = (xp - 1 >= x0 && yp >= y0) ? &rec : cu_at(d, xp - 1, yp);
+                    if (!(r->flags & ORC_F_INTER)) ca = (xp - 1 >= x0 && yp >= y0) ? lmodes[(k & 2) | 0] : r->intra_mode[r->flags & ORC_F_NXN ? ((((yp) >> 2) & 1) * 2 + 1) : 0];
+                }
+                if (avail_z(d, xp, yp, xp, yp - 1) && ((yp - 1) >> d->log2_ctb) == (yp >> d->log2_ctb)) {
+                    const orc_cu_rec *r = (yp - 1 >= y0 && xp >= x0) ? &rec : cu_at(d, xp, yp - 1);
+                    if (!(r->flags & ORC_F_INTER)) cbm = (yp - 1 >= y0 && xp >= x0) ? lmodes[k & 1] : r->intra_mode[r->flags & ORC_F_NXN ? (2 + (((xp) >> 2) & 1)) : 0];
+                }
+                int cand[3];
+                if (ca == cbm) {
+                    if (ca < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+                    else { cand[0] = ca; cand[1] = 2 + ((ca + 29) & 31); cand[2] = 2 + ((ca - 2 + 1) & 31); }
+                } else { cand[0] = ca; cand[1] = cbm; cand[2] = (ca != 0 && cbm != 0) ? 0 : (ca != 1 && cbm != 1) ? 1 : 26; }
+                int mode;
+                if (prev[k]) mode = cand[mpm_idx[k]];
+                else {
+                    if (cand[0] > cand[1]) { int t = cand[0]; cand[0] = cand[1]; cand[1] = t; }
+                    if (cand[0] > cand[2]) { int t = cand[0]; cand[0] = cand[2]; cand[2] = t; }
+                    if (cand[1] > cand[2]) { int t = cand[1]; cand[1] = cand[2]; cand[2] = t; }
+                    mode = rem[k];
+                    for (int i = 0; i < 3; i++) if (mode >= cand[i]) mode++;
+                }
+                lmodes[k] = (uint8_t)mode;
+                if (!nxn) lmodes[1] = lmodes[2] = lmodes[3] = (uint8_t)mode;
+            }
+            if (cb_decision(c, CX_CHROMA_MODE)) cm = (int)cb_bypass_n(c, 2);
+            static const uint8_t cmap[4] = {0, 26, 10, 1};
+            if (cm == 4) chroma_mode = lmodes[0];
+            else { chroma_mode = cmap[cm]; if (chroma_mode == lmodes[0]) chroma_mode = 34; }
+        } else {
+            merge = cb_decision(c, CX_MERGE_FLAG);
+            if (merge) { if (d->max_merge > 1) while (merge_idx < d->max_merge - 1 && (merge_idx == 0 ? cb_decision(c, CX_MERGE_IDX) : cb_bypass(c))) merge_idx++; }
+        }
+    }
+    rec.flags = (uint8_t)((intra ? 0 : ORC_F_INTER) | (nxn ? ORC_F_NXN : 0));
+    memcpy(rec.intra_mode, lmodes, 4); rec.chroma_mode = (uint8_t)chroma_mode;
+    if (!intra) {
+        int mvx, mvy;
+        if (merge) { mvcand l[5]; merge_list(d, x0, y0, n, l); mvx = l[merge_idx].mvx; mvy = l[merge_idx].mvy; }
+        else {
+            int dx, dy;
+            if (read_mvd(c, &dx, &dy)) { set_err(d, "mvd escape too long"); return -1; }
+            int flag = cb_decision(c, CX_MVP);
+            mvcand l[2]; amvp_list(d, x0, y0, n, l);
+            mvx = l[flag].mvx + dx; mvy = l[flag].mvy + dy;
+        }
+        rec.mvx = (int16_t)mvx; rec.mvy = (int16_t)mvy;
+        mc_block(d, ref, 0, x0, y0, n, mvx, mvy);
+        mc_block(d, ref, 1, x0 >> 1, y0 >> 1, n >> 1, mvx, mvy);
+        mc_block(d, ref, 2, x0 >> 1, y0 >> 1, n >> 1, mvx, mvy);
+    }
+    for (int yy = 0; yy < n; yy += 8)
+        for (int xx = 0; xx < n; xx += 8) { *cu_at(d, x0 + xx, y0 + yy) = rec; d->skip8[((y0 + yy) >> 3) * w8 + ((x0 + xx) >> 3)] = (uint8_t)skip; }
+    int root_cbf = 1;
+    if (skip) root_cbf = 0;
+    else if (!intra && !merge) root_cbf = cb_decision(c, CX_RQT_ROOT);   /* merge 2Nx2N: inferred 1 (7.3.8.5) */
+    if (root_cbf) {
+        if (transform_tree(d, x0, y0, x0, y0, log2n, 0, 0, intra, nxn, lmodes, chroma_mode, 0, 0)) return -1;
+        orc_cu_rec *first = cu_at(d, x0, y0);
+        for (int yy = 0; yy < n; yy += 8)
+            for (int xx = 0; xx < n; xx += 8) { orc_cu_rec *r = cu_at(d, x0 + xx, y0 + yy); r->flags = first->flags; r->cbf_y4 = first->cbf_y4; }
+    }
+    return c->err ? -1 : 0;
+}
+
+static int coding_quadtree(orc_decoder *d, int x0, int y0, int log2n, int depth)
+{
+    int n = 1 << log2n, split, w8 = d->w >> 3;
+    if (x0 + n <= d->w && y0 + n <= d->h && log2n > d->log2_min_cb) {
+        int l = avail_z(d, x0, y0, x0 - 1, y0) && d->depth8[(y0 >> 3) * w8 + ((x0 - 1) >> 3)] > depth;
+        int a = avail_z(d, x0, y0, x0, y0 - 1) && d->depth8[((y0 - 1) >> 3) * w8 + (x0 >> 3)] > depth;
+        split = cb_decision(&d->cb, CX_SPLIT_CU + l + a);
+    } else split = log2n > d->log2_min_cb;
+    if (split) {
+        int h = n >> 1;
+        for (int k = 0; k < 4; k++) {
+            int x1 = x0 + (k & 1) * h, y1 = y0 + (k >> 1) * h;
+            if (x1 < d->w && y1 < d->h && coding_quadtree(d, x1, y1, log2n - 1, depth + 1)) return -1;
+        }
+        return 0;
+    }
+    for (int yy = 0; yy < n; yy += 8)
+        for (int xx = 0; xx < n; xx += 8) d->depth8[((y0 + yy) >> 3) * w8 + ((x0 + xx) >> 3)] = (uint8_t)depth;
+    return coding_unit(d, x0, y0, log2n);
+}
+
+/* 7.3.8.3 sao() */
+static void parse_sao(orc_decoder *d, int rx, int ry)
+{
+    cabac *c = &d->cb;
+    int wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2;
+    orc_sao_ctu *o = &d->sao[ry * wc + rx];
+    memset(o, 0, sizeof *o);
+    if (rx > 0 && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[ry * wc + rx - 1]; goto mask; }
+    if (ry > 0 && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[(ry - 1) * wc + rx]; goto mask; }
+    for (int ci = 0; ci < 3; ci++) {
+        if ((ci == 0 && !d->sao_luma) || (ci > 0 && !d->sao_chroma)) continue;
+        int t = ci ? 1 : 0;
+        if (ci < 2) { o->type[t] = 0; if (cb_decision(c, CX_SAO_TYPE)) o->type[t] = (uint8_t)(cb_bypass(c) ? 2 : 1); }
+        if (!o->type[t]) continue;
+        int a[4], cmax = (1 << ((d->bit_depth < 10 ? d->bit_depth : 10) - 5)) - 1;
+        for (int i = 0; i < 4; i++) { a[i] = 0; while (a[i] < cmax && cb_bypass(c)) a[i]++; }
+        if (o->type[t] == 1) {
+            for (int i = 0; i < 4; i++) if (a[i] && cb_bypass(c)) a[i] = -a[i];
+            o->band_pos[ci] = (uint8_t)cb_bypass_n(c, 5);
+        } else {
+            if (ci == 0) o->eo_class[0] = (uint8_t)cb_bypass_n(c, 2);
+            if (ci == 1) o->eo_class[1] = (uint8_t)cb_bypass_n(c, 2);
+            a[2] = -a[2]; a[3] = -a[3];
+        }
+        for (int i = 0; i < 4; i++) o->offset[ci][i] = (int8_t)a[i];
+    }
+mask:
+    if (!d->sao_luma) o->type[0] = 0;
+    if (!d->sao_chroma) o->type[1] = 0;
+}
+
+static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_type)
+{
+    if (!d->have_sps || !d->have_pps) { set_err(d, "slice before parameter sets"); return -1; }
+    bitrd b = {rbsp, n, 0, 0};
+    if (!br_bit(&b)) { set_err(d, "multiple slice segments unsupported"); return -1; }
+    int irap = nal_type >= 16 && nal_type <= 23, idr = nal_type == 19 || nal_type == 20;
+    if (irap) br_bit(&b);
+    if (br_ue(&b)) { set_err(d, "slice: pps id"); return -1; }
+    d->slice_type = (int)br_ue(&b);
+    if (d->slice_type == 0) { set_err(d, "B slices unsupported"); return -1; }
+    d->poc = 0;
+    if (!idr) {
+        int lsb = (int)br_u(&b, d->poc_bits);
+        int prev = d->n_pics ? d->pics[d->n_pics - 1].poc : 0;   /* all pictures are reference pictures at TemporalId 0 */
+        int maxl = 1 << d->poc_bits, prev_lsb = prev & (maxl - 1), prev_msb = prev - prev_lsb, msb;
+        if (lsb < prev_lsb && prev_lsb - lsb >= maxl / 2) msb = prev_msb + maxl;
+        else if (lsb > prev_lsb && lsb - prev_lsb > maxl / 2) msb = prev_msb - maxl;
+        else msb = prev_msb;
+        d->poc = msb + lsb;
+        if (!br_bit(&b)) { set_err(d, "slice: explicit RPS unsupported"); return -1; }
+        if (d->num_strps > 1) { int nb = 0; while ((1 << nb) < d->num_strps) nb++; d->ref_idx = (int)br_u(&b, nb); } else d->ref_idx = 0;
+        if (d->strps_neg[d->ref_idx] != 1 || d->strps_delta[d->ref_idx][0] != -1) { set_err(d, "slice: RPS is not {-1}"); return -1; }
+    }
+    d->sao_luma = d->sao_chroma = 0;
+    if (d->sao_on) { d->sao_luma = br_bit(&b); d->sao_chroma = br_bit(&b); }
+    d->max_merge = 5;
+    if (d->slice_type != 2) {
+        if (br_bit(&b)) { set_err(d, "slice: num_ref_idx override"); return -1; }
+        d->max_merge = 5 - (int)br_ue(&b);
+    }
+    d->slice_qp = d->init_qp + br_se(&b);
+    if (d->lf_across) br_bit(&b);      /* slice_loop_filter_across_slices_enabled_flag: deblocking is on, so present */
+    if (!br_bit(&b)) { set_err(d, "slice: byte_alignment bit"); return -1; }
+    while (b.pos & 7) if (br_bit(&b)) { set_err(d, "slice: alignment zero bits"); return -1; }
+    if (b.err) { set_err(d, "slice header truncated"); return -1; }
+    put_kv(d, "slice.last_qp", d->slice_qp); put_kv(d, "slice.last_type", d->slice_type); put_kv(d, "slice.max_merge", d->max_merge);
+
+    if (idr) { for (int i = 0; i < d->n_pics; i++) d->pics[i].poc = -1000000 - i; }  /* IDR: earlier pictures leave the DPB */
+    int w8 = d->w >> 3, h8 = d->h >> 3, wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2, hc = (d->h + ORC_CTU - 1) >> ORC_CTU_LOG2;
+    if (!d->cu) {
+        d->cu = (orc_cu_rec *)calloc((size_t)w8 * h8, sizeof(orc_cu_rec));
+        d->depth8 = (uint8_t *)calloc((size_t)w8 * h8, 1); d->skip8 = (uint8_t *)calloc((size_t)w8 * h8, 1);
+        d->sao = (orc_sao_ctu *)calloc((size_t)wc * hc, sizeof(orc_sao_ctu));
+    }
+    memset(d->cu, 0, sizeof(orc_cu_rec) * w8 * h8); memset(d->depth8, 0, (size_t)w8 * h8); memset(d->skip8, 0, (size_t)w8 * h8);
+    memset(d->sao, 0, sizeof(orc_sao_ctu) * wc * hc);
+    alloc_pic(d, &d->cur); d->cur_valid = 1; d->cur.poc = d->poc;
+    build_scans();
+    cb_init(&d->cb, rbsp + (b.pos >> 3), n - (b.pos >> 3), d->slice_type == 2 ? 0 : 1, d->slice_qp);
+    int ok = -1;
+    for (int ry = 0; ry < hc; ry++)
+        for (int rx = 0; rx < wc; rx++) {
+            if (d->sao_luma || d->sao_chroma) parse_sao(d, rx, ry);
+            if (coding_quadtree(d, rx << ORC_CTU_LOG2, ry << ORC_CTU_LOG2, ORC_CTU_LOG2, 0)) goto done;
+            int end = cb_terminate(&d->cb);
+            int last = ry == hc - 1 && rx == wc - 1;
+            if (end != last) { set_err(d, "end_of_slice_segment_flag=%d at ctu (%d,%d)", end, rx, ry); goto done;}
+        }
+    if (d->cb.err) { set_err(d, "slice data truncated"); goto done; }
+    /* in-loop filters, then the picture becomes a reference */
+    orc_deblock_frame(d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1], d->w, d->h, d->cu, d->bit_depth, d->cb_off);
+    if (d->sao_luma || d->sao_chroma) {
+        picture out; memset(&out, 0, sizeof out); alloc_pic(d, &out); out.poc = d->poc;
+        orc_sao_apply_frame(d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1],
+                            out.pl[0], out.pl[1], out.pl[2], out.stride[0], out.stride[1], d->w, d->h, d->bit_depth, d->sao);
+        free_pic(&d->cur); d->cur = out;
+    }
+    if (d->n_pics == d->cap_pics) { d->cap_pics = d->cap_pics ? d->cap_pics * 2 : 16; d->pics = (picture *)realloc(d->pics, sizeof(picture) * d->cap_pics); }
+    d->pics[d->n_pics++] = d->cur; d->cur_valid = 0;
+    ok = 0;
+done:
+    if (d->cur_valid) { free_pic(&d->cur); d->cur_valid = 0; }
+    return ok;
+}
+
+int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
+{
+    size_t i = 0;
+    int n_aud = 0, n_slices = 0;
+    uint8_t *rbsp = (uint8_t *)malloc(size + 8);
+    while (i + 3 < size) {
+        /* find start code */
+        if (!(data[i] == 0 && data[i + 1] == 0 && data[i + 2] == 1)) { i++; continue; }
+        size_t s = i + 3, e = s;
+        while (e + 2 < size && !(data[e] == 0 && data[e + 1] == 0 && (data[e + 2] == 1 || (data[e + 2] == 0 && e + 3 < size && data[e + 3] == 1)))) e++;
+        if (e + 2 >= size) e = size;
+        /* NAL header + emulation prevention removal (7.3.1.1) */
+        if (e - s < 2) { set_err(d, "short NAL"); break; }
+        if (data[s] & 0x80) { set_err(d, "forbidden_zero_bit"); break; }
+        int type = (data[s] >> 1) & 63, tid = data[s + 1] & 7;
+        if (tid != 1 || ((data[s] & 1) << 5 | data[s + 1] >> 3) != 0) { set_err(d, "nuh layer/temporal id"); break; }
+        size_t m = 0; int zeros = 0;
+        for (size_t k = s + 2; k < e; k++) {
+            if (zeros >= 2 && data[k] == 3) { zeros = 0; continue; }
+            if (zeros >= 2 && data[k] < 3) { set_err(d, "start-code emulation inside NAL type %d", type); goto out; }
+            rbsp[m++] = data[k];
+            zeros = data[k] == 0 ? zeros + 1 : 0;
+        }
+        bitrd b = {rbsp, m, 0, 0};
+        int rc = 0;
+        if (type == 32) rc = parse_vps(d, &b);
+        else if (type == 33) rc = parse_sps(d, &b);
+        else if (type == 34) rc = parse_pps(d, &b);
+        else if (type == 35) { n_aud++; put_kv(d, "aud.last_pic_type", br_u(&b, 3)); if (!br_trailing_ok(&b)) { set_err(d, "aud trailing"); rc = -1; } }
+        else if (type == 39 || type == 40) rc = parse_sei(d, &b);
+        else if (type == 1 || type == 19 || type == 20) { rc = decode_slice(d, rbsp, m, type); n_slices++; }
+        else { set_err(d, "unsupported NAL type %d", type); rc = -1; }
+        if (rc) break;
+        i = e;
+    }
+out:
+    free(rbsp);
+    put_kv(d, "count.aud", n_aud); put_kv(d, "count.slices", n_slices);
+    return d->err[0] ? -1 : d->n_pics;
+}

@@ -1,0 +1,991 @@
+/* oracle/hevc_oracle.c — TEST INFRASTRUCTURE, NOT PRODUCT (see hevc_oracle.h for scope and pinning).
+ *
+ * Scalar restatement of the per-CTU encode loop the reference obtains from libx265
+ * (reference call sites: core/transcoder.py:398-412 operating point, :463 `-c:v`, :506 spawn).
+ * Normative parts cite their H.265 clause; encoder-side choices are defined here and mirrored by
+ * hevc_amd/csrc/kernels/*.hip.  PARITY UNPINNED vs libx265 (no golden vectors exist; see header).
+ */
+#include "hevc_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define CLIP3(lo, hi, v) ((v) < (lo) ? (lo) : (v) > (hi) ? (hi) : (v))
+static inline int iabs(int v) { return v < 0 ? -v : v; }
+static inline int ilog2u(unsigned v) { int r = 0; while (v >>= 1) r++; return r; }
+
+/* ------------------------------------------------------------------------------------------------
+ * Transform matrices — H.265 8.6.4.2 (transMatrix) generated from the 32 unique cosine magnitudes.
+ * ------------------------------------------------------------------------------------------------ */
+static const int16_t kCos64[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+                                   61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+static int16_t g_mat32[32][32];
+static int g_mat_ready;
+static const int16_t kDst4[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+
+static void build_matrix(void)
+{
+    if (g_mat_ready) return;
+    for (int k = 0; k < 32; k++)
+        for (int n = 0; n < 32; n++) {
+            int t = (k * (2 * n + 1)) % 128; /* angle in units of pi/64 */
+            if (t > 64) t = 128 - t;
+            g_mat32[k][n] = (int16_t)(t > 32 ? -kCos64[64 - t] : kCos64[t]);
+        }
+    g_mat_ready = 1;
+}
+void orc_transform_matrix(int16_t *out)
+{
+    build_matrix();
+    memcpy(out, g_mat32, sizeof g_mat32);
+}
+static inline int mat(int log2n, int dst, int k, int n)
+{
+    if (dst) return kDst4[k][n];
+    return g_mat32[k << (5 - log2n)][n];
+}
+
+/* Forward transform (encoder side; the conventional two-stage integer form):
+ * stage 1 horizontal, shift log2N + bitDepth - 9; stage 2 vertical, shift log2N + 6. */
+void orc_fwd_transform(const int16_t *res, int rstride, int16_t *coef, int log2n, int dst, int bit_depth)
+{
+    build_matrix();
+    int n = 1 << log2n, s1 = log2n + bit_depth - 9, s2 = log2n + 6;
+    int32_t tmp[32 * 32];
+    for (int y = 0; y < n; y++)
+        for (int u = 0; u < n; u++) {
+            int64_t acc = 0;
+            for (int x = 0; x < n; x++) acc += mat(log2n, dst, u, x) * res[y * rstride + x];
+            tmp[y * n + u] = (int32_t)(s1 > 0 ? (acc + (1 << (s1 - 1))) >> s1 : acc);
+        }
+    for (int v = 0; v < n; v++)
+        for (int u = 0; u < n; u++) {
+            int64_t acc = 0;
+            for (int y = 0; y < n; y++) acc += (int64_t)mat(log2n, dst, v, y) * tmp[y * n + u];
+            acc = (acc + (1 << (s2 - 1))) >> s2;
+            coef[v * n + u] = (int16_t)CLIP3(-32768, 32767, acc);
+        }
+}
+
+/* Inverse transform — H.265 8.6.4.2: columns first (shift 7, clip to 16 bit), then rows (shift 20 - bitDepth). */
+void orc_inv_transform(const int16_t *coef, int16_t *res, int rstride, int log2n, int dst, int bit_depth)
+{
+    build_matrix();
+    int n = 1 << log2n, s2 = 20 - bit_depth;
+    int32_t g[32 * 32];
+    for (int x = 0; x < n; x++)
+        for (int y = 0; y < n; y++) {
+            int64_t acc = 0;
+            for (int j = 0; j < n; j++) acc += mat(log2n, dst, j, y) * coef[j * n + x];
+            acc = (acc + 64) >> 7;
+            g[y * n + x] = (int32_t)CLIP3(-32768, 32767, acc);
+        }
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            int64_t acc = 0;
+            for (int j = 0; j < n; j++) acc += (int64_t)mat(log2n, dst, j, x) * g[y * n + j];
+            res[y * rstride + x] = (int16_t)((acc + (1 << (s2 - 1))) >> s2);
+        }
+}
+
+static const int kQuantScale[6] = {26214, 23302, 20560, 18396, 16384, 14564};
+static const int kLevelScale[6] = {40, 45, 51, 57, 64, 72};
+
+/* Quantisation (encoder side): dead-zone rounding 171/512 (intra) or 85/512 (inter). Returns #nonzero. */
+int orc_quant(const int16_t *coef, int16_t *lvl, int log2n, int qp, int bit_depth, int intra)
+{
+    int q = qp + 6 * (bit_depth - 8);
+    int qbits = 14 + q / 6 + (15 - bit_depth - log2n);
+    int64_t add = (int64_t)(intra ? 171 : 85) << (qbits - 9);
+    int scale = kQuantScale[q % 6], nnz = 0, n2 = 1 << (2 * log2n);
+    for (int i = 0; i < n2; i++) {
+        int c = coef[i];
+        int64_t a = ((int64_t)iabs(c) * scale + add) >> qbits;
+        if (a > 32767) a = 32767;
+        lvl[i] = (int16_t)(c < 0 ? -a : a);
+        nnz += a != 0;
+    }
+    return nnz;
+}
+
+/* Scaling (dequantisation) — H.265 8.6.4.1 with flat m = 16. */
+void orc_dequant(const int16_t *lvl, int16_t *coef, int log2n, int qp, int bit_depth)
+{
+    int q = qp + 6 * (bit_depth - 8);
+    int bd_shift = bit_depth + log2n - 5;
+    int64_t scale = (int64_t)16 * kLevelScale[q % 6] << (q / 6);
+    int n2 = 1 << (2 * log2n);
+    for (int i = 0; i < n2; i++) {
+        int64_t v = (lvl[i] * scale + ((int64_t)1 << (bd_shift - 1))) >> bd_shift;
+        coef[i] = (int16_t)CLIP3(-32768, 32767, v);
+    }
+}
+
+/* Chroma QP mapping, ChromaArrayType == 1 — H.265 Table 8-10 (offsets 0). Input/outputs are syntax QPs. */
+int orc_chroma_qp(int qp_y)
+{
+    static const int8_t t[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+    int qpi = CLIP3(-12, 57, qp_y);
+    if (qpi < 30) return qpi;
+    if (qpi > 43) return qpi - 6;
+    return t[qpi - 30];
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Intra prediction — H.265 8.4.4.2
+ * ------------------------------------------------------------------------------------------------ */
+static inline int zorder6(int bx, int by) /* 3 bits each -> interleaved */
+{
+    int z = 0;
+    for (int i = 0; i < 3; i++) z |= ((bx >> i) & 1) << (2 * i) | ((by >> i) & 1) << (2 * i + 1);
+    return z;
+}
+/* z-scan address of the 4x4 luma unit containing (x,y) — 6.4.1 / 6.5.2 at min-TB granularity */
+static inline int zaddr(int x, int y, int pic_w)
+{
+    int wc = (pic_w + ORC_CTU - 1) >> ORC_CTU_LOG2;
+    int ctu = (y >> ORC_CTU_LOG2) * wc + (x >> ORC_CTU_LOG2);
+    return (ctu << 6) | zorder6((x & (ORC_CTU - 1)) >> 2, (y & (ORC_CTU - 1)) >> 2);
+}
+
+/* 8.4.4.2.2 reference sample availability + substitution.
+ * ref[0] = p[-1][2N-1] ... ref[2N-1] = p[-1][0], ref[2N] = p[-1][-1], ref[2N+1+x] = p[x][-1].
+ * (x0,y0), pic_w/h in units of the component's samples. avail_map is unused (z-order rule is applied). */
+void orc_intra_build_ref(const pix *rec, int stride, int x0, int y0, int log2n, int pic_w, int pic_h,
+                         const uint8_t *avail_map, int map_stride, int c_idx, int bit_depth, pix *ref)
+{
+    (void)avail_map; (void)map_stride;
+    int n = 1 << log2n, s = c_idx ? 1 : 0, total = 4 * n + 1;
+    int lw = pic_w << s;
+    int zc = zaddr(x0 << s, y0 << s, lw);
+    uint8_t av[4 * 32 + 1];
+    for (int i = 0; i < total; i++) {
+        int xn, yn;
+        if (i < 2 * n) { xn = x0 - 1; yn = y0 + 2 * n - 1 - i; }
+        else if (i == 2 * n) { xn = x0 - 1; yn = y0 - 1; }
+        else { xn = x0 + (i - 2 * n - 1); yn = y0 - 1; }
+        int ok = xn >= 0 && yn >= 0 && xn < pic_w && yn < pic_h && zaddr(xn << s, yn << s, lw) < zc;
+        av[i] = (uint8_t)ok;
+        ref[i] = ok ? rec[yn * stride + xn] : 0;
+    }
+    int first = -1;
+    for (int i = 0; i < total; i++) if (av[i]) { first = i; break; }
+    if (first < 0) {
+        for (int i = 0; i < total; i++) ref[i] = (pix)(1 << (bit_depth - 1));
+        return;
+    }
+    if (!av[0]) ref[0] = ref[first];
+    for (int i = 1; i < total; i++) if (!av[i]) ref[i] = ref[i - 1];
+}
+
+/* 8.4.4.2.3 filtering of neighbouring samples. Writes filt[] (copy when the filter is off). */
+void orc_intra_filter_ref(const pix *ref, pix *filt, int log2n, int mode, int c_idx, int bit_depth, int strong)
+{
+    int n = 1 << log2n, total = 4 * n + 1;
+    int on = 0;
+    if (c_idx == 0 && mode != 1 && n != 4) {
+        int d1 = iabs(mode - 26), d2 = iabs(mode - 10);
+        int dist = d1 < d2 ? d1 : d2;
+        int thr = n == 8 ? 7 : n == 16 ? 1 : 0;
+        on = dist > thr;
+    }
+    if (!on) { memcpy(filt, ref, total * sizeof(pix)); return; }
+    if (strong && n == 32) {
+        int thr = 1 << (bit_depth - 5);
+        int c = ref[64], a = ref[0], b = ref[128];
+        if (iabs(c + b - 2 * ref[96]) < thr && iabs(c + a - 2 * ref[32]) < thr) {
+            filt[0] = ref[0]; filt[64] = ref[64]; filt[128] = ref[128];
+            for (int i = 1; i < 64; i++) filt[i] = (pix)((i * c + (64 - i) * a + 32) >> 6);
+            for (int x = 0; x < 63; x++) filt[65 + x] = (pix)(((63 - x) * c + (x + 1) * b + 32) >> 6);
+            return;
+        }
+    }
+    filt[0] = ref[0]; filt[total - 1] = ref[total - 1];
+    for (int i = 1; i < total - 1; i++) filt[i] = (pix)((ref[i - 1] + 2 * ref[i] + ref[i + 1] + 2) >> 2);
+}
+
+static const int8_t kIntraAngle[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32,
+                                       -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
+static const int16_t kInvAngle[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+
+/* 8.4.4.2.4 planar, .5 DC, .6 angular. `ref` is the (already filtered where applicable) 4N+1 array. */
+void orc_intra_pred(const pix *ref, pix *dst, int dstride, int log2n, int mode, int c_idx, int bit_depth)
+{
+    int n = 1 << log2n, maxv = (1 << bit_depth) - 1;
+    const pix *left = ref + 2 * n - 1; /* left[-y] = p[-1][y] */
+    const pix *top = ref + 2 * n + 1;  /* top[x]  = p[x][-1] ; top[-1] = corner */
+#define PL(y) left[-(y)]
+#define PT(x) top[(x)]
+    if (mode == 0) {
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++)
+                dst[y * dstride + x] = (pix)(((n - 1 - x) * PL(y) + (x + 1) * PT(n) + (n - 1 - y) * PT(x) + (y + 1) * PL(n) + n) >> (log2n + 1));
+        return;
+    }
+    if (mode == 1) {
+        int sum = n;
+        for (int i = 0; i < n; i++) sum += PT(i) + PL(i);
+        int dc = sum >> (log2n + 1);
+        for (int y = 0; y < n; y++)
+            for (int x = 0; x < n; x++) dst[y * dstride + x] = (pix)dc;
+        if (c_idx == 0 && n < 32) {
+            dst[0] = (pix)((PL(0) + 2 * dc + PT(0) + 2) >> 2);
+            for (int x = 1; x < n; x++) dst[x] = (pix)((PT(x) + 3 * dc + 2) >> 2);
+            for (int y = 1; y < n; y++) dst[y * dstride] = (pix)((PL(y) + 3 * dc + 2) >> 2);
+        }
+        return;
+    }
+    int angle = kIntraAngle[mode];
+    int vertical = mode >= 18;
+    pix buf[3 * 32 + 1];
+    pix *r = buf + 32; /* r[-n .. 2n] */
+    /* main reference: for vertical modes the top row, else the left column; side = the other one */
+    for (int i = 0; i <= n; i++) r[i] = vertical ? top[i - 1] : left[-(i - 1)];
+    if (angle < 0) {
+        int last = (n * angle) >> 5;
+        if (last < -1) {
+            int inv = kInvAngle[mode - 11];
+            for (int i = -1; i >= last; i--) {
+                int k = -1 + ((i * inv + 128) >> 8);
+                r[i] = vertical ? left[-k] : top[k];
+            }
+        }
+    } else {
+        for (int i = n + 1; i <= 2 * n; i++) r[i] = vertical ? top[i - 1] : left[-(i - 1)];
+    }
+    for (int a = 0; a < n; a++) {       /* a: along the prediction direction (y for vertical, x for horizontal) */
+        int idx = ((a + 1) * angle) >> 5, f = ((a + 1) * angle) & 31;
+        for (int b = 0; b < n; b++) {
+            int v = f ? ((32 - f) * r[b + idx + 1] + f * r[b + idx + 2] + 16) >> 5 : r[b + idx + 1];
+            if (vertical) dst[a * dstride + b] = (pix)v; else dst[b * dstride + a] = (pix)v;
+        }
+    }
+    if (angle == 0 && c_idx == 0 && n < 32) {   /* modes 26 / 10 edge filter */
+        int corner = top[-1];
+        if (vertical)
+            for (int y = 0; y < n; y++) { int v = PT(0) + ((PL(y) - corner) >> 1); dst[y * dstride] = (pix)CLIP3(0, maxv, v); }
+        else
+            for (int x = 0; x < n; x++) { int v = PL(0) + ((PT(x) - corner) >> 1); dst[x] = (pix)CLIP3(0, maxv, v); }
+    }
+#undef PL
+#undef PT
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Inter prediction sample interpolation — H.265 8.5.3.3.3 (+ default weighted prediction 8.5.3.3.4.2, uni-pred)
+ * ------------------------------------------------------------------------------------------------ */
+static const int8_t kLumaTap[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+static const int8_t kChromaTap[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+
+void orc_interp_luma(const pix *ref, int rstride, int x, int y, int mvx, int mvy, int w, int h, int bit_depth,
+                     pix *dst, int dstride)
+{
+    int fx = mvx & 3, fy = mvy & 3, xi = x + (mvx >> 2), yi = y + (mvy >> 2);
+    int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
+    int off = 1 << (shift3 - 1);
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const pix *p = ref + (yi + j) * rstride + xi + i;
+            int v;
+            if (!fx && !fy) v = p[0] << shift3;
+            else if (!fy) { int a = 0; for (int k = 0; k < 8; k++) a += kLumaTap[fx][k] * p[k - 3]; v = a >> shift1; }
+            else if (!fx) { int a = 0; for (int k = 0; k < 8; k++) a += kLumaTap[fy][k] * p[(k - 3) * rstride]; v = a >> shift1; }
+            else {
+                int a = 0;
+                for (int r = 0; r < 8; r++) {
+                    int t = 0;
+                    for (int k = 0; k < 8; k++) t += kLumaTap[fx][k] * p[(r - 3) * rstride + k - 3];
+                    a += kLumaTap[fy][r] * (t >> shift1);
+                }
+                v = a >> 6;
+            }
+            v = (v + off) >> shift3;
+            dst[j * dstride + i] = (pix)CLIP3(0, maxv, v);
+        }
+}
+
+void orc_interp_chroma(const pix *ref, int rstride, int xc, int yc, int mvx, int mvy, int wc, int hc, int bit_depth,
+                       pix *dst, int dstride)
+{
+    int fx = mvx & 7, fy = mvy & 7, xi = xc + (mvx >> 3), yi = yc + (mvy >> 3);
+    int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
+    int off = 1 << (shift3 - 1);
+    for (int j = 0; j < hc; j++)
+        for (int i = 0; i < wc; i++) {
+            const pix *p = ref + (yi + j) * rstride + xi + i;
+            int v;
+            if (!fx && !fy) v = p[0] << shift3;
+            else if (!fy) { int a = 0; for (int k = 0; k < 4; k++) a += kChromaTap[fx][k] * p[k - 1]; v = a >> shift1; }
+            else if (!fx) { int a = 0; for (int k = 0; k < 4; k++) a += kChromaTap[fy][k] * p[(k - 1) * rstride]; v = a >> shift1; }
+            else {
+                int a = 0;
+                for (int r = 0; r < 4; r++) {
+                    int t = 0;
+                    for (int k = 0; k < 4; k++) t += kChromaTap[fx][k] * p[(r - 1) * rstride + k - 1];
+                    a += kChromaTap[fy][r] * (t >> shift1);
+                }
+                v = a >> 6;
+            }
+            v = (v + off) >> shift3;
+            dst[j * dstride + i] = (pix)CLIP3(0, maxv, v);
+        }
+}
+
+int orc_sad(const pix *a, int as, const pix *b, int bs, int w, int h)
+{
+    int s = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) s += iabs(a[y * as + x] - b[y * bs + x]);
+    return s;
+}
+
+static int hadamard8(const pix *a, int as, const pix *b, int bs)
+{
+    int m[8][8];
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) m[y][x] = a[y * as + x] - b[y * bs + x];
+    for (int y = 0; y < 8; y++)
+        for (int st = 1; st < 8; st <<= 1)
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[y][i], q = m[y][i + st]; m[y][i] = p + q; m[y][i + st] = p - q; }
+    for (int x = 0; x < 8; x++)
+        for (int st = 1; st < 8; st <<= 1)
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[i][x], q = m[i + st][x]; m[i][x] = p + q; m[i + st][x] = p - q; }
+    int s = 0;
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) s += iabs(m[y][x]);
+    return (s + 2) >> 2;
+}
+static int hadamard4(const pix *a, int as, const pix *b, int bs)
+{
+    int m[4][4];
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) m[y][x] = a[y * as + x] - b[y * bs + x];
+    for (int y = 0; y < 4; y++)
+        for (int st = 1; st < 4; st <<= 1)
+            for (int i = 0; i < 4; i++)
+                if (!(i & st)) { int p = m[y][i], q = m[y][i + st]; m[y][i] = p + q; m[y][i + st] = p - q; }
+    for (int x = 0; x < 4; x++)
+        for (int st = 1; st < 4; st <<= 1)
+            for (int i = 0; i < 4; i++)
+                if (!(i & st)) { int p = m[i][x], q = m[i + st][x]; m[i][x] = p + q; m[i + st][x] = p - q; }
+    int s = 0;
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) s += iabs(m[y][x]);
+    return (s + 1) >> 1;
+}
+/* SATD: sum over 8x8 Hadamard tiles ((sum|c|+2)>>2 each); 4x4 blocks use the 4x4 Hadamard ((sum+1)>>1). */
+int orc_satd(const pix *a, int as, const pix *b, int bs, int w, int h)
+{
+    int s = 0;
+    if (w >= 8 && h >= 8) {
+        for (int y = 0; y < h; y += 8)
+            for (int x = 0; x < w; x += 8) s += hadamard8(a + y * as + x, as, b + y * bs + x, bs);
+    } else {
+        for (int y = 0; y < h; y += 4)
+            for (int x = 0; x < w; x += 4) s += hadamard4(a + y * as + x, as, b + y * bs + x, bs);
+    }
+    return s;
+}
+
+/* bins of one mvd component: greater0, greater1, EG1(|d|-2), sign (H.265 7.3.8.9 / 9.3.3) */
+int orc_mvd_bits(int d)
+{
+    int a = iabs(d);
+    if (a == 0) return 1;
+    if (a == 1) return 3;
+    return 3 + 2 * ilog2u((unsigned)a);
+}
+
+void orc_pad_plane(pix *p, int stride, int w, int h, int pad)
+{
+    for (int y = 0; y < h; y++) {
+        pix *row = p + y * stride;
+        for (int x = 1; x <= pad; x++) { row[-x] = row[0]; row[w - 1 + x] = row[w - 1]; }
+    }
+    for (int y = 1; y <= pad; y++) {
+        memcpy(p - y * stride - pad, p - pad, (w + 2 * pad) * sizeof(pix));
+        memcpy(p + (h - 1 + y) * stride - pad, p + (h - 1) * stride - pad, (w + 2 * pad) * sizeof(pix));
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Residual coding of one TU (shared by intra and inter): returns cbf, writes levels + reconstruction.
+ * ------------------------------------------------------------------------------------------------ */
+static int code_tu(const pix *src, int sstride, const pix *pred, int pstride, pix *rec, int rstride,
+                   int16_t *coef_out, int cstride, int log2n, int qp, int bit_depth, int intra, int dst,
+                   int64_t *sse_out, int *bits_q4_out)
+{
+    int n = 1 << log2n, maxv = (1 << bit_depth) - 1;
+    int16_t res[32 * 32], coef[32 * 32], lvl[32 * 32], rc[32 * 32];
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) res[y * n + x] = (int16_t)(src[y * sstride + x] - pred[y * pstride + x]);
+    orc_fwd_transform(res, n, coef, log2n, dst, bit_depth);
+    int nnz = orc_quant(coef, lvl, log2n, qp, bit_depth, intra);
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) coef_out[y * cstride + x] = lvl[y * n + x];
+    if (nnz) {
+        orc_dequant(lvl, coef, log2n, qp, bit_depth);
+        orc_inv_transform(coef, rc, n, log2n, dst, bit_depth);
+    } else {
+        memset(rc, 0, sizeof(int16_t) * n * n);
+    }
+    int64_t sse = 0;
+    for (int y = 0; y < n; y++)
+        for (int x = 0; x < n; x++) {
+            int v = pred[y * pstride + x] + rc[y * n + x];
+            v = CLIP3(0, maxv, v);
+            rec[y * rstride + x] = (pix)v;
+            int d = src[y * sstride + x] - v;
+            sse += d * d;
+        }
+    if (sse_out) *sse_out = sse;
+    if (bits_q4_out) {
+        int bits = 0;
+        for (int sy = 0; sy < n; sy += 4)
+            for (int sx = 0; sx < n; sx += 4) {
+                int any = 0;
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++) {
+                        int a = iabs(lvl[(sy + y) * n + sx + x]);
+                        if (!a) continue;
+                        any = 1;
+                        bits += a == 1 ? 40 : a == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(a - 1));
+                    }
+                if (any) bits += 24;
+            }
+        if (bits) bits += 16;
+        *bits_q4_out = bits;
+    }
+    return nnz != 0;
+}
+
+/* ================================================================================================
+ * K1 + K3 : inter frame
+ * ================================================================================================ */
+static const int8_t kFracOff[8][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+
+/* node n of the CTU quadtree: 0 = 32x32, 1..4 = 16x16 (z-order), 5..20 = 8x8 (z-order inside each 16x16) */
+static void node_geom(int node, int *x, int *y, int *log2n)
+{
+    if (node == 0) { *x = 0; *y = 0; *log2n = 5; return; }
+    if (node < 5) { int q = node - 1; *x = (q & 1) * 16; *y = (q >> 1) * 16; *log2n = 4; return; }
+    int q = (node - 5) >> 2, s = (node - 5) & 3;
+    *x = (q & 1) * 16 + (s & 1) * 8; *y = (q >> 1) * 16 + (s >> 1) * 8; *log2n = 3;
+}
+
+void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                             const pix *ref_y, const pix *ref_u, const pix *ref_v, int ref_stride, int ref_cstride,
+                             int w, int h, const orc_params *prm, const int16_t *centers,
+                             pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump)
+{
+    const int R = prm->me_range, span = 2 * R + 1, bd = prm->bit_depth, lam = prm->lambda_sad_q4;
+    const int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU, w8 = w >> 3;
+    uint32_t *sad8 = (uint32_t *)malloc(sizeof(uint32_t) * 16 * span * span);
+    for (int cy = 0; cy < hc; cy++)
+        for (int cx = 0; cx < wc; cx++) {
+            int ctu = cy * wc + cx, x0 = cx * ORC_CTU, y0 = cy * ORC_CTU;
+            int sx = centers ? centers[2 * ctu] : 0, sy = centers ? centers[2 * ctu + 1] : 0;
+            int valid[21], nx[21], ny[21], nl[21];
+            for (int nd = 0; nd < 21; nd++) {
+                node_geom(nd, &nx[nd], &ny[nd], &nl[nd]);
+                valid[nd] = x0 + nx[nd] + (1 << nl[nd]) <= w && y0 + ny[nd] + (1 << nl[nd]) <= h;
+            }
+            /* --- integer full search: SAD of every 8x8 block at every position --- */
+            for (int b = 0; b < 16; b++) {
+                int nd = 5 + b;
+                if (!valid[nd]) continue;
+                for (int dy = -R; dy <= R; dy++)
+                    for (int dx = -R; dx <= R; dx++)
+                        sad8[(b * span + dy + R) * span + dx + R] = (uint32_t)orc_sad(
+                            src_y + (y0 + ny[nd]) * src_stride + x0 + nx[nd], src_stride,
+                            ref_y + (y0 + ny[nd] + sy + dy) * ref_stride + x0 + nx[nd] + sx + dx, ref_stride, 8, 8);
+            }
+            int mvx[21], mvy[21];
+            uint32_t cost[21];
+            for (int nd = 0; nd < 21; nd++) {
+                mvx[nd] = mvy[nd] = 0; cost[nd] = 0;
+                if (!valid[nd]) continue;
+                uint64_t best = ~0ull;
+                for (int dy = -R; dy <= R; dy++)
+                    for (int dx = -R; dx <= R; dx++) {
+                        uint32_t s = 0;
+                        int p = (dy + R) * span + dx + R;
+                        if (nd == 0) for (int b = 0; b < 16; b++) s += sad8[b * span * span + p];
+                        else if (nd < 5) for (int b = 0; b < 4; b++) s += sad8[((nd - 1) * 4 + b) * span * span + p];
+                        else s = sad8[(nd - 5) * span * span + p];
+                        uint32_t c = (s << 4) + (uint32_t)(lam * (orc_mvd_bits(4 * dx) + orc_mvd_bits(4 * dy)));
+                        uint64_t key = ((uint64_t)c << 16) | (uint32_t)p;
+                        if (key < best) best = key;
+                    }
+                int p = (int)(best & 0xffff);
+                mvx[nd] = 4 * (sx + p % span - R); mvy[nd] = 4 * (sy + p / span - R);
+                cost[nd] = (uint32_t)(best >> 16);
+            }
+            if (me_dump)
+                for (int nd = 0; nd < 21; nd++) {
+                    me_dump[(ctu * 21 + nd) * 3 + 0] = valid[nd] ? mvx[nd] : 0;
+                    me_dump[(ctu * 21 + nd) * 3 + 1] = valid[nd] ? mvy[nd] : 0;
+                    me_dump[(ctu * 21 + nd) * 3 + 2] = valid[nd] ? (int32_t)cost[nd] : -1;
+                }
+            /* --- fractional refinement with SATD: half-pel ring then quarter-pel ring --- */
+            uint32_t J[21];
+            pix pred[32 * 32];
+            for (int nd = 0; nd < 21; nd++) {
+                J[nd] = 0;
+                if (!valid[nd]) continue;
+                int n = 1 << nl[nd], bx = x0 + nx[nd], by = y0 + ny[nd];
+                const pix *s = src_y + by * src_stride + bx;
+                int cmx = mvx[nd], cmy = mvy[nd];
+                orc_interp_luma(ref_y, ref_stride, bx, by, cmx, cmy, n, n, bd, pred, n);
+                uint32_t cbest = ((uint32_t)orc_satd(s, src_stride, pred, n, n, n) << 4) +
+                                 (uint32_t)(lam * (orc_mvd_bits(cmx - 4 * sx) + orc_mvd_bits(cmy - 4 * sy)));
+                for (int step = 2; step >= 1; step--) {
+                    uint64_t best = ((uint64_t)cbest << 4) | 0;
+                    for (int k = 0; k < 8; k++) {
+                        int tx = cmx + kFracOff[k][0] * step, ty = cmy + kFracOff[k][1] * step;
+                        orc_interp_luma(ref_y, ref_stride, bx, by, tx, ty, n, n, bd, pred, n);
+                        uint32_t c = ((uint32_t)orc_satd(s, src_stride, pred, n, n, n) << 4) +
+                                     (uint32_t)(lam * (orc_mvd_bits(tx - 4 * sx) + orc_mvd_bits(ty - 4 * sy)));
+                        uint64_t key = ((uint64_t)c << 4) | (uint32_t)(k + 1);
+                        if (key < best) best = key;
+                    }
+                    int k = (int)(best & 15);
+                    if (k) { cmx += kFracOff[k - 1][0] * step; cmy += kFracOff[k - 1][1] * step; }
+                    cbest = (uint32_t)(best >> 4);
+                }
+                mvx[nd] = cmx; mvy[nd] = cmy;
+                J[nd] = cbest + (uint32_t)(lam * 4);
+            }
+            /* --- quadtree decision, bottom-up --- */
+            int use16[4], use32;
+            uint32_t J16[4];
+            for (int q = 0; q < 4; q++) {
+                uint32_t js = (uint32_t)(lam * 2);
+                for (int s = 0; s < 4; s++) if (valid[5 + 4 * q + s]) js += J[5 + 4 * q + s];
+                use16[q] = valid[1 + q] && J[1 + q] <= js;
+                J16[q] = use16[q] ? J[1 + q] : js;
+            }
+            {
+                uint32_t js = (uint32_t)(lam * 2);
+                for (int q = 0; q < 4; q++) js += J16[q];
+                use32 = valid[0] && J[0] <= js;
+            }
+            /* --- residual coding of the chosen CUs --- */
+            for (int nd = 0; nd < 21; nd++) {
+                if (!valid[nd]) continue;
+                int chosen;
+                if (nd == 0) chosen = use32;
+                else if (nd < 5) chosen = !use32 && use16[nd - 1];
+                else chosen = !use32 && !use16[(nd - 5) >> 2];
+                if (!chosen) continue;
+                int n = 1 << nl[nd], bx = x0 + nx[nd], by = y0 + ny[nd];
+                pix pc[16 * 16];
+                int flags = ORC_F_INTER;
+                orc_interp_luma(ref_y, ref_stride, bx, by, mvx[nd], mvy[nd], n, n, bd, pred, n);
+                if (code_tu(src_y + by * src_stride + bx, src_stride, pred, n, rec_y + by * rec_stride + bx, rec_stride,
+                            coef_y + by * w + bx, w, nl[nd], prm->qp, bd, 0, 0, NULL, NULL)) flags |= ORC_F_CBF_Y;
+                for (int c = 0; c < 2; c++) {
+                    const pix *rp = c ? ref_v : ref_u, *sp = c ? src_v : src_u;
+                    pix *dp = c ? rec_v : rec_u;
+                    int16_t *cp = c ? coef_v : coef_u;
+                    orc_interp_chroma(rp, ref_cstride, bx / 2, by / 2, mvx[nd], mvy[nd], n / 2, n / 2, bd, pc, n / 2);
+                    if (code_tu(sp + (by / 2) * src_cstride + bx / 2, src_cstride, pc, n / 2,
+                                dp + (by / 2) * rec_cstride + bx / 2, rec_cstride, cp + (by / 2) * (w / 2) + bx / 2, w / 2,
+                                nl[nd] - 1, prm->qp_c, bd, 0, 0, NULL, NULL)) flags |= c ? ORC_F_CBF_CR : ORC_F_CBF_CB;
+                }
+                for (int yy = 0; yy < n; yy += 8)
+                    for (int xx = 0; xx < n; xx += 8) {
+                        orc_cu_rec *r = &cu[((by + yy) >> 3) * w8 + ((bx + xx) >> 3)];
+                        memset(r, 0, sizeof *r);
+                        r->log2_size = (uint8_t)nl[nd]; r->flags = (uint8_t)flags; r->qp = (uint8_t)prm->qp;
+                        r->mvx = (int16_t)mvx[nd]; r->mvy = (int16_t)mvy[nd];
+                        r->intra_mode[0] = 1; r->chroma_mode = 1;
+                    }
+            }
+        }
+    free(sad8);
+}
+
+/* ================================================================================================
+ * K2 + K3 : intra frame
+ * ================================================================================================ */
+typedef struct {
+    const pix *src[3]; int sstride[3];
+    pix *rec[3]; int rstride[3];
+    int16_t *coef[3];
+    orc_cu_rec *cu;
+    int w, h, w8;
+    const orc_params *prm;
+} intra_ctx;
+
+/* 8.4.2: candModeList from the left (x-1,y) and above (x,y-1) CUs; above is DC outside the current CTU row */
+static void mpm_list(const intra_ctx *c, int x, int y, int cand[3])
+{
+    int a = 1, b = 1;
+    if (x > 0) {
+        const orc_cu_rec *r = &c->cu[(y >> 3) * c->w8 + ((x - 1) >> 3)];
+        if (!(r->flags & ORC_F_INTER)) a = r->intra_mode[0];
+    }
+    if (y > 0 && ((y - 1) >> ORC_CTU_LOG2) == (y >> ORC_CTU_LOG2)) {
+        const orc_cu_rec *r = &c->cu[((y - 1) >> 3) * c->w8 + (x >> 3)];
+        if (!(r->flags & ORC_F_INTER)) b = r->intra_mode[0];
+    }
+    if (a == b) {
+        if (a < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+        else { cand[0] = a; cand[1] = 2 + ((a + 29) & 31); cand[2] = 2 + ((a - 2 + 1) & 31); }
+    } else {
+        cand[0] = a; cand[1] = b;
+        cand[2] = (a != 0 && b != 0) ? 0 : (a != 1 && b != 1) ? 1 : 26;
+    }
+}
+static int intra_mode_bits(const int cand[3], int mode)
+{
+    if (mode == cand[0]) return 2;
+    if (mode == cand[1] || mode == cand[2]) return 3;
+    return 6;
+}
+
+/* one 2Nx2N intra CU: SATD mode search, reconstruction (Y, Cb, Cr), records; returns RD cost */
+static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
+{
+    const orc_params *prm = c->prm;
+    int n = 1 << log2n, bd = prm->bit_depth;
+    pix ref[129], filt[129], pred[32 * 32];
+    int cand[3];
+    mpm_list(c, x, y, cand);
+    orc_intra_build_ref(c->rec[0], c->rstride[0], x, y, log2n, c->w, c->h, NULL, 0, 0, bd, ref);
+    uint64_t best = ~0ull;
+    const pix *s = c->src[0] + y * c->sstride[0] + x;
+    for (int mode = 0; mode < 35; mode++) {
+        orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
+        orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
+        uint32_t cst = ((uint32_t)orc_satd(s, c->sstride[0], pred, n, n, n) << 4) +
+                       (uint32_t)(prm->lambda_sad_q4 * intra_mode_bits(cand, mode));
+        uint64_t key = ((uint64_t)cst << 6) | (uint32_t)mode;
+        if (key < best) best = key;
+    }
+    int mode = (int)(best & 63);
+    int64_t sse, sse_total = 0;
+    int bits, bits_total = 16 * intra_mode_bits(cand, mode) + 16 + 24;
+    int flags = 0;
+    orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
+    orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
+    if (code_tu(s, c->sstride[0], pred, n, c->rec[0] + y * c->rstride[0] + x, c->rstride[0],
+                c->coef[0] + y * c->w + x, c->w, log2n, prm->qp, bd, 1, 0, &sse, &bits)) flags |= ORC_F_CBF_Y;
+    sse_total += sse; bits_total += bits;
+    for (int ci = 1; ci < 3; ci++) {
+        int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
+        orc_intra_build_ref(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, NULL, 0, ci, bd, ref);
+        orc_intra_pred(ref, pred, nc, l2, mode, ci, bd);
+        if (code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc,
+                    c->rec[ci] + yc * c->rstride[ci] + xc, c->rstride[ci], c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1,
+                    l2, prm->qp_c, bd, 1, 0, &sse, &bits)) flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
+        sse_total += sse; bits_total += bits;
+    }
+    for (int yy = 0; yy < n; yy += 8)
+        for (int xx = 0; xx < n; xx += 8) {
+            orc_cu_rec *r = &c->cu[((y + yy) >> 3) * c->w8 + ((x + xx) >> 3)];
+            memset(r, 0, sizeof *r);
+            r->log2_size = (uint8_t)log2n; r->flags = (uint8_t)flags; r->qp = (uint8_t)prm->qp;
+            r->intra_mode[0] = r->intra_mode[1] = r->intra_mode[2] = r->intra_mode[3] = (uint8_t)mode;
+            r->chroma_mode = (uint8_t)mode;
+        }
+    return ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);
+}
+
+static void region_copy(pix *dst, int ds, const pix *src, int ss, int w, int h)
+{
+    for (int y = 0; y < h; y++) memcpy(dst + y * ds, src + y * ss, w * sizeof(pix));
+}
+static void region_copy16(int16_t *dst, int ds, const int16_t *src, int ss, int w, int h)
+{
+    for (int y = 0; y < h; y++) memcpy(dst + y * ds, src + y * ss, w * sizeof(int16_t));
+}
+
+/* depth-first: children first, then the whole block; keep the cheaper (whole wins ties) */
+static uint64_t intra_tree(intra_ctx *c, int x, int y, int log2n)
+{
+    if (x >= c->w || y >= c->h) return 0;
+    int n = 1 << log2n;
+    if (log2n == ORC_MINCU_LOG2) return intra_cu(c, x, y, log2n);
+    int fits = x + n <= c->w && y + n <= c->h;
+    uint64_t jsplit = ((uint64_t)c->prm->lambda_q4 * 16) >> 4;
+    for (int q = 0; q < 4; q++) jsplit += intra_tree(c, x + (q & 1) * (n / 2), y + (q >> 1) * (n / 2), log2n - 1);
+    if (!fits) return jsplit;
+    pix sv[3][32 * 32];
+    int16_t sc[3][32 * 32];
+    orc_cu_rec scu[16];
+    for (int ci = 0; ci < 3; ci++) {
+        int sh = ci ? 1 : 0;
+        region_copy(sv[ci], n >> sh, c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], n >> sh, n >> sh);
+        region_copy16(sc[ci], n >> sh, c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, n >> sh, n >> sh);
+    }
+    for (int yy = 0; yy < n / 8; yy++)
+        for (int xx = 0; xx < n / 8; xx++) scu[yy * 4 + xx] = c->cu[((y >> 3) + yy) * c->w8 + (x >> 3) + xx];
+    uint64_t jwhole = intra_cu(c, x, y, log2n) + (((uint64_t)c->prm->lambda_q4 * 16) >> 4);
+    if (jwhole <= jsplit) return jwhole;
+    for (int ci = 0; ci < 3; ci++) {
+        int sh = ci ? 1 : 0;
+        region_copy(c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], sv[ci], n >> sh, n >> sh, n >> sh);
+        region_copy16(c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, sc[ci], n >> sh, n >> sh, n >> sh);
+    }
+    for (int yy = 0; yy < n / 8; yy++)
+        for (int xx = 0; xx < n / 8; xx++) c->cu[((y >> 3) + yy) * c->w8 + (x >> 3) + xx] = scu[yy * 4 + xx];
+    return jsplit;
+}
+
+void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                             int w, int h, const orc_params *prm,
+                             pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v)
+{
+    intra_ctx c;
+    c.src[0] = src_y; c.src[1] = src_u; c.src[2] = src_v;
+    c.sstride[0] = src_stride; c.sstride[1] = c.sstride[2] = src_cstride;
+    c.rec[0] = rec_y; c.rec[1] = rec_u; c.rec[2] = rec_v;
+    c.rstride[0] = rec_stride; c.rstride[1] = c.rstride[2] = rec_cstride;
+    c.coef[0] = coef_y; c.coef[1] = coef_u; c.coef[2] = coef_v;
+    c.cu = cu; c.w = w; c.h = h; c.w8 = w >> 3; c.prm = prm;
+    for (int y = 0; y < h; y += ORC_CTU)
+        for (int x = 0; x < w; x += ORC_CTU) intra_tree(&c, x, y, ORC_CTU_LOG2);
+}
+
+/* ================================================================================================
+ * K4a : deblocking — H.265 8.7.2
+ * ================================================================================================ */
+static const uint8_t kBeta[52] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18,
+                                  20, 22, 24, 26, 28, 30, 32, 34, 36, 38, 40, 42, 44, 46, 48, 50, 52, 54, 56, 58, 60, 62, 64};
+static const uint8_t kTc[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+                                5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+
+/* 8.7.2.4 boundary strength between the 8x8 blocks P and Q across a CU(=TU=PU) edge */
+static int edge_bs(const orc_cu_rec *p, const orc_cu_rec *q)
+{
+    if (!(p->flags & ORC_F_INTER) || !(q->flags & ORC_F_INTER)) return 2;
+    if ((p->flags & ORC_F_CBF_Y) || (q->flags & ORC_F_CBF_Y)) return 1;
+    if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
+    return 0;
+}
+
+/* filter one 4-sample luma segment; `s` steps across the edge, `t` along it (8.7.2.5.3 / .6 / .7) */
+static void luma_segment(pix *q0p, int s, int t, int beta, int tc, int maxv)
+{
+#define P(i, k) q0p[-(i + 1) * s + (k) * t]
+#define Q(i, k) q0p[(i) * s + (k) * t]
+    int dp0 = iabs(P(2, 0) - 2 * P(1, 0) + P(0, 0)), dp3 = iabs(P(2, 3) - 2 * P(1, 3) + P(0, 3));
+    int dq0 = iabs(Q(2, 0) - 2 * Q(1, 0) + Q(0, 0)), dq3 = iabs(Q(2, 3) - 2 * Q(1, 3) + Q(0, 3));
+    int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3, d = dpq0 + dpq3;
+    if (d >= beta) return;
+    int sam0 = 2 * dpq0 < (beta >> 2) && iabs(P(3, 0) - P(0, 0)) + iabs(Q(0, 0) - Q(3, 0)) < (beta >> 3) &&
+               iabs(P(0, 0) - Q(0, 0)) < ((5 * tc + 1) >> 1);
+    int sam3 = 2 * dpq3 < (beta >> 2) && iabs(P(3, 3) - P(0, 3)) + iabs(Q(0, 3) - Q(3, 3)) < (beta >> 3) &&
+               iabs(P(0, 3) - Q(0, 3)) < ((5 * tc + 1) >> 1);
+    int strong = sam0 && sam3;
+    int dep = dp < ((beta + (beta >> 1)) >> 3), deq = dq < ((beta + (beta >> 1)) >> 3);
+    for (int k = 0; k < 4; k++) {
+        int p0 = P(0, k), p1 = P(1, k), p2 = P(2, k), p3 = P(3, k), q0 = Q(0, k), q1 = Q(1, k), q2 = Q(2, k), q3 = Q(3, k);
+        if (strong) {
+            P(0, k) = (pix)CLIP3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+            P(1, k) = (pix)CLIP3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+            P(2, k) = (pix)CLIP3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+            Q(0, k) = (pix)CLIP3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+            Q(1, k) = (pix)CLIP3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+            Q(2, k) = (pix)CLIP3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+        } else {
+            int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+            if (iabs(delta) >= tc * 10) continue;
+            delta = CLIP3(-tc, tc, delta);
+            P(0, k) = (pix)CLIP3(0, maxv, p0 + delta);
+            Q(0, k) = (pix)CLIP3(0, maxv, q0 - delta);
+            if (dep) { int dl = CLIP3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1); P(1, k) = (pix)CLIP3(0, maxv, p1 + dl); }
+            if (deq) { int dl = CLIP3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1); Q(1, k) = (pix)CLIP3(0, maxv, q1 + dl); }
+        }
+    }
+#undef P
+#undef Q
+}
+
+void orc_deblock_frame(pix *rec_y, pix *rec_u, pix *rec_v, int stride, int cstride, int w, int h,
+                       const orc_cu_rec *cu, int bit_depth, int cqp_off)
+{
+    int w8 = w >> 3, h8 = h >> 3, maxv = (1 << bit_depth) - 1, sc = 1 << (bit_depth - 8);
+    for (int dir = 0; dir < 2; dir++) {      /* 0: vertical edges (filter across x), 1: horizontal edges */
+        for (int by = 0; by < h8; by++)
+            for (int bx = 0; bx < w8; bx++) {
+                const orc_cu_rec *q = &cu[by * w8 + bx];
+                int x = bx * 8, y = by * 8;
+                int cu_mask = (1 << q->log2_size) - 1;
+                if (dir == 0 ? (x == 0 || (x & cu_mask)) : (y == 0 || (y & cu_mask))) continue; /* not a CU edge */
+                const orc_cu_rec *p = dir == 0 ? q - 1 : q - w8;
+                int bs = edge_bs(p, q);
+                if (!bs) continue;
+                int qpl = (p->qp + q->qp + 1) >> 1;
+                int beta = kBeta[CLIP3(0, 51, qpl)] * sc;
+                int tc = kTc[CLIP3(0, 53, qpl + 2 * (bs - 1))] * sc;
+                pix *e = rec_y + y * stride + x;
+                for (int seg = 0; seg < 2; seg++)
+                    luma_segment(dir == 0 ? e + seg * 4 * stride : e + seg * 4, dir == 0 ? 1 : stride, dir == 0 ? stride : 1, beta, tc, maxv);
+                /* chroma: bS == 2 edges on the 8-sample chroma grid (8.7.2.5.5) */
+                if (bs == 2 && ((dir == 0 ? x : y) & 15) == 0) {
+                    int qpc = orc_chroma_qp(qpl + cqp_off);
+                    int tcc = kTc[CLIP3(0, 53, qpc + 2)] * sc;
+                    for (int ci = 0; ci < 2; ci++) {
+                        pix *c = (ci ? rec_v : rec_u) + (y >> 1) * cstride + (x >> 1);
+                        int s = dir == 0 ? 1 : cstride, t = dir == 0 ? cstride : 1;
+                        for (int k = 0; k < 4; k++) {
+                            int p0 = c[-s + k * t], p1 = c[-2 * s + k * t], q0 = c[k * t], q1 = c[s + k * t];
+                            int delta = CLIP3(-tcc, tcc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+                            c[-s + k * t] = (pix)CLIP3(0, maxv, p0 + delta);
+                            c[k * t] = (pix)CLIP3(0, maxv, q0 - delta);
+                        }
+                    }
+                }
+            }
+    }
+}
+
+/* ================================================================================================
+ * K4b : SAO — H.265 8.7.3 (apply) + encoder-side statistics/decision
+ * ================================================================================================ */
+static const int8_t kEoDx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};
+static const int8_t kEoDy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+static inline int sgn(int v) { return (v > 0) - (v < 0); }
+static inline int eo_cat(const pix *p, int stride, int x, int y, int w, int h, int cls)
+{
+    int xa = x + kEoDx[cls][0], ya = y + kEoDy[cls][0], xb = x + kEoDx[cls][1], yb = y + kEoDy[cls][1];
+    if (xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= w || xb >= w || ya >= h || yb >= h) return 0;
+    int c = p[y * stride + x];
+    int e = 2 + sgn(c - p[ya * stride + xa]) + sgn(c - p[yb * stride + xb]);
+    return e == 2 ? 0 : e < 2 ? e + 1 : e;     /* 0->1, 1->2, 2->0, 3->3, 4->4 */
+}
+
+/* best offset for (count n, sum s): start from the rounded mean (sign-constrained, |o|<=maxoff: 7 at 8 bit, 31 at 10) and walk toward 0
+ * minimising  (n*o*o - 2*o*s)*16 + lambda_q4 * rate(o) ; returns offset, adds its cost to *cost */
+static int sao_offset_rd(int n, int s, int sign_rule, int lam_q4, int band, int maxoff, int64_t *cost)
+{
+    if (n == 0) { *cost += 0 + (int64_t)lam_q4 * 1; return 0; }
+    int o = (int)((2 * (int64_t)iabs(s) + n) / (2 * n));   /* round(|s|/n) */
+    if (s < 0) o = -o;
+    if (sign_rule > 0 && o < 0) o = 0;
+    if (sign_rule < 0 && o > 0) o = 0;
+    o = CLIP3(-maxoff, maxoff, o);
+    int best_o = 0;
+    int64_t best = (int64_t)lam_q4 * 1;        /* o = 0: one bin */
+    int step = o > 0 ? 1 : -1;
+    for (int t = step; o != 0 && t != o + step; t += step) {
+        int a = iabs(t);
+        int rate = (a < maxoff ? a + 1 : maxoff) + (band ? 1 : 0);
+        int64_t c = (((int64_t)n * t * t - 2 * (int64_t)t * s) << 4) + (int64_t)lam_q4 * rate;
+        if (c < best) { best = c; best_o = t; }
+    }
+    *cost += best;
+    return best_o;
+}
+
+typedef struct { int type, cls, band; int8_t off[4]; int64_t cost; } sao_choice;
+
+static void sao_stats(const pix *src, int sstride, const pix *dbk, int stride, int x0, int y0, int cw, int ch,
+                      int w, int h, int bit_depth, int32_t eo_n[4][5], int32_t eo_s[4][5], int32_t bo_n[32], int32_t bo_s[32])
+{
+    memset(eo_n, 0, sizeof(int32_t) * 20); memset(eo_s, 0, sizeof(int32_t) * 20);
+    memset(bo_n, 0, sizeof(int32_t) * 32); memset(bo_s, 0, sizeof(int32_t) * 32);
+    for (int y = y0; y < y0 + ch && y < h; y++)
+        for (int x = x0; x < x0 + cw && x < w; x++) {
+            int d = src[y * sstride + x] - dbk[y * stride + x];
+            int b = dbk[y * stride + x] >> (bit_depth - 5);
+            bo_n[b]++; bo_s[b] += d;
+            for (int c = 0; c < 4; c++) { int k = eo_cat(dbk, stride, x, y, w, h, c); eo_n[c][k]++; eo_s[c][k] += d; }
+        }
+}
+
+/* candidates in fixed order: off, band, edge class 0..3; strict < keeps the earliest on ties */
+static void sao_eval(int32_t eo_n[4][5], int32_t eo_s[4][5], int32_t bo_n[32], int32_t bo_s[32], int lam_q4, int bit_depth, sao_choice out[6])
+{
+    int maxoff = (1 << ((bit_depth < 10 ? bit_depth : 10) - 5)) - 1;
+    memset(out, 0, sizeof(sao_choice) * 6);
+    out[0].type = 0; out[0].cost = 0;
+    /* band */
+    int8_t bo_off[32]; int64_t bo_cost[32];
+    for (int b = 0; b < 32; b++) { bo_cost[b] = 0; bo_off[b] = (int8_t)sao_offset_rd(bo_n[b], bo_s[b], 0, lam_q4, 1, maxoff, &bo_cost[b]); }
+    int64_t bestb = 0; int pos = -1;
+    for (int p = 0; p <= 28; p++) {
+        int64_t c = bo_cost[p] + bo_cost[p + 1] + bo_cost[p + 2] + bo_cost[p + 3];
+        if (pos < 0 || c < bestb) { bestb = c; pos = p; }
+    }
+    out[1].type = 1; out[1].band = pos; out[1].cost = bestb + (int64_t)lam_q4 * 7;
+    for (int i = 0; i < 4; i++) out[1].off[i] = bo_off[pos + i];
+    for (int c = 0; c < 4; c++) {
+        sao_choice *o = &out[2 + c];
+        o->type = 2; o->cls = c; o->cost = (int64_t)lam_q4 * 4;
+        for (int k = 1; k <= 4; k++) o->off[k - 1] = (int8_t)sao_offset_rd(eo_n[c][k], eo_s[c][k], k <= 2 ? 1 : -1, lam_q4, 0, maxoff, &o->cost);
+    }
+}
+
+static void sao_apply_ctb(const pix *dbk, int stride, pix *out, int ostride, int x0, int y0, int cw, int ch, int w, int h,
+                          int bit_depth, int type, int cls, int band, const int8_t off[4])
+{
+    int maxv = (1 << bit_depth) - 1;
+    for (int y = y0; y < y0 + ch && y < h; y++)
+        for (int x = x0; x < x0 + cw && x < w; x++) {
+            int v = dbk[y * stride + x];
+            if (type == 2) {
+                int k = eo_cat(dbk, stride, x, y, w, h, cls);
+                if (k) v = CLIP3(0, maxv, v + off[k - 1]);
+            } else if (type == 1) {
+                int k = ((v >> (bit_depth - 5)) - band) & 31;
+                if (k < 4) v = CLIP3(0, maxv, v + off[k]);
+            }
+            out[y * ostride + x] = (pix)v;
+        }
+}
+
+void orc_sao_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                   const pix *dbk_y, const pix *dbk_u, const pix *dbk_v, int stride, int cstride,
+                   pix *out_y, pix *out_u, pix *out_v, int ostride, int ocstride,
+                   int w, int h, const orc_params *prm, orc_sao_ctu *sao)
+{
+    int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU, bd = prm->bit_depth;
+    int32_t eo_n[4][5], eo_s[4][5], bo_n[32], bo_s[32];
+    for (int cy = 0; cy < hc; cy++)
+        for (int cx = 0; cx < wc; cx++) {
+            orc_sao_ctu *o = &sao[cy * wc + cx];
+            memset(o, 0, sizeof *o);
+            sao_choice ch[3][6];
+            sao_stats(src_y, src_stride, dbk_y, stride, cx * ORC_CTU, cy * ORC_CTU, ORC_CTU, ORC_CTU, w, h, bd, eo_n, eo_s, bo_n, bo_s);
+            sao_eval(eo_n, eo_s, bo_n, bo_s, prm->lambda_q4, bd, ch[0]);
+            sao_stats(src_u, src_cstride, dbk_u, cstride, cx * 16, cy * 16, 16, 16, w / 2, h / 2, bd, eo_n, eo_s, bo_n, bo_s);
+            sao_eval(eo_n, eo_s, bo_n, bo_s, prm->lambda_q4, bd, ch[1]);
+            sao_stats(src_v, src_cstride, dbk_v, cstride, cx * 16, cy * 16, 16, 16, w / 2, h / 2, bd, eo_n, eo_s, bo_n, bo_s);
+            sao_eval(eo_n, eo_s, bo_n, bo_s, prm->lambda_q4, bd, ch[2]);
+            int bl = 0, bc = 0;
+            for (int k = 1; k < 6; k++) {
+                if (ch[0][k].cost < ch[0][bl].cost) bl = k;
+                if (ch[1][k].cost + ch[2][k].cost < ch[1][bc].cost + ch[2][bc].cost) bc = k;
+            }
+            o->type[0] = (uint8_t)ch[0][bl].type; o->eo_class[0] = (uint8_t)ch[0][bl].cls; o->band_pos[0] = (uint8_t)ch[0][bl].band;
+            memcpy(o->offset[0], ch[0][bl].off, 4);
+            o->type[1] = (uint8_t)ch[1][bc].type; o->eo_class[1] = (uint8_t)ch[1][bc].cls;
+            o->band_pos[1] = (uint8_t)ch[1][bc].band; o->band_pos[2] = (uint8_t)ch[2][bc].band;
+            memcpy(o->offset[1], ch[1][bc].off, 4); memcpy(o->offset[2], ch[2][bc].off, 4);
+        }
+    orc_sao_apply_frame(dbk_y, dbk_u, dbk_v, stride, cstride, out_y, out_u, out_v, ostride, ocstride, w, h, bd, sao);
+}
+
+void orc_sao_apply_frame(const pix *dbk_y, const pix *dbk_u, const pix *dbk_v, int stride, int cstride,
+                         pix *out_y, pix *out_u, pix *out_v, int ostride, int ocstride,
+                         int w, int h, int bit_depth, const orc_sao_ctu *sao)
+{
+    int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU;
+    for (int cy = 0; cy < hc; cy++)
+        for (int cx = 0; cx < wc; cx++) {
+            const orc_sao_ctu *o = &sao[cy * wc + cx];
+            sao_apply_ctb(dbk_y, stride, out_y, ostride, cx * ORC_CTU, cy * ORC_CTU, ORC_CTU, ORC_CTU, w, h, bit_depth,
+                          o->type[0], o->eo_class[0], o->band_pos[0], o->offset[0]);
+            sao_apply_ctb(dbk_u, cstride, out_u, ocstride, cx * 16, cy * 16, 16, 16, w / 2, h / 2, bit_depth,
+                          o->type[1], o->eo_class[1], o->band_pos[1], o->offset[1]);
+            sao_apply_ctb(dbk_v, cstride, out_v, ocstride, cx * 16, cy * 16, 16, 16, w / 2, h / 2, bit_depth,
+                          o->type[1], o->eo_class[1], o->band_pos[2], o->offset[2]);
+        }
+}

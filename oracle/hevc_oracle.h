@@ -1,0 +1,136 @@
+/* oracle/hevc_oracle.h — TEST INFRASTRUCTURE, NOT PRODUCT.
+ *
+ * Scalar CPU restatement of the HEVC encode hot path.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this; the product (hevc_amd/)
+ * never links or calls it.
+ *
+ * What it follows.  The reference (uingei/hevc) reaches this arithmetic through an external
+ * `ffmpeg -c:v libx265` child (core/transcoder.py:412 codec name, :398-411 params, :463, :506); libx265 is
+ * third-party, unpinned and absent from /root/reference and from this image, and the reference's own tests hold
+ * no golden vector for it (tests/test_transcoder.py:32,47 assert only a status string).  PARITY UNPINNED against
+ * libx265.  The normative (decoder-side) arithmetic therefore follows ITU-T H.265 (04/2013 and later) clause by
+ * clause — each function names its clause — and is pinned by the closed-form known-answer tests in
+ * tests/test_oracle_kat.py and by the independent decoder in hevc_dec.c (encode -> bitstream -> decode must
+ * reproduce the encoder's reconstruction bit for bit).  Encoder-side choices (search, costs) are this build's own
+ * and are DEFINED here: the HIP kernels must reproduce them exactly.
+ *
+ * All sample planes are uint16_t containers (8- and 10-bit alike) to keep the restatement single-typed.
+ */
+#ifndef HEVC_ORACLE_H
+#define HEVC_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t pix;
+
+#define ORC_CTU_LOG2 5
+#define ORC_CTU 32
+#define ORC_MINCU_LOG2 3
+#define ORC_PAD 80            /* luma border of reference planes (chroma: half) */
+
+/* per-8x8 block record, identical to the product's mihevc_cu_rec (include/mihevc.h) */
+typedef struct {
+    uint8_t log2_size;   /* CU size: 3,4,5 */
+    uint8_t flags;       /* bit0 inter, bit1 cbf_y, bit2 cbf_cb, bit3 cbf_cr, bit4 intra NxN, bit5 (host) skip */
+    uint8_t chroma_mode; /* actual chroma intra mode 0..34 */
+    uint8_t qp;
+    uint8_t intra_mode[4];
+    int16_t mvx, mvy;    /* quarter-pel */
+    uint8_t cbf_y4;      /* NxN: luma cbf of the four 4x4 TUs */
+    uint8_t pad[3];
+} orc_cu_rec;
+
+#define ORC_F_INTER 1
+#define ORC_F_CBF_Y 2
+#define ORC_F_CBF_CB 4
+#define ORC_F_CBF_CR 8
+#define ORC_F_NXN 16
+
+typedef struct {
+    uint8_t type[2];      /* [0] luma, [1] chroma: 0 off, 1 band, 2 edge */
+    uint8_t eo_class[2];
+    uint8_t band_pos[3];
+    int8_t  offset[3][4]; /* signed final SaoOffsetVal[1..4] */
+    uint8_t pad;
+} orc_sao_ctu;
+
+/* integer cost parameters (computed on the host from QP; see hevc_amd/csrc/ratectl) */
+typedef struct {
+    int qp;            /* luma QP of the frame */
+    int qp_c;          /* chroma QP (table-mapped, cb/cr offsets 0) */
+    int bit_depth;
+    int lambda_sad_q4; /* sqrt(lambda_mode) * 16 */
+    int lambda_q4;     /* lambda_mode * 16  (SSE domain) */
+    int me_range;      /* integer search +-range, <= 64 */
+} orc_params;
+
+/* ---- primitives (clauses of H.265 in the .c) ---- */
+void orc_fwd_transform(const int16_t *res, int rstride, int16_t *coef, int log2n, int dst, int bit_depth);
+void orc_inv_transform(const int16_t *coef, int16_t *res, int rstride, int log2n, int dst, int bit_depth);
+int  orc_quant(const int16_t *coef, int16_t *lvl, int log2n, int qp, int bit_depth, int intra);
+void orc_dequant(const int16_t *lvl, int16_t *coef, int log2n, int qp, int bit_depth);
+int  orc_chroma_qp(int qp_y);
+void orc_transform_matrix(int16_t *out32x32);
+
+void orc_intra_build_ref(const pix *rec, int stride, int x0, int y0, int log2n, int pic_w, int pic_h,
+                         const uint8_t *avail_map, int map_stride, int c_idx, int bit_depth, pix *ref /*4N+1*/);
+void orc_intra_filter_ref(const pix *ref, pix *filt, int log2n, int mode, int c_idx, int bit_depth, int strong);
+void orc_intra_pred(const pix *ref, pix *dst, int dstride, int log2n, int mode, int c_idx, int bit_depth);
+
+void orc_interp_luma(const pix *ref, int rstride, int x, int y, int mvx, int mvy, int w, int h, int bit_depth,
+                     pix *dst, int dstride);
+void orc_interp_chroma(const pix *ref, int rstride, int xc, int yc, int mvx, int mvy, int wc, int hc, int bit_depth,
+                       pix *dst, int dstride);
+int  orc_sad(const pix *a, int as, const pix *b, int bs, int w, int h);
+int  orc_satd(const pix *a, int as, const pix *b, int bs, int w, int h);
+int  orc_mvd_bits(int d);
+
+void orc_pad_plane(pix *p, int stride, int w, int h, int pad);
+
+/* ---- frame-level stages: the definition of what each HIP stage must output ---- */
+/* K1+K3: inter (P) frame.  ref_* are padded planes (ORC_PAD / ORC_PAD/2); rec_* receive the pre-deblock
+ * reconstruction; coef_* receive levels in TU-local raster at picture coordinates. */
+void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                             const pix *ref_y, const pix *ref_u, const pix *ref_v, int ref_stride, int ref_cstride,
+                             int w, int h, const orc_params *prm, const int16_t *centers /*2 per CTU or NULL*/,
+                             pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                             int32_t *me_dump /* optional: per CTU 21*(mvx,mvy,cost) after integer search, or NULL */);
+/* K2+K3: intra (I) frame */
+void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                             int w, int h, const orc_params *prm,
+                             pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v);
+/* K4a: deblocking, in place on rec_* (clause 8.7.2) */
+void orc_deblock_frame(pix *rec_y, pix *rec_u, pix *rec_v, int stride, int cstride, int w, int h,
+                       const orc_cu_rec *cu, int bit_depth, int deblock_chroma_qp_offset);
+/* K4b: SAO decision + apply: reads deblocked dbk_*, writes out_* (clause 8.7.3) and sao params */
+void orc_sao_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                   const pix *dbk_y, const pix *dbk_u, const pix *dbk_v, int stride, int cstride,
+                   pix *out_y, pix *out_u, pix *out_v, int ostride, int ocstride,
+                   int w, int h, const orc_params *prm, orc_sao_ctu *sao);
+void orc_sao_apply_frame(const pix *dbk_y, const pix *dbk_u, const pix *dbk_v, int stride, int cstride,
+                         pix *out_y, pix *out_u, pix *out_v, int ostride, int ocstride,
+                         int w, int h, int bit_depth, const orc_sao_ctu *sao);
+
+/* ---- hevc_dec.c: independent decoder for the syntax subset the encoder emits ---- */
+typedef struct orc_decoder orc_decoder;
+orc_decoder *orc_dec_open(void);
+/* feed a whole Annex-B stream; returns number of decoded pictures or <0 on syntax error */
+int  orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size);
+int  orc_dec_info(const orc_decoder *d, int *w, int *h, int *bit_depth, int *conf_w, int *conf_h);
+/* copy decoded picture idx (output order == decode order here) into 16-bit planes of the coded size */
+int  orc_dec_get_frame(const orc_decoder *d, int idx, pix *y, pix *u, pix *v);
+const char *orc_dec_error(const orc_decoder *d);
+/* parsed header fields for conformance assertions in tests: name -> value, returns 0 if unknown */
+int  orc_dec_query(const orc_decoder *d, const char *field, long long *value);
+void orc_dec_close(orc_decoder *d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
