@@ -1,0 +1,77 @@
+// hevc_amd/csrc/bitstream.h — host-side HEVC bitstream writer (parameter sets, slice header, CABAC slice data).
+//
+// Stays on host cores by design (BASELINE.json north_star: "CABAC entropy coding and MP4 mux stay on host cores").
+// Replaces what libx265 does behind `ffmpeg -c:v libx265` in the reference (core/transcoder.py:412,463,506) for the
+// syntax subset the device analysis produces.  Clause numbers refer to ITU-T H.265.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <vector>
+
+#include "../../include/mihevc.h"
+
+namespace mihevc {
+
+constexpr int kCtuLog2 = 5;
+constexpr int kCtu = 32;
+constexpr int kMaxMergeCand = 5;
+
+enum : uint8_t { F_INTER = 1, F_CBF_Y = 2, F_CBF_CB = 4, F_CBF_CR = 8, F_NXN = 16 };
+
+struct CodedSize {
+    int w, h;          // multiples of 8
+    int crop_r, crop_b; // luma samples cropped by the conformance window
+};
+inline CodedSize coded_size(int width, int height)
+{
+    CodedSize c;
+    c.w = (width + 7) & ~7;
+    c.h = (height + 7) & ~7;
+    c.crop_r = c.w - width;
+    c.crop_b = c.h - height;
+    return c;
+}
+
+class BitWriter {
+public:
+    void put(uint32_t v, int n);            // n <= 32, MSB first
+    void put1(int b) { put((uint32_t)(b != 0), 1); }
+    void ue(uint32_t v);
+    void se(int32_t v);
+    void trailing();                         // rbsp_trailing_bits
+    void align_zero();
+    bool aligned() const { return nbits_ == 0; }
+    std::vector<uint8_t> &bytes() { return buf_; }
+    const std::vector<uint8_t> &bytes() const { return buf_; }
+    void append_bytes(const uint8_t *p, size_t n) { buf_.insert(buf_.end(), p, p + n); }
+
+private:
+    std::vector<uint8_t> buf_;
+    uint32_t acc_ = 0;
+    int nbits_ = 0;
+};
+
+// append start code + 2-byte NAL header + escaped payload to out (7.3.1.1, Annex B)
+void append_nal(std::vector<uint8_t> &out, int nal_type, const std::vector<uint8_t> &rbsp);
+
+void write_vps(const mihevc_config &cfg, std::vector<uint8_t> &out);
+void write_sps(const mihevc_config &cfg, std::vector<uint8_t> &out);
+void write_pps(const mihevc_config &cfg, std::vector<uint8_t> &out);
+void write_sei_hdr10(const mihevc_config &cfg, std::vector<uint8_t> &out);
+void write_aud(int slice_type, std::vector<uint8_t> &out);
+void write_parameter_sets(const mihevc_config &cfg, std::vector<uint8_t> &out);
+
+// One picture's symbols (pointers into pinned host copies of the device outputs).
+struct PictureSyms {
+    int slice_type;      // 2 = I (coded as IDR_W_RADL), 1 = P (TRAIL_R)
+    int poc;             // position in the closed GOP (0 for the IDR)
+    int qp;              // slice QP
+    const mihevc_cu_rec *cu;      // (h/8) x (w/8)
+    const int16_t *coef[3];       // TU-local raster at picture coordinates; strides w, w/2, w/2
+    const mihevc_sao_ctu *sao;    // per CTU, or nullptr when SAO is off for the picture
+};
+
+// CABAC-code the picture into one slice-segment NAL appended to out; returns the number of bins coded (stats).
+size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out);
+
+}  // namespace mihevc

@@ -1,0 +1,164 @@
+/* include/mihevc.h — C ABI of the MI355X-native HEVC encode path (libmihevc.so).
+ *
+ * This is the drop-in boundary.  The reference has no FFI: its encode step is the child process
+ * `ffmpeg -c:v libx265|hevc_nvenc` spawned by run_ffmpeg (reference core/transcoder.py:497-535) with the operating
+ * point built by build_ffmpeg_params (core/transcoder.py:357-412).  The entry points below are what a binding for
+ * that step would call instead; hevc_amd/encoder.py is that binding (ctypes), INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain C types only; every int-returning function returns 0 (MIHEVC_OK) or a negative mihevc_err;
+ * nothing throws or aborts; distinct sessions may be used from distinct threads concurrently (the reference calls
+ * convert_video from N QThreads, gui/mainwindow.py:289-301); one session is driven by one thread at a time.
+ * ctypes releases the GIL during calls, which that threading model relies on.
+ */
+#ifndef MIHEVC_H
+#define MIHEVC_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIHEVC_ABI_VERSION 1
+
+typedef enum {
+    MIHEVC_OK = 0,
+    MIHEVC_EAGAIN = -1,     /* receive_packet: nothing ready yet (send more frames or flush) */
+    MIHEVC_EOF = -2,        /* receive_packet after flush: stream complete */
+    MIHEVC_EINVAL = -3,     /* bad argument / unsupported configuration */
+    MIHEVC_ENODEV = -4,     /* no gfx950 device (or HIP runtime unusable) */
+    MIHEVC_ENOMEM = -5,
+    MIHEVC_EDEVICE = -6,    /* HIP call failed; see mihevc_last_error */
+    MIHEVC_ESTATE = -7      /* call sequence error (e.g. send after flush) */
+} mihevc_err;
+
+/* Encoder operating point.  Field-for-field this is what the reference passes to libx265 through
+ * `-x265-params` (core/transcoder.py:398-411) plus the HDR10 set of core/utils.py:58-69. */
+typedef struct mihevc_config {
+    int32_t width, height;            /* display size; coded size is rounded up to a multiple of 8 + conformance window */
+    int32_t fps_num, fps_den;         /* VUI/VPS timing */
+    int32_t bit_depth;                /* 8 (Main) or 10 (Main10) */
+    int32_t level_idc;                /* general_level_idc = 30 * level  (x265 level-idc) */
+    int32_t tier;                     /* 0 main, 1 high                  (x265 tier) */
+    int32_t crf;                      /* constant-quality target         (x265 crf); frame QP is derived from it */
+    int32_t qp;                       /* >= 0: force this QP for P frames (I frames qp-3); -1: derive from crf */
+    int32_t vbv_maxrate_kbps;         /* x265 vbv-maxrate; 0 = unconstrained */
+    int32_t vbv_bufsize_kbits;        /* x265 vbv-bufsize */
+    int32_t keyint, min_keyint;       /* closed GOP length (IDR period)  (x265 keyint / min-keyint) */
+    int32_t colour_primaries, transfer, matrix;   /* VUI code points: 1/1/1 bt709, 9/16/9 HDR10 (x265 colorprim/transfer/colormatrix) */
+    int32_t full_range;               /* 0: `-color_range tv` (core/transcoder.py:490) */
+    int32_t chroma_loc;               /* -1: not signalled; 0..5 chroma_sample_loc_type (x265 chromaloc) */
+    int32_t aud;                      /* emit access unit delimiters     (x265 aud) */
+    int32_t repeat_headers;           /* VPS/SPS/PPS before every IDR    (x265 repeat-headers); the first IDR always has them */
+    int32_t hdr10;                    /* emit SEI 137 + 144              (x265 hdr10 / master-display / max-cll) */
+    uint16_t md_primaries[3][2];      /* G,B,R (x,y) in 0.00002 units */
+    uint16_t md_white[2];
+    uint32_t md_max_lum, md_min_lum;  /* 0.0001 cd/m2 */
+    uint16_t max_cll, max_fall;
+    int32_t me_range;                 /* integer search +-range (<= 64); 0 = default */
+    int32_t gops_in_flight;           /* closed GOPs encoded in lock-step on the device; 0 = default */
+    int32_t host_threads;             /* CABAC worker threads; 0 = default */
+    int32_t sao;                      /* 1 (default -1 -> 1) enable SAO */
+    int32_t reserved[8];
+} mihevc_config;
+
+typedef struct mihevc_session mihevc_session;
+
+typedef struct mihevc_stats {
+    int64_t frames_in, frames_out, bytes_out;
+    double  sse_y, sse_u, sse_v;      /* encoder reconstruction vs source (summed over frames_out), for PSNR */
+    double  device_ms, entropy_ms;    /* accumulated device time (HIP events) and host CABAC time (sum over threads) */
+    int32_t last_qp;
+    int32_t reserved[7];
+} mihevc_stats;
+
+int  mihevc_abi_version(void);
+int  mihevc_device_count(void);                      /* gfx950 devices visible; 0 when none / no runtime */
+void mihevc_config_default(mihevc_config *cfg);      /* 1080p30 8-bit SDR at the reference's operating point */
+int  mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out);
+/* Caller-owned host planes (8-bit: 1 byte/sample, 10-bit: 2 bytes little endian), copied/uploaded before return. */
+int  mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const void *v,
+                       int pitch_y, int pitch_c, int64_t pts);
+/* Frames already resident in device memory (same layout, device pointers): the benchmark path. */
+int  mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, const void *v,
+                              int pitch_y, int pitch_c, int64_t pts);
+/* One access unit (Annex-B NAL units) in session-owned memory, valid until the next receive/close. */
+int  mihevc_receive_packet(mihevc_session *s, const uint8_t **data, size_t *size,
+                           int64_t *pts, int64_t *dts, int *keyframe);
+int  mihevc_flush(mihevc_session *s);                /* no more input; drain with receive_packet until MIHEVC_EOF */
+void mihevc_close(mihevc_session *s);
+int  mihevc_get_stats(const mihevc_session *s, mihevc_stats *out);
+/* VPS+SPS+PPS (Annex-B) for the muxer's hvcC box; valid until close. */
+int  mihevc_get_headers(mihevc_session *s, const uint8_t **data, size_t *size);
+/* Copy the reconstruction of output frame `index` (display order) as 16-bit planes of the CODED size; only
+ * available when the session was opened with keep_recon (tests): returns MIHEVC_ESTATE otherwise. */
+int  mihevc_set_keep_recon(mihevc_session *s, int keep);
+int  mihevc_get_recon(mihevc_session *s, int64_t index, uint16_t *y, uint16_t *u, uint16_t *v);
+int  mihevc_coded_size(const mihevc_session *s, int *w, int *h);
+const char *mihevc_strerror(int err);
+const char *mihevc_last_error(const mihevc_session *s);
+
+/* ---- integer cost parameters derived from a QP (shared by every stage; exported so tests can hand the same
+ *      numbers to the oracle) ---- */
+typedef struct mihevc_cost_params {
+    int32_t qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
+} mihevc_cost_params;
+void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);
+
+/* per-8x8-block record produced by the analysis kernels and consumed by deblocking and the host entropy coder */
+typedef struct mihevc_cu_rec {
+    uint8_t log2_size;     /* CU size 3..5 (CU = PU = TU except intra NxN) */
+    uint8_t flags;         /* bit0 inter, bit1 cbf_y, bit2 cbf_cb, bit3 cbf_cr, bit4 intra NxN */
+    uint8_t chroma_mode;   /* chroma intra prediction mode 0..34 */
+    uint8_t qp;
+    uint8_t intra_mode[4];
+    int16_t mvx, mvy;      /* quarter-sample units */
+    uint8_t cbf_y4;
+    uint8_t pad[3];
+} mihevc_cu_rec;
+
+typedef struct mihevc_sao_ctu {
+    uint8_t type[2];       /* luma, chroma: 0 off, 1 band, 2 edge */
+    uint8_t eo_class[2];
+    uint8_t band_pos[3];
+    int8_t  offset[3][4];
+    uint8_t pad;
+} mihevc_sao_ctu;
+
+/* ---- per-stage entry points: host buffers in, host buffers out, one device pass each.  They run the SAME kernels
+ *      the session runs, so the parity tests (tests/test_gpu_parity.py) hit each stage alone.  Sample planes are
+ *      uint8_t when bit_depth == 8 and uint16_t otherwise; pitches are in samples. ---- */
+/* K3: forward transform + quantisation + dequantisation + inverse transform of n_blocks residual blocks */
+int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int16_t *recon_residual,
+                       int n_blocks, int log2n, int qp, int bit_depth, int intra, int dst4);
+/* K2+K3: intra picture analysis -> pre-deblock reconstruction, CU records, levels */
+int mihevc_k_intra_frame(int device, const void *src_y, const void *src_u, const void *src_v, int width, int height,
+                         const mihevc_cost_params *prm, void *rec_y, void *rec_u, void *rec_v,
+                         mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v);
+/* K1+K3: inter picture analysis against one (unpadded) reference reconstruction */
+int mihevc_k_inter_frame(int device, const void *src_y, const void *src_u, const void *src_v,
+                         const void *ref_y, const void *ref_u, const void *ref_v, int width, int height,
+                         const mihevc_cost_params *prm, const int16_t *centers, void *rec_y, void *rec_u, void *rec_v,
+                         mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump);
+/* K4a: deblocking in place */
+int mihevc_k_deblock(int device, void *rec_y, void *rec_u, void *rec_v, int width, int height,
+                     const mihevc_cu_rec *cu, int bit_depth);
+/* K4b: SAO statistics + decision + apply */
+int mihevc_k_sao(int device, const void *src_y, const void *src_u, const void *src_v,
+                 const void *dbk_y, const void *dbk_u, const void *dbk_v, int width, int height,
+                 const mihevc_cost_params *prm, void *out_y, void *out_u, void *out_v, mihevc_sao_ctu *sao);
+
+/* ---- host-only stages (no device needed): bitstream ---- */
+/* VPS+SPS+PPS (+SEI when hdr10) as Annex-B into buf; returns size or negative error */
+int mihevc_write_parameter_sets(const mihevc_config *cfg, uint8_t *buf, size_t cap);
+/* CABAC-code one picture from its symbols into one slice NAL (+AUD when cfg->aud); returns size or negative error.
+ * slice_type 2 = I (IDR), 1 = P; poc = position inside the closed GOP. */
+int mihevc_encode_picture_host(const mihevc_config *cfg, int slice_type, int poc, int qp,
+                               const mihevc_cu_rec *cu, const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v,
+                               const mihevc_sao_ctu *sao, uint8_t *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIHEVC_H */
