@@ -1,0 +1,41 @@
+// hevc_amd/csrc/device.h — launch layer over the gfx950 kernels (hevc_amd/csrc/kernels/*.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "kernels/common.h"
+#include "kernels/inter.h"
+#include "kernels/intra.h"
+#include "kernels/loopfilter.h"
+
+namespace mihevc {
+
+// a device sample plane with an edge border; `pl.p` addresses sample (0,0)
+template <typename T> struct DevPlane {
+    T *base = nullptr;
+    Plane<T> pl{nullptr, 0};
+    int w = 0, h = 0, pad = 0;
+    size_t bytes() const { return (size_t)pl.stride * (h + 2 * pad) * sizeof(T); }
+};
+template <typename T> hipError_t alloc_plane(DevPlane<T> &d, int w, int h, int pad);
+template <typename T> void free_plane(DevPlane<T> &d);
+
+// Per-picture argument blocks live in device memory (one per picture in flight); launches take an array of them
+// and index it with blockIdx.y, so one launch covers every picture of a lock-step batch.
+template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
+template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
+// all anti-diagonals of an I picture batch; h_args is the host copy (geometry only), d_args the device array
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch);
+template <typename T> hipError_t launch_deblock(hipStream_t st, const DeblockArgs<T> *d_args_v, const DeblockArgs<T> *d_args_h, int w, int h, int batch);
+template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch, bool decide);
+template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch);
+// per-picture sum of squared error into args.sse[0..2] (u64, accumulated with atomics: zero the targets first)
+template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch);
+
+template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p, int sw, int sh, int pw, int ph);
+
+int gfx950_device_count();
+
+}  // namespace mihevc

@@ -1,0 +1,518 @@
+// hevc_amd/csrc/device.hip — __global__ entry points, launchers and the per-stage C-ABI functions (mihevc_k_*).
+#include "device.h"
+
+#include <cstring>
+#include <vector>
+
+namespace mihevc {
+
+__host__ __device__ static inline size_t round16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+// XCD-aware block -> CTU map: blocks b and b+8 share an XCD (and its L2), so give each XCD one contiguous run of
+// CTUs; neighbouring CTUs overlap in their search windows (MI355X_MICROARCH.md, workgroup dispatch).
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    int chunk = (n + 7) >> 3;
+    return (b & 7) * chunk + (b >> 3);
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void k_me_search(const InterArgs<T> *args, int n_ctu)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int ctu = xcd_remap(blockIdx.x, n_ctu);
+    if (ctu >= n_ctu) return;
+    const InterArgs<T> &a = args[blockIdx.y];
+    MeShared<T> &s = *reinterpret_cast<MeShared<T> *>(smem);
+    T *win = reinterpret_cast<T *>(smem + round16(sizeof(MeShared<T>)));
+    GpuExec ex;
+    me_search_program<T>(ex, s, win, a, ctu);
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void k_inter_ctu(const InterArgs<T> *args, int n_ctu)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int ctu = xcd_remap(blockIdx.x, n_ctu);
+    if (ctu >= n_ctu) return;
+    const InterArgs<T> &a = args[blockIdx.y];
+    const int R = a.prm.me_range;
+    InterShared<T> &s = *reinterpret_cast<InterShared<T> *>(smem);
+    size_t off = round16(sizeof(InterShared<T>));
+    T *wy = reinterpret_cast<T *>(smem + off);
+    off += round16((size_t)mc_win_y(R) * mc_win_y_stride(R) * sizeof(T));
+    T *wu = reinterpret_cast<T *>(smem + off);
+    off += round16((size_t)mc_win_c(R) * mc_win_c_stride(R) * sizeof(T));
+    T *wv = reinterpret_cast<T *>(smem + off);
+    GpuExec ex;
+    inter_ctu_program<T>(ex, s, wy, wu, wv, a, ctu);
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int cy_first)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const IntraArgs<T> &a = args[blockIdx.y];
+    const int cy = cy_first + blockIdx.x, cx = diagonal - 2 * cy;
+    if (cy >= a.ctus_h || cx < 0 || cx >= a.ctus_w) return;
+    IntraShared<T> &s = *reinterpret_cast<IntraShared<T> *>(smem);
+    GpuExec ex;
+    intra_ctu_program<T>(ex, s, a, cx, cy);
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_deblock(const DeblockArgs<T> *args)
+{
+    deblock_segment<T>(args[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
+}
+
+template <typename T> __global__ __launch_bounds__(NT) void k_sao_decide(const SaoArgs<T> *args, int n_ctu)
+{
+    __shared__ SaoShared s;
+    const int ctu = xcd_remap(blockIdx.x, n_ctu);
+    if (ctu >= n_ctu) return;
+    const SaoArgs<T> &a = args[blockIdx.y];
+    GpuExec ex;
+    sao_ctu_program<T>(ex, s, a, ctu);
+}
+
+// one thread per sample; rows of a plane are walked by consecutive lanes (coalesced)
+template <typename T> __global__ __launch_bounds__(256) void k_sao_apply(const SaoArgs<T> *args)
+{
+    const SaoArgs<T> &a = args[blockIdx.y];
+    const int nl = a.w * a.h, nc = nl >> 2;
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nl) { sao_apply_sample<T>(a, 0, i % a.w, i / a.w); return; }
+    i -= nl;
+    if (i < nc) { sao_apply_sample<T>(a, 1, i % (a.w >> 1), i / (a.w >> 1)); return; }
+    i -= nc;
+    if (i < nc) sao_apply_sample<T>(a, 2, i % (a.w >> 1), i / (a.w >> 1));
+}
+
+template <typename T> __global__ __launch_bounds__(256) void k_pad(const SaoArgs<T> *args)
+{
+    const SaoArgs<T> &a = args[blockIdx.y];
+    const int ny = (a.w + 2 * PAD_Y) * (a.h + 2 * PAD_Y), ncp = ((a.w >> 1) + 2 * PAD_C) * ((a.h >> 1) + 2 * PAD_C);
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < ny) { pad_sample<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
+    i -= ny;
+    if (i < ncp) { pad_sample<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
+    i -= ncp;
+    if (i < ncp) pad_sample<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
+}
+
+// fill the coded-size margin of a source plane (columns sw..pw-1, rows sh..ph-1) by edge replication
+template <typename T> __global__ __launch_bounds__(256) void k_extend_margin(Plane<T> p, int sw, int sh, int pw, int ph)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= pw * ph) return;
+    int x = i % pw, y = i / pw;
+    if (x < sw && y < sh) return;
+    p.p[(ptrdiff_t)y * p.stride + x] = p.p[(ptrdiff_t)(y < sh ? y : sh - 1) * p.stride + (x < sw ? x : sw - 1)];
+}
+template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p, int sw, int sh, int pw, int ph)
+{
+    hipLaunchKernelGGL(k_extend_margin<T>, dim3((unsigned)((pw * ph + 255) / 256)), dim3(256), 0, st, p, sw, sh, pw, ph);
+    return hipGetLastError();
+}
+
+// sum of squared error between source and final reconstruction, per plane (encoder PSNR statistics)
+template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const SaoArgs<T> *args)
+{
+    const SaoArgs<T> &a = args[blockIdx.y];
+    const int nl = a.w * a.h, nc = nl >> 2, n = nl + 2 * nc;
+    unsigned long long acc[3] = {0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        int pl = i < nl ? 0 : i < nl + nc ? 1 : 2, k = pl == 0 ? i : pl == 1 ? i - nl : i - nl - nc, pw = pl ? a.w >> 1 : a.w;
+        int x = k % pw, y = k / pw;
+        int d = (int)a.src[pl].p[(ptrdiff_t)y * a.src[pl].stride + x] - (int)a.out[pl].p[(ptrdiff_t)y * a.out[pl].stride + x];
+        acc[pl] += (unsigned long long)(d * d);
+    }
+    __shared__ unsigned long long red[3];
+    if (threadIdx.x < 3) red[threadIdx.x] = 0;
+    __syncthreads();
+    for (int pl = 0; pl < 3; pl++) {
+        unsigned long long v = acc[pl];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&red[pl], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && red[threadIdx.x]) atomicAdd(a.sse + threadIdx.x, red[threadIdx.x]);
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch)
+{
+    hipLaunchKernelGGL(k_frame_sse<T>, dim3(64, (unsigned)batch), dim3(256), 0, st, d_args);
+    return hipGetLastError();
+}
+template <typename K> static hipError_t ensure_smem(K kernel, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
+{
+    size_t smem = round16(sizeof(MeShared<T>)) + (size_t)(32 + 2 * R) * me_win_stride(R) * sizeof(T);
+    hipError_t e = ensure_smem(k_me_search<T>, smem);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);
+    hipLaunchKernelGGL(k_me_search<T>, grid, dim3(NT), smem, st, d_args, n_ctu);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
+{
+    size_t smem = round16(sizeof(InterShared<T>)) + round16((size_t)mc_win_y(R) * mc_win_y_stride(R) * sizeof(T)) +
+                  2 * round16((size_t)mc_win_c(R) * mc_win_c_stride(R) * sizeof(T));
+    hipError_t e = ensure_smem(k_inter_ctu<T>, smem);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);
+    hipLaunchKernelGGL(k_inter_ctu<T>, grid, dim3(NT), smem, st, d_args, n_ctu);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch)
+{
+    size_t smem = round16(sizeof(IntraShared<T>));
+    hipError_t e = ensure_smem(k_intra_diag<T>, smem);
+    if (e != hipSuccess) return e;
+    for (int d = 0; d <= (ctus_w - 1) + 2 * (ctus_h - 1); d++) {
+        int cy_lo = d - (ctus_w - 1) > 0 ? (d - (ctus_w - 1) + 1) / 2 : 0, cy_hi = d / 2 < ctus_h - 1 ? d / 2 : ctus_h - 1;
+        if (cy_hi < cy_lo) continue;
+        hipLaunchKernelGGL(k_intra_diag<T>, dim3((unsigned)(cy_hi - cy_lo + 1), (unsigned)batch), dim3(NT), smem, st, d_args, d, cy_lo);
+    }
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_deblock(hipStream_t st, const DeblockArgs<T> *d_v, const DeblockArgs<T> *d_h, int w, int h, int batch)
+{
+    int segs = (w >> 3) * (h >> 3) * 2;
+    dim3 grid((unsigned)((segs + 255) / 256), (unsigned)batch);
+    hipLaunchKernelGGL(k_deblock<T>, grid, dim3(256), 0, st, d_v);
+    hipLaunchKernelGGL(k_deblock<T>, grid, dim3(256), 0, st, d_h);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch, bool decide)
+{
+    int n_ctu = ((w + CTU - 1) / CTU) * ((h + CTU - 1) / CTU);
+    if (decide) hipLaunchKernelGGL(k_sao_decide<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), 0, st, d_args, n_ctu);
+    int n = w * h + (w * h >> 1);
+    hipLaunchKernelGGL(k_sao_apply<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch)
+{
+    int n = (w + 2 * PAD_Y) * (h + 2 * PAD_Y) + 2 * ((w >> 1) + 2 * PAD_C) * ((h >> 1) + 2 * PAD_C);
+    hipLaunchKernelGGL(k_pad<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t alloc_plane(DevPlane<T> &d, int w, int h, int pad)
+{
+    d.w = w; d.h = h; d.pad = pad;
+    d.pl.stride = (w + 2 * pad + 63) & ~63;
+    hipError_t e = hipMalloc((void **)&d.base, (size_t)d.pl.stride * (h + 2 * pad) * sizeof(T));
+    if (e != hipSuccess) { d.base = nullptr; return e; }
+    d.pl.p = d.base + (size_t)pad * d.pl.stride + pad;
+    return hipSuccess;
+}
+template <typename T> void free_plane(DevPlane<T> &d)
+{
+    if (d.base) (void)hipFree(d.base);
+    d.base = nullptr; d.pl.p = nullptr;
+}
+
+int gfx950_device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, i) == hipSuccess && strncmp(p.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+#define INSTANTIATE(T)                                                                                                   \
+    template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
+    template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
+    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int);                      \
+    template hipError_t launch_deblock<T>(hipStream_t, const DeblockArgs<T> *, const DeblockArgs<T> *, int, int, int);  \
+    template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
+    template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
+    template hipError_t launch_frame_sse<T>(hipStream_t, const SaoArgs<T> *, int);                                       \
+    template hipError_t launch_extend_margin<T>(hipStream_t, Plane<T>, int, int, int, int);                             \
+    template hipError_t alloc_plane<T>(DevPlane<T> &, int, int, int);                                                   \
+    template void free_plane<T>(DevPlane<T> &);
+INSTANTIATE(uint8_t)
+INSTANTIATE(uint16_t)
+
+// ------------------------------------------------------------------------------------------ K3 alone (parity/bench entry)
+// One workgroup per batch of residual blocks laid out as a pseudo-CTU: the blocks of one launch share log2n.
+__global__ __launch_bounds__(NT) void k_transform_blocks(const int16_t *res, int16_t *lvl, int16_t *rec, int n_blocks, int log2n, int qp,
+                                                         int bit_depth, int intra)
+{
+    __shared__ ResidualShared s;
+    GpuExec ex;
+    const int n = 1 << log2n, per = 1024 >> (2 * log2n);          // luma-area blocks per workgroup
+    const int first = blockIdx.x * per;
+    residual_init(ex, s);
+    ex.phase([&](int tid) {
+        if (tid < 16) {
+            int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
+            int blk = first + (ty >> (log2n < 3 ? 3 : log2n)) * (32 >> (log2n < 3 ? 3 : log2n)) + (tx >> (log2n < 3 ? 3 : log2n));
+            s.tu_log2[tid] = (log2n >= 3 && blk < n_blocks) ? (uint8_t)log2n : 0;
+            s.tu_intra[tid] = (uint8_t)intra;
+        }
+        for (int i = tid; i < 1536; i += NT) s.res[i] = 0;
+    });
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1024; i += NT) {
+            int x = i & 31, y = i >> 5, blk = first + (y >> log2n) * (32 >> log2n) + (x >> log2n);
+            if (blk < n_blocks) s.res[i] = res[(size_t)blk * n * n + (y & (n - 1)) * n + (x & (n - 1))];
+        }
+    });
+    residual_pipeline(ex, s, qp, qp, bit_depth);
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1024; i += NT) {
+            int x = i & 31, y = i >> 5, blk = first + (y >> log2n) * (32 >> log2n) + (x >> log2n);
+            if (blk >= n_blocks) continue;
+            size_t o = (size_t)blk * n * n + (y & (n - 1)) * n + (x & (n - 1));
+            lvl[o] = s.lvl[i];
+            rec[o] = s.res[i];
+        }
+    });
+}
+
+}  // namespace mihevc
+
+// ================================================================================================ C ABI: stages
+using namespace mihevc;
+
+namespace {
+
+struct DevBuf {      // RAII device allocation
+    void *p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    template <typename U> U *as() const { return static_cast<U *>(p); }
+};
+#define CK(expr)                                     \
+    do {                                             \
+        hipError_t e_ = (expr);                      \
+        if (e_ != hipSuccess) return MIHEVC_EDEVICE; \
+    } while (0)
+
+template <typename T> struct Planes3 {
+    DevPlane<T> p[3];
+    int alloc(int w, int h, bool padded)
+    {
+        for (int i = 0; i < 3; i++)
+            if (alloc_plane<T>(p[i], i ? w / 2 : w, i ? h / 2 : h, padded ? (i ? PAD_C : PAD_Y) : 0) != hipSuccess) return MIHEVC_ENOMEM;
+        return 0;
+    }
+    int upload(const void *y, const void *u, const void *v)
+    {
+        const void *src[3] = {y, u, v};
+        for (int i = 0; i < 3; i++)
+            CK(hipMemcpy2D(p[i].pl.p, p[i].pl.stride * sizeof(T), src[i], p[i].w * sizeof(T), p[i].w * sizeof(T), p[i].h, hipMemcpyHostToDevice));
+        return 0;
+    }
+    int download(void *y, void *u, void *v)
+    {
+        void *dst[3] = {y, u, v};
+        for (int i = 0; i < 3; i++)
+            CK(hipMemcpy2D(dst[i], p[i].w * sizeof(T), p[i].pl.p, p[i].pl.stride * sizeof(T), p[i].w * sizeof(T), p[i].h, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    ~Planes3() { for (auto &x : p) free_plane<T>(x); }
+};
+
+CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range}; }
+
+bool geometry_ok(int w, int h) { return w >= 16 && h >= 16 && !(w & 7) && !(h & 7) && w <= 8192 && h <= 4352; }
+
+template <typename T>
+int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *ry, void *ru, void *rv,
+                mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+{
+    Planes3<T> src, rec;
+    if (src.alloc(w, h, false) || rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
+    if (int e = src.upload(sy, su, sv)) return e;
+    const size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h;
+    DevBuf dcu, dc0, dc1, dc2, dargs;
+    CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dc0.alloc(ny * 2)); CK(dc1.alloc(ny / 2)); CK(dc2.alloc(ny / 2)); CK(dargs.alloc(sizeof(IntraArgs<T>)));
+    CK(hipMemset(dcu.p, 0, n8 * sizeof(mihevc_cu_rec)));
+    IntraArgs<T> a;
+    for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.rec[i] = rec.p[i].pl; }
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
+    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0;
+    CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
+    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1));
+    CK(hipDeviceSynchronize());
+    if (int e = rec.download(ry, ru, rv)) return e;
+    CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(cy, dc0.p, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cu_, dc1.p, ny / 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cv, dc2.p, ny / 2, hipMemcpyDeviceToHost));
+    return MIHEVC_OK;
+}
+
+template <typename T>
+int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, const void *fu, const void *fv, int w, int h,
+                const mihevc_cost_params *prm, const int16_t *centers, void *ry, void *ru, void *rv, mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_,
+                int16_t *cv, int32_t *me_dump)
+{
+    Planes3<T> src, ref, rec;
+    if (src.alloc(w, h, false) || ref.alloc(w, h, true) || rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
+    if (int e = src.upload(sy, su, sv)) return e;
+    if (int e = ref.upload(fy, fu, fv)) return e;
+    const int ctus_w = (w + CTU - 1) / CTU, n_ctu = ctus_w * ((h + CTU - 1) / CTU);
+    const size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h;
+    DevBuf dcu, dc0, dc1, dc2, dargs, dme, dcen, dpad;
+    CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dc0.alloc(ny * 2)); CK(dc1.alloc(ny / 2)); CK(dc2.alloc(ny / 2));
+    CK(dargs.alloc(sizeof(InterArgs<T>))); CK(dme.alloc((size_t)n_ctu * 63 * 4)); CK(dcen.alloc((size_t)n_ctu * 4)); CK(dpad.alloc(sizeof(SaoArgs<T>)));
+    CK(hipMemset(dcu.p, 0, n8 * sizeof(mihevc_cu_rec)));
+    if (centers) CK(hipMemcpy(dcen.p, centers, (size_t)n_ctu * 4, hipMemcpyHostToDevice));
+    // border extension of the uploaded reference (the pad kernel works on the `out` planes of a SaoArgs block)
+    SaoArgs<T> pa;
+    memset(&pa, 0, sizeof pa);
+    for (int i = 0; i < 3; i++) pa.out[i] = ref.p[i].pl;
+    pa.w = w; pa.h = h;
+    CK(hipMemcpy(dpad.p, &pa, sizeof pa, hipMemcpyHostToDevice));
+    CK(launch_pad<T>(0, dpad.as<SaoArgs<T>>(), w, h, 1));
+    InterArgs<T> a;
+    for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.ref[i] = {ref.p[i].pl.p, ref.p[i].pl.stride}; a.rec[i] = rec.p[i].pl; }
+    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.centers = centers ? dcen.as<int16_t>() : nullptr; a.me = dme.as<int32_t>();
+    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>();
+    CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
+    CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
+    CK(launch_inter_ctu<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
+    CK(hipDeviceSynchronize());
+    if (int e = rec.download(ry, ru, rv)) return e;
+    CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(cy, dc0.p, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cu_, dc1.p, ny / 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cv, dc2.p, ny / 2, hipMemcpyDeviceToHost));
+    if (me_dump) CK(hipMemcpy(me_dump, dme.p, (size_t)n_ctu * 63 * 4, hipMemcpyDeviceToHost));
+    return MIHEVC_OK;
+}
+
+template <typename T> int stage_deblock(void *ry, void *ru, void *rv, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
+{
+    Planes3<T> rec;
+    if (rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
+    if (int e = rec.upload(ry, ru, rv)) return e;
+    const size_t n8 = (size_t)(w / 8) * (h / 8);
+    DevBuf dcu, dargs;
+    CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dargs.alloc(2 * sizeof(DeblockArgs<T>)));
+    CK(hipMemcpy(dcu.p, cu, n8 * sizeof(mihevc_cu_rec), hipMemcpyHostToDevice));
+    DeblockArgs<T> a[2];
+    for (int d = 0; d < 2; d++) {
+        for (int i = 0; i < 3; i++) a[d].rec[i] = rec.p[i].pl;
+        a[d].w = w; a[d].h = h; a[d].cu = dcu.as<mihevc_cu_rec>(); a[d].bit_depth = bit_depth; a[d].dir = d;
+    }
+    CK(hipMemcpy(dargs.p, a, sizeof a, hipMemcpyHostToDevice));
+    CK(launch_deblock<T>(0, dargs.as<DeblockArgs<T>>(), dargs.as<DeblockArgs<T>>() + 1, w, h, 1));
+    CK(hipDeviceSynchronize());
+    return rec.download(ry, ru, rv);
+}
+
+template <typename T>
+int stage_sao(const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int h,
+              const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *sao)
+{
+    Planes3<T> src, dbk, out;
+    if (src.alloc(w, h, false) || dbk.alloc(w, h, false) || out.alloc(w, h, true)) return MIHEVC_ENOMEM;
+    if (int e = src.upload(sy, su, sv)) return e;
+    if (int e = dbk.upload(dy, du, dv)) return e;
+    const int ctus_w = (w + CTU - 1) / CTU, n_ctu = ctus_w * ((h + CTU - 1) / CTU);
+    DevBuf dsao, dargs;
+    CK(dsao.alloc((size_t)n_ctu * sizeof(mihevc_sao_ctu))); CK(dargs.alloc(sizeof(SaoArgs<T>)));
+    SaoArgs<T> a;
+    for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.dbk[i] = {dbk.p[i].pl.p, dbk.p[i].pl.stride}; a.out[i] = out.p[i].pl; }
+    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.sao = dsao.as<mihevc_sao_ctu>(); a.sse = nullptr;
+    CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
+    CK(launch_sao<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1, true));
+    CK(launch_pad<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1));
+    CK(hipDeviceSynchronize());
+    if (int e = out.download(oy, ou, ov)) return e;
+    CK(hipMemcpy(sao, dsao.p, (size_t)n_ctu * sizeof(mihevc_sao_ctu), hipMemcpyDeviceToHost));
+    return MIHEVC_OK;
+}
+
+int select_device(int device)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIHEVC_ENODEV;
+    if (device < 0 || device >= n) return MIHEVC_EINVAL;
+    return hipSetDevice(device) == hipSuccess ? 0 : MIHEVC_EDEVICE;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mihevc_device_count(void) { return gfx950_device_count(); }
+
+int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int16_t *recon_residual, int n_blocks, int log2n, int qp,
+                       int bit_depth, int intra, int dst4)
+{
+    if (!residual || !levels || !recon_residual || n_blocks <= 0 || log2n < 2 || log2n > 5 || dst4) return MIHEVC_EINVAL;
+    if (bit_depth != 8 && bit_depth != 10) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    const size_t bytes = (size_t)n_blocks << (2 * log2n + 1);
+    DevBuf dres, dlvl, drec;
+    CK(dres.alloc(bytes)); CK(dlvl.alloc(bytes)); CK(drec.alloc(bytes));
+    CK(hipMemcpy(dres.p, residual, bytes, hipMemcpyHostToDevice));
+    // 4x4 blocks are packed as chroma-style TUs of an 8x8 luma grid: run them through the 8x8 tile map with log2 2
+    if (log2n == 2) return MIHEVC_EINVAL;     // 4x4 is exercised through the chroma planes of the frame stages
+    const int per = 1024 >> (2 * log2n);
+    hipLaunchKernelGGL(k_transform_blocks, dim3((unsigned)((n_blocks + per - 1) / per)), dim3(NT), 0, 0, dres.as<int16_t>(), dlvl.as<int16_t>(),
+                       drec.as<int16_t>(), n_blocks, log2n, qp, bit_depth, intra);
+    CK(hipGetLastError());
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(levels, dlvl.p, bytes, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(recon_residual, drec.p, bytes, hipMemcpyDeviceToHost));
+    return MIHEVC_OK;
+}
+
+int mihevc_k_intra_frame(int device, const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *ry, void *ru,
+                         void *rv, mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+{
+    if (!sy || !su || !sv || !prm || !ry || !ru || !rv || !cu || !cy || !cu_ || !cv || !geometry_ok(w, h)) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    if (prm->bit_depth == 8) return stage_intra<uint8_t>(sy, su, sv, w, h, prm, ry, ru, rv, cu, cy, cu_, cv);
+    if (prm->bit_depth == 10) return stage_intra<uint16_t>(sy, su, sv, w, h, prm, ry, ru, rv, cu, cy, cu_, cv);
+    return MIHEVC_EINVAL;
+}
+
+int mihevc_k_inter_frame(int device, const void *sy, const void *su, const void *sv, const void *fy, const void *fu, const void *fv, int w, int h,
+                         const mihevc_cost_params *prm, const int16_t *centers, void *ry, void *ru, void *rv, mihevc_cu_rec *cu, int16_t *cy,
+                         int16_t *cu_, int16_t *cv, int32_t *me_dump)
+{
+    if (!sy || !su || !sv || !fy || !fu || !fv || !prm || !ry || !ru || !rv || !cu || !cy || !cu_ || !cv || !geometry_ok(w, h)) return MIHEVC_EINVAL;
+    if (prm->me_range < 1 || prm->me_range > MAX_RANGE) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    if (prm->bit_depth == 8) return stage_inter<uint8_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump);
+    if (prm->bit_depth == 10) return stage_inter<uint16_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump);
+    return MIHEVC_EINVAL;
+}
+
+int mihevc_k_deblock(int device, void *ry, void *ru, void *rv, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
+{
+    if (!ry || !ru || !rv || !cu || !geometry_ok(w, h)) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    if (bit_depth == 8) return stage_deblock<uint8_t>(ry, ru, rv, w, h, cu, bit_depth);
+    if (bit_depth == 10) return stage_deblock<uint16_t>(ry, ru, rv, w, h, cu, bit_depth);
+    return MIHEVC_EINVAL;
+}
+
+int mihevc_k_sao(int device, const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int h,
+                 const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *sao)
+{
+    if (!sy || !su || !sv || !dy || !du || !dv || !prm || !oy || !ou || !ov || !sao || !geometry_ok(w, h)) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    if (prm->bit_depth == 8) return stage_sao<uint8_t>(sy, su, sv, dy, du, dv, w, h, prm, oy, ou, ov, sao);
+    if (prm->bit_depth == 10) return stage_sao<uint16_t>(sy, su, sv, dy, du, dv, w, h, prm, oy, ou, ov, sao);
+    return MIHEVC_EINVAL;
+}
+
+}  // extern "C"

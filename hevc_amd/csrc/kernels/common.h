@@ -1,0 +1,228 @@
+// hevc_amd/csrc/kernels/common.h — shared definitions of the gfx950 kernels.
+//
+// Every per-CTU kernel is written as a "phase program": a sequence of phases, each a lambda run by all threads of
+// the workgroup followed by a workgroup barrier (`ex.phase(...)`).  Thread-private values never live across a phase
+// boundary; everything that does lives in the workgroup's LDS image (`Shared` structs).  The HIP executor
+// (GpuExec, below) maps a phase to `f(threadIdx.x); __syncthreads();`.  tests/emu/ instantiates the same programs
+// with a sequential executor to step the kernel source on a CPU — a structural test of the kernel logic, not a
+// product path (the package never loads it).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define DEV __device__ __forceinline__
+#define HD __host__ __device__
+#define HDI __host__ __device__ inline
+#define DEVCONST __device__ const
+#define MIHEVC_GPU 1
+#else
+#define DEV inline
+#define HD
+#define HDI inline
+#define DEVCONST static const
+#define MIHEVC_GPU 0
+#endif
+
+#include "../../../include/mihevc.h"
+
+namespace mihevc {
+
+constexpr int CTU = 32;
+constexpr int CTU_LOG2 = 5;
+constexpr int PAD_Y = 80;     // luma border of reference planes
+constexpr int PAD_C = 40;
+constexpr int NT = 256;       // threads per CTU workgroup
+constexpr int MAX_RANGE = 64;
+
+enum : uint8_t { CU_INTER = 1, CU_CBF_Y = 2, CU_CBF_CB = 4, CU_CBF_CR = 8, CU_NXN = 16 };
+
+template <typename T> struct PixTraits;
+template <> struct PixTraits<uint8_t> { static constexpr int kBitDepth = 8; };
+template <> struct PixTraits<uint16_t> { static constexpr int kBitDepth = 10; };
+
+// a sample plane; `p` addresses sample (0,0); padded planes hold valid samples at negative coordinates
+template <typename T> struct Plane {
+    T *p;
+    int stride;
+};
+
+struct CostParams {
+    int qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
+};
+
+// ------------------------------------------------------------------------------------------ tables
+struct Tables {
+    int8_t mat[32][32];       // H.265 8.6.4.2 transMatrix (32-point; N-point = rows k*(32/N), first N columns)
+    int8_t dst4[4][4];
+    int8_t luma_tap[4][8];    // 8.5.3.3.3.1 Table 8-11
+    int8_t chroma_tap[8][4];  // Table 8-12
+    int8_t intra_angle[35];   // 8.4.4.2.6 Table 8-4
+    int16_t inv_angle[15];    // Table 8-5 (modes 11..25)
+    uint8_t beta[52], tc[54]; // 8.7.2.5.3 Table 8-12 (beta', tc')
+    int16_t quant_scale[6];
+    uint8_t level_scale[6];
+    int8_t chroma_qp[14];     // Table 8-10 for qPi 30..43
+    uint8_t zorder[16];       // 4x4 grid of 8x8 tiles: raster index -> z-order index
+};
+
+constexpr Tables make_tables()
+{
+    Tables t{};
+    const int c64[33] = {64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64, 61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0};
+    for (int k = 0; k < 32; k++)
+        for (int n = 0; n < 32; n++) {
+            int a = (k * (2 * n + 1)) % 128;
+            if (a > 64) a = 128 - a;
+            t.mat[k][n] = (int8_t)(a > 32 ? -c64[64 - a] : c64[a]);
+        }
+    const int d[4][4] = {{29, 55, 74, 84}, {74, 74, 0, -74}, {84, -29, -74, 55}, {55, -84, 74, -29}};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) t.dst4[i][j] = (int8_t)d[i][j];
+    const int lt[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) t.luma_tap[i][j] = (int8_t)lt[i][j];
+    const int ct[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 4; j++) t.chroma_tap[i][j] = (int8_t)ct[i][j];
+    const int ang[35] = {0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32};
+    for (int i = 0; i < 35; i++) t.intra_angle[i] = (int8_t)ang[i];
+    const int inv[15] = {-4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096};
+    for (int i = 0; i < 15; i++) t.inv_angle[i] = (int16_t)inv[i];
+    for (int q = 0; q < 52; q++) t.beta[q] = (uint8_t)(q < 16 ? 0 : q < 29 ? q - 10 : 2 * q - 38);
+    const int tcv[54] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4,
+                         5, 5, 6, 6, 7, 8, 9, 10, 11, 13, 14, 16, 18, 20, 22, 24};
+    for (int i = 0; i < 54; i++) t.tc[i] = (uint8_t)tcv[i];
+    const int qs[6] = {26214, 23302, 20560, 18396, 16384, 14564}, ls[6] = {40, 45, 51, 57, 64, 72};
+    for (int i = 0; i < 6; i++) { t.quant_scale[i] = (int16_t)qs[i]; t.level_scale[i] = (uint8_t)ls[i]; }
+    const int cq[14] = {29, 30, 31, 32, 33, 33, 34, 34, 35, 35, 36, 36, 37, 37};
+    for (int i = 0; i < 14; i++) t.chroma_qp[i] = (int8_t)cq[i];
+    for (int ty = 0; ty < 4; ty++)
+        for (int tx = 0; tx < 4; tx++) t.zorder[ty * 4 + tx] = (uint8_t)(((ty >> 1) * 2 + (tx >> 1)) * 4 + (ty & 1) * 2 + (tx & 1));
+    return t;
+}
+DEVCONST Tables g_tab = make_tables();
+
+// ------------------------------------------------------------------------------------------ small helpers
+DEV int iabs(int v) { return v < 0 ? -v : v; }
+DEV int imin(int a, int b) { return a < b ? a : b; }
+DEV int imax(int a, int b) { return a > b ? a : b; }
+DEV int clip3(int lo, int hi, int v) { return v < lo ? lo : v > hi ? hi : v; }
+DEV int ilog2u(unsigned v) { return 31 - __builtin_clz(v | 1); }
+DEV int mvd_bits(int d)
+{
+    int a = iabs(d);
+    return a == 0 ? 1 : a == 1 ? 3 : 3 + 2 * ilog2u((unsigned)a);
+}
+DEV int chroma_qp_of(int qp)
+{
+    int q = clip3(-12, 57, qp);
+    return q < 30 ? q : q > 43 ? q - 6 : g_tab.chroma_qp[q - 30];
+}
+// z-scan address of the 4x4 unit holding luma sample (x,y) (6.4.1 at min-TB granularity)
+DEV int zaddr(int x, int y, int ctus_w)
+{
+    int bx = (x & 31) >> 2, by = (y & 31) >> 2, z = 0;
+    for (int i = 0; i < 3; i++) z |= ((bx >> i) & 1) << (2 * i) | ((by >> i) & 1) << (2 * i + 1);
+    return (((y >> CTU_LOG2) * ctus_w + (x >> CTU_LOG2)) << 6) | z;
+}
+// quadtree node geometry: 0 = 32x32, 1..4 = 16x16 (z-order), 5..20 = 8x8 (z-order inside each 16x16)
+DEV void node_geom(int node, int &x, int &y, int &log2n)
+{
+    if (node == 0) { x = 0; y = 0; log2n = 5; }
+    else if (node < 5) { int q = node - 1; x = (q & 1) * 16; y = (q >> 1) * 16; log2n = 4; }
+    else { int q = (node - 5) >> 2, s = (node - 5) & 3; x = (q & 1) * 16 + (s & 1) * 8; y = (q >> 1) * 16 + (s >> 1) * 8; log2n = 3; }
+}
+// node that covers tile (tx,ty) of the 4x4 tile grid at level 0 (32), 1 (16), 2 (8)
+DEV int node_of_tile(int level, int tx, int ty)
+{
+    if (level == 0) return 0;
+    int q = (ty >> 1) * 2 + (tx >> 1);
+    return level == 1 ? 1 + q : 5 + q * 4 + (ty & 1) * 2 + (tx & 1);
+}
+
+// sum of absolute differences of 4 (8-bit) / 2 (16-bit) packed samples
+DEV uint32_t sad_packed_u8(uint32_t a, uint32_t b, uint32_t acc)
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_sad_u8(a, b, acc);
+#else
+    for (int i = 0; i < 4; i++) acc += (uint32_t)iabs((int)((a >> (8 * i)) & 255) - (int)((b >> (8 * i)) & 255));
+    return acc;
+#endif
+}
+DEV uint32_t sad_packed_u16(uint32_t a, uint32_t b, uint32_t acc)
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_sad_u16(a, b, acc);
+#else
+    for (int i = 0; i < 2; i++) acc += (uint32_t)iabs((int)((a >> (16 * i)) & 65535) - (int)((b >> (16 * i)) & 65535));
+    return acc;
+#endif
+}
+DEV uint32_t load_u32(const void *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+// SAD of one 8-sample row
+DEV uint32_t sad_row8(const uint8_t *a, const uint8_t *b, uint32_t acc)
+{
+    acc = sad_packed_u8(load_u32(a), load_u32(b), acc);
+    return sad_packed_u8(load_u32(a + 4), load_u32(b + 4), acc);
+}
+DEV uint32_t sad_row8(const uint16_t *a, const uint16_t *b, uint32_t acc)
+{
+    for (int i = 0; i < 8; i += 2) acc = sad_packed_u16(load_u32(a + i), load_u32(b + i), acc);
+    return acc;
+}
+
+// in-place 8x8 Hadamard SATD of a difference block held in registers: (sum |H d H| + 2) >> 2
+DEV int hadamard8_satd(int (&m)[8][8])
+{
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[y][i], q = m[y][i + st]; m[y][i] = p + q; m[y][i + st] = p - q; }
+    }
+    int s = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[i][x], q = m[i + st][x]; m[i][x] = p + q; m[i + st][x] = p - q; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) s += iabs(m[i][x]);
+    }
+    return (s + 2) >> 2;
+}
+
+// ------------------------------------------------------------------------------------------ executors
+#if MIHEVC_GPU
+struct GpuExec {
+    template <class F> DEV void phase(F &&f)
+    {
+        f((int)threadIdx.x);
+        __syncthreads();
+    }
+    DEV void atomic_add(int *p, int v) { atomicAdd(p, v); }
+    DEV void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
+    DEV void atomic_or(unsigned *p, unsigned v) { atomicOr(p, v); }
+    DEV void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
+};
+#endif
+struct SeqExec {      // sequential stepping of a phase program (tests/emu)
+    template <class F> void phase(F &&f)
+    {
+        for (int t = 0; t < NT; t++) f(t);
+    }
+    void atomic_add(int *p, int v) { *p += v; }
+    void atomic_add(unsigned *p, unsigned v) { *p += v; }
+    void atomic_or(unsigned *p, unsigned v) { *p |= v; }
+    void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
+};
+
+}  // namespace mihevc

@@ -1,0 +1,335 @@
+// hevc_amd/csrc/kernels/inter.h — K1 (integer full-search SAD + fractional SATD refinement) and the P-picture
+// CTU program (quadtree decision, motion compensation, K3 residual, reconstruction).
+//
+// One 256-thread workgroup per 32x32 CTU; every CTU of a P picture is independent (the reference picture is the
+// previous reconstructed picture), so the grid is all CTUs of all pictures in flight.  Source tile and reference
+// search window are staged through LDS with row-contiguous loads; nothing else is read from HBM.
+// Decisions are defined by oracle/hevc_oracle.c orc_analyze_inter_frame and reproduced exactly:
+//   integer:  cost = (SAD << 4) + lambda_sad_q4 * (bits(4dx) + bits(4dy)), ties -> smaller raster position
+//   fraction: half-pel ring then quarter-pel ring, cost = (SATD << 4) + lambda * mvd bits, ties -> lower index
+//   tree:     bottom-up, J = cost + 4 lambda per CU, split adds 2 lambda, whole wins ties
+// Motion compensation is H.265 8.5.3.3.3 (luma 8-tap, chroma 4-tap, uni-prediction rounding).
+#pragma once
+#include "common.h"
+#include "residual.h"
+
+namespace mihevc {
+
+template <typename T> struct InterArgs {
+    Plane<const T> src[3];       // unpadded source planes (coded size)
+    Plane<const T> ref[3];       // padded reference reconstruction
+    Plane<T> rec[3];             // pre-deblock reconstruction out (may be padded planes; only [0,w)x[0,h) written)
+    int w, h, ctus_w;
+    CostParams prm;
+    const int16_t *centers;      // per CTU (sx, sy) integer search centre, or nullptr
+    int32_t *me;                 // per CTU 21 x (mvx, mvy, cost): written by me_search, read by inter_ctu
+    mihevc_cu_rec *cu;           // (h/8) x (w/8)
+    int16_t *coef[3];            // strides w, w/2, w/2
+};
+
+// candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
+DEVCONST int8_t kOff[9][2] = {{0, 0}, {-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+
+// ------------------------------------------------------------------------------------------ integer search
+template <typename T> struct MeShared {
+    T src[32 * 32];
+    unsigned long long best[21];
+    uint8_t valid[21];
+    // followed in LDS by the search window: T win[(32 + 2R) * wstride]
+};
+HDI int me_win_stride(int R) { return 32 + 2 * R + 4; }    // +4 keeps rows 4-byte aligned for 8-bit samples
+
+template <typename T, class Ex>
+DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a, int ctu)
+{
+    const int R = a.prm.me_range, span = 2 * R + 1, ws = me_win_stride(R), wn = 32 + 2 * R;
+    const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
+    const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1024; i += NT) {
+            int x = x0 + (i & 31), y = y0 + (i >> 5);
+            s.src[i] = (x < a.w && y < a.h) ? a.src[0].p[(size_t)y * a.src[0].stride + x] : (T)0;
+        }
+        for (int i = tid; i < wn * wn; i += NT) {
+            int wx = i % wn, wy = i / wn;
+            int x = clip3(-PAD_Y, a.w + PAD_Y - 1, x0 + sx - R + wx), y = clip3(-PAD_Y, a.h + PAD_Y - 1, y0 + sy - R + wy);
+            win[wy * ws + wx] = a.ref[0].p[(ptrdiff_t)y * a.ref[0].stride + x];
+        }
+        if (tid < 21) {
+            int nx, ny, nl;
+            node_geom(tid, nx, ny, nl);
+            s.valid[tid] = x0 + nx + (1 << nl) <= a.w && y0 + ny + (1 << nl) <= a.h;
+            s.best[tid] = ~0ull;
+        }
+    });
+    ex.phase([&](int tid) {
+        unsigned long long best[21];
+        for (int n = 0; n < 21; n++) best[n] = ~0ull;
+        for (int p = tid; p < span * span; p += NT) {
+            int dx = p % span - R, dy = p / span - R;
+            unsigned sad8[16];
+            for (int b = 0; b < 16; b++) {           // b in z-order: node 5 + b
+                sad8[b] = 0;
+                if (!s.valid[5 + b]) continue;
+                int bx, by, bl;
+                node_geom(5 + b, bx, by, bl);
+                const T *sp = s.src + by * 32 + bx;
+                const T *rp = win + (by + dy + R) * ws + bx + dx + R;
+                unsigned acc = 0;
+                for (int r = 0; r < 8; r++) acc = sad_row8(sp + r * 32, rp + r * ws, acc);
+                sad8[b] = acc;
+            }
+            unsigned bits = (unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * dx) + mvd_bits(4 * dy)));
+            unsigned s32 = 0;
+            for (int q = 0; q < 4; q++) {
+                unsigned s16 = sad8[4 * q] + sad8[4 * q + 1] + sad8[4 * q + 2] + sad8[4 * q + 3];
+                s32 += s16;
+                unsigned long long k16 = ((unsigned long long)((s16 << 4) + bits) << 16) | (unsigned)p;
+                if (k16 < best[1 + q]) best[1 + q] = k16;
+                for (int t = 0; t < 4; t++) {
+                    unsigned long long k8 = ((unsigned long long)((sad8[4 * q + t] << 4) + bits) << 16) | (unsigned)p;
+                    if (k8 < best[5 + 4 * q + t]) best[5 + 4 * q + t] = k8;
+                }
+            }
+            unsigned long long k32 = ((unsigned long long)((s32 << 4) + bits) << 16) | (unsigned)p;
+            if (k32 < best[0]) best[0] = k32;
+        }
+        for (int n = 0; n < 21; n++)
+            if (s.valid[n] && best[n] != ~0ull) ex.atomic_min(&s.best[n], best[n]);
+    });
+    ex.phase([&](int tid) {
+        if (tid < 21) {
+            int32_t *o = a.me + ((size_t)ctu * 21 + tid) * 3;
+            if (s.valid[tid]) {
+                int p = (int)(s.best[tid] & 0xffff);
+                o[0] = 4 * (sx + p % span - R); o[1] = 4 * (sy + p / span - R); o[2] = (int32_t)(s.best[tid] >> 16);
+            } else { o[0] = 0; o[1] = 0; o[2] = -1; }
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------ P-picture CTU program
+template <typename T> struct InterShared {
+    ResidualShared rs;
+    T src[1536];                 // Y 32x32, U 16x16, V 16x16
+    T pred[1536];
+    int mvx[21], mvy[21];
+    unsigned cost[21];           // current best cost of each node (SATD << 4 + lambda * mvd bits)
+    uint8_t valid[21];
+    int satd[3][9][16];          // [level][candidate][tile]
+    int tile_mvx[16], tile_mvy[16];
+    uint8_t tile_node[16];
+    // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
+};
+HDI int mc_win_y(int R) { return 32 + 2 * R + 8; }
+HDI int mc_win_y_stride(int R) { return mc_win_y(R) + 4; }
+HDI int mc_win_c(int R) { return 16 + R + 8; }
+HDI int mc_win_c_stride(int R) { return mc_win_c(R) + 4; }
+
+// quarter-sample luma prediction of one 8x8 tile from the LDS window (8.5.3.3.3.1; the general 2-D form with the
+// {0,0,0,64,0,0,0,0} tap set for a zero fraction is exact for every case).  p00 = window sample at the tile's
+// integer position.  When diff_src != nullptr returns the 8x8 Hadamard SATD of (src - pred), else writes pred.
+template <typename T>
+DEV int luma_tile(const T *p00, int ws, int fx, int fy, int bit_depth, const T *diff_src, int src_stride, T *pred_out, int pred_stride)
+{
+    const int8_t *tx = g_tab.luma_tap[fx], *ty = g_tab.luma_tap[fy];
+    const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
+    int acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[j][i] = 0;
+    for (int r = 0; r < 15; r++) {                 // intermediate row r corresponds to reference row r - 3
+        const T *row = p00 + (r - 3) * ws - 3;
+        int px[15];
+#pragma unroll
+        for (int i = 0; i < 15; i++) px[i] = row[i];
+        int hv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v += tx[k] * px[i + k];
+            hv[i] = v >> shift1;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int k = r - j;
+            if (k >= 0 && k < 8) {
+                int t = ty[k];
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[j][i] += t * hv[i];
+            }
+        }
+    }
+    const int off = 1 << (shift3 - 1);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int v = clip3(0, maxv, ((acc[j][i] >> 6) + off) >> shift3);
+            if (diff_src) acc[j][i] = (int)diff_src[j * src_stride + i] - v;
+            else pred_out[j * pred_stride + i] = (T)v;
+        }
+    return diff_src ? hadamard8_satd(acc) : 0;
+}
+
+template <typename T>
+DEV int chroma_sample(const T *p00, int ws, int fx, int fy, int bit_depth)
+{
+    const int8_t *tx = g_tab.chroma_tap[fx], *ty = g_tab.chroma_tap[fy];
+    const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
+    int acc = 0;
+    for (int r = 0; r < 4; r++) {
+        const T *row = p00 + (r - 1) * ws - 1;
+        int v = tx[0] * row[0] + tx[1] * row[1] + tx[2] * row[2] + tx[3] * row[3];
+        acc += ty[r] * (v >> shift1);
+    }
+    return clip3(0, maxv, ((acc >> 6) + (1 << (shift3 - 1))) >> shift3);
+}
+
+template <typename T, class Ex>
+DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win_v, const InterArgs<T> &a, int ctu)
+{
+    const int R = a.prm.me_range, bd = a.prm.bit_depth, lam = a.prm.lambda_sad_q4;
+    const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
+    const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
+    const int wy = mc_win_y(R), wys = mc_win_y_stride(R), wc = mc_win_c(R), wcs = mc_win_c_stride(R);
+    const int oy_x = x0 + sx - R - 4, oy_y = y0 + sy - R - 4;                                  // luma window origin
+    const int oc_x = (x0 >> 1) + ((4 * sx - 4 * R - 3) >> 3) - 1, oc_y = (y0 >> 1) + ((4 * sy - 4 * R - 3) >> 3) - 1;
+
+    residual_init(ex, s.rs);
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1536; i += NT) {
+            int pl, x, y;
+            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
+            int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
+            s.src[i] = (gx < pw && gy < ph) ? a.src[pl].p[(size_t)gy * a.src[pl].stride + gx] : (T)0;
+        }
+        for (int i = tid; i < wy * wy; i += NT) {
+            int cx = i % wy, cy = i / wy;
+            int x = clip3(-PAD_Y, a.w + PAD_Y - 1, oy_x + cx), y = clip3(-PAD_Y, a.h + PAD_Y - 1, oy_y + cy);
+            win_y[cy * wys + cx] = a.ref[0].p[(ptrdiff_t)y * a.ref[0].stride + x];
+        }
+        for (int i = tid; i < 2 * wc * wc; i += NT) {
+            int pl = i >= wc * wc, k = pl ? i - wc * wc : i, cx = k % wc, cy = k / wc;
+            int x = clip3(-PAD_C, (a.w >> 1) + PAD_C - 1, oc_x + cx), y = clip3(-PAD_C, (a.h >> 1) + PAD_C - 1, oc_y + cy);
+            (pl ? win_v : win_u)[cy * wcs + cx] = a.ref[1 + pl].p[(ptrdiff_t)y * a.ref[1 + pl].stride + x];
+        }
+        if (tid < 21) {
+            const int32_t *m = a.me + ((size_t)ctu * 21 + tid) * 3;
+            s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.valid[tid] = m[2] >= 0; s.cost[tid] = 0;
+        }
+    });
+    // fractional refinement: round 0 = centre + half-pel ring, round 1 = quarter-pel ring
+    for (int round = 0; round < 2; round++) {
+        const int step = round == 0 ? 2 : 1, k0 = round == 0 ? 0 : 1;
+        ex.phase([&](int tid) {
+            for (int u = tid; u < 3 * 9 * 16; u += NT) {
+                int level = u / 144, k = (u / 16) % 9, t = u & 15;
+                if (k < k0) continue;
+                int txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
+                if (!s.valid[node]) continue;
+                int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
+                int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
+                s.satd[level][k][t] = luma_tile<T>(win_y + py * wys + px, wys, mx & 3, my & 3, bd, s.src + typ * 8 * 32 + txp * 8, 32, nullptr, 0);
+            }
+        });
+        ex.phase([&](int tid) {
+            if (tid >= 21 || !s.valid[tid]) return;
+            int nx, ny, nl;
+            node_geom(tid, nx, ny, nl);
+            int level = 5 - nl, tiles = 1 << (nl - 3);
+            unsigned long long best = round == 0 ? ~0ull : ((unsigned long long)s.cost[tid] << 4);
+            for (int k = k0; k < 9; k++) {
+                unsigned satd = 0;
+                for (int j = 0; j < tiles; j++)
+                    for (int i = 0; i < tiles; i++) satd += (unsigned)s.satd[level][k][((ny >> 3) + j) * 4 + (nx >> 3) + i];
+                int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
+                unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
+                unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
+                if (key < best) best = key;
+            }
+            int k = (int)(best & 15);
+            s.mvx[tid] += kOff[k][0] * step; s.mvy[tid] += kOff[k][1] * step;
+            s.cost[tid] = (unsigned)(best >> 4);
+        });
+    }
+    // quadtree decision
+    ex.phase([&](int tid) {
+        if (tid != 0) return;
+        unsigned J[21];
+        for (int n = 0; n < 21; n++) J[n] = s.valid[n] ? s.cost[n] + (unsigned)(lam * 4) : 0;
+        int use16[4], use32;
+        unsigned J16[4], js32 = (unsigned)(lam * 2);
+        for (int q = 0; q < 4; q++) {
+            unsigned js = (unsigned)(lam * 2);
+            for (int t = 0; t < 4; t++) if (s.valid[5 + 4 * q + t]) js += J[5 + 4 * q + t];
+            use16[q] = s.valid[1 + q] && J[1 + q] <= js;
+            J16[q] = use16[q] ? J[1 + q] : js;
+            js32 += J16[q];
+        }
+        use32 = s.valid[0] && J[0] <= js32;
+        for (int t = 0; t < 16; t++) {
+            int txp = t & 3, typ = t >> 2, q = (typ >> 1) * 2 + (txp >> 1);
+            int n8 = node_of_tile(2, txp, typ);
+            int node = use32 ? 0 : use16[q] ? 1 + q : n8;
+            int inside = s.valid[n8];                 // the 8x8 tile itself lies inside the picture
+            s.tile_node[t] = (uint8_t)node;
+            s.tile_mvx[t] = s.mvx[node]; s.tile_mvy[t] = s.mvy[node];
+            s.rs.tu_log2[t] = inside ? (uint8_t)(node == 0 ? 5 : node < 5 ? 4 : 3) : 0;
+            s.rs.tu_intra[t] = 0;
+        }
+    });
+    // motion compensation of the chosen CUs: luma per 8x8 tile (threads 0..15), chroma per sample (threads 64..255)
+    ex.phase([&](int tid) {
+        if (tid < 16) {
+            int t = tid, txp = t & 3, typ = t >> 2;
+            if (s.rs.tu_log2[t]) {
+                int mx = s.tile_mvx[t], my = s.tile_mvy[t];
+                int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
+                luma_tile<T>(win_y + py * wys + px, wys, mx & 3, my & 3, bd, nullptr, 0, s.pred + typ * 8 * 32 + txp * 8, 32);
+            }
+        } else if (tid >= 64) {
+            for (int i = tid - 64; i < 512; i += NT - 64) {
+                int pl = i >> 8, k = i & 255, x = k & 15, y = k >> 4, t = (y >> 2) * 4 + (x >> 2);
+                if (!s.rs.tu_log2[t]) continue;
+                int mx = s.tile_mvx[t], my = s.tile_mvy[t];
+                int px = (x0 >> 1) + x + (mx >> 3) - oc_x, py = (y0 >> 1) + y + (my >> 3) - oc_y;
+                s.pred[1024 + i] = (T)chroma_sample<T>((pl ? win_v : win_u) + py * wcs + px, wcs, mx & 7, my & 7, bd);
+            }
+        }
+    });
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1536; i += NT) s.rs.res[i] = (int16_t)((int)s.src[i] - (int)s.pred[i]);
+    });
+    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd);
+    // reconstruction + outputs
+    ex.phase([&](int tid) {
+        const int maxv = (1 << bd) - 1;
+        for (int i = tid; i < 1536; i += NT) {
+            SampleLoc l = locate(s.rs, i);
+            if (!l.log2n) continue;
+            int gx = (l.plane ? x0 >> 1 : x0) + l.x, gy = (l.plane ? y0 >> 1 : y0) + l.y;
+            int v = clip3(0, maxv, (int)s.pred[i] + s.rs.res[i]);
+            a.rec[l.plane].p[(ptrdiff_t)gy * a.rec[l.plane].stride + gx] = (T)v;
+            a.coef[l.plane][(size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx] = s.rs.lvl[i];
+        }
+        if (tid < 16 && s.rs.tu_log2[tid]) {
+            int t = tid, txp = t & 3, typ = t >> 2, node = s.tile_node[t], nx, ny, nl;
+            node_geom(node, nx, ny, nl);
+            int t0 = (ny >> 3) * 4 + (nx >> 3);
+            mihevc_cu_rec r;
+            r.log2_size = (uint8_t)nl;
+            r.flags = (uint8_t)(CU_INTER | ((s.rs.cbf[0] >> t0) & 1 ? CU_CBF_Y : 0) | ((s.rs.cbf[1] >> t0) & 1 ? CU_CBF_CB : 0) |
+                                ((s.rs.cbf[2] >> t0) & 1 ? CU_CBF_CR : 0));
+            r.chroma_mode = 1; r.qp = (uint8_t)a.prm.qp;
+            r.intra_mode[0] = 1; r.intra_mode[1] = r.intra_mode[2] = r.intra_mode[3] = 0;
+            r.mvx = (int16_t)s.tile_mvx[t]; r.mvy = (int16_t)s.tile_mvy[t];
+            r.cbf_y4 = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+            a.cu[(size_t)((y0 >> 3) + typ) * (a.w >> 3) + (x0 >> 3) + txp] = r;
+        }
+    });
+}
+
+}  // namespace mihevc

@@ -1,0 +1,355 @@
+// hevc_amd/csrc/kernels/intra.h — K2: intra prediction + mode decision (35 modes, SATD) + K3 residual for the CTUs
+// of an I picture.  One 256-thread workgroup per 32x32 CTU; CTUs are launched one anti-diagonal (x + 2y = d) at a
+// time because a CTU predicts from its left, top-left, top and top-right neighbours' reconstructions.
+//
+// Inside the CTU the quadtree is walked depth first exactly like oracle/hevc_oracle.c intra_tree: the four 8x8
+// children of a 16x16 block first, then the 16x16 block itself, keep the cheaper (whole wins ties); then the same
+// for 32x32.  The CTU's reconstruction, levels and CU records live in LDS until the CTU is final.
+// Prediction is H.265 8.4.4.2 (reference availability by z-scan order, substitution, [1 2 1] / strong smoothing,
+// planar, DC, angular with the boundary filters); MPM list per 8.4.2.
+#pragma once
+#include "common.h"
+#include "residual.h"
+
+namespace mihevc {
+
+template <typename T> struct IntraArgs {
+    Plane<const T> src[3];
+    Plane<T> rec[3];             // pre-deblock reconstruction (read for neighbours, written for this CTU)
+    int w, h, ctus_w, ctus_h;
+    CostParams prm;
+    mihevc_cu_rec *cu;
+    int16_t *coef[3];
+    int diagonal;                // CTUs with cx + 2*cy == diagonal are processed by this launch
+};
+
+constexpr int RY_STRIDE = 68;    // LDS luma neighbourhood: rows -1..31, cols -1..63 (+ pad)
+constexpr int RC_STRIDE = 36;    // chroma: rows -1..15, cols -1..31
+
+template <typename T> struct IntraShared {
+    ResidualShared rs;
+    T src[1536];
+    T pred[1536];
+    T rec_y[33 * RY_STRIDE];
+    T rec_c[2][17 * RC_STRIDE];
+    T save_y[32 * 32];
+    T save_c[2][16 * 16];
+    int16_t coef_acc[1536], coef_save[1536];
+    mihevc_cu_rec cu_acc[16], cu_save[16];
+    T ref_raw[3][132], ref[3][132], filt[132];   // [plane]: 4N+1 reference samples (raw, substituted); filtered luma
+    uint8_t avail[3][132];
+    int satd[35][16];
+    unsigned mode_cost[35];
+    int cand[3], best_mode, dc_val[3];
+    unsigned sse;
+    int bits[3];
+    unsigned long long j_cu;
+};
+
+// p[x][y] accessors on the linear 4N+1 layout: L[0] = p[-1][2N-1] ... L[2N] = p[-1][-1] ... L[4N] = p[2N-1][-1]
+template <typename T> DEV int ref_left(const T *L, int n, int y) { return L[2 * n - 1 - y]; }
+template <typename T> DEV int ref_top(const T *L, int n, int x) { return L[2 * n + 1 + x]; }
+
+// one predicted sample — 8.4.4.2.4 (planar), .5 (DC incl. edge smoothing), .6 (angular incl. modes 10/26 edge filter)
+template <typename T> DEV int intra_sample(const T *L, int log2n, int mode, int x, int y, int c_idx, int bit_depth, int dc)
+{
+    const int n = 1 << log2n;
+    if (mode == 0)
+        return ((n - 1 - x) * ref_left(L, n, y) + (x + 1) * ref_top(L, n, n) + (n - 1 - y) * ref_top(L, n, x) + (y + 1) * ref_left(L, n, n) + n) >> (log2n + 1);
+    if (mode == 1) {
+        if (c_idx == 0 && n < 32) {
+            if (x == 0 && y == 0) return (ref_left(L, n, 0) + 2 * dc + ref_top(L, n, 0) + 2) >> 2;
+            if (y == 0) return (ref_top(L, n, x) + 3 * dc + 2) >> 2;
+            if (x == 0) return (ref_left(L, n, y) + 3 * dc + 2) >> 2;
+        }
+        return dc;
+    }
+    const int angle = g_tab.intra_angle[mode], vertical = mode >= 18;
+    const int a = vertical ? y : x, b = vertical ? x : y;     // a: along the prediction direction
+    if (angle == 0 && c_idx == 0 && n < 32 && b == 0) {
+        int corner = L[2 * n];
+        int v = vertical ? ref_top(L, n, 0) + ((ref_left(L, n, a) - corner) >> 1) : ref_left(L, n, 0) + ((ref_top(L, n, a) - corner) >> 1);
+        return clip3(0, (1 << bit_depth) - 1, v);
+    }
+    const int idx = ((a + 1) * angle) >> 5, f = ((a + 1) * angle) & 31;
+    auto r = [&](int i) -> int {
+        if (i >= 0) return vertical ? L[2 * n + i] : L[2 * n - i];
+        int k = -1 + ((i * g_tab.inv_angle[mode - 11] + 128) >> 8);
+        return vertical ? L[2 * n - 1 - k] : L[2 * n + 1 + k];
+    };
+    int v0 = r(b + idx + 1);
+    return f ? ((32 - f) * v0 + f * r(b + idx + 2) + 16) >> 5 : v0;
+}
+
+DEV bool intra_filter_on(int log2n, int mode)
+{
+    if (mode == 1 || log2n == 2) return false;
+    int d = imin(iabs(mode - 26), iabs(mode - 10));
+    return d > (log2n == 3 ? 7 : log2n == 4 ? 1 : 0);
+}
+
+template <typename T, class Ex>
+DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int y0, int cx, int cy, int log2n)
+{
+    const int n = 1 << log2n, bd = a.prm.bit_depth, tiles = n >> 3, ntile = tiles * tiles;
+    const int gx = x0 + cx, gy = y0 + cy;        // picture coordinates of the CU
+    // reference samples: availability + raw values for the three planes
+    ex.phase([&](int tid) {
+        for (int u = tid; u < 3 * 129; u += NT) {
+            int pl = u / 129, i = u % 129, np = pl ? n >> 1 : n, total = 4 * np + 1;
+            if (i >= total) continue;
+            int px = pl ? cx >> 1 : cx, py = pl ? cy >> 1 : cy, xn, yn;
+            if (i < 2 * np) { xn = px - 1; yn = py + 2 * np - 1 - i; }
+            else if (i == 2 * np) { xn = px - 1; yn = py - 1; }
+            else { xn = px + (i - 2 * np - 1); yn = py - 1; }
+            int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;      // luma picture position of the neighbour
+            bool ok = lx >= 0 && ly >= 0 && lx < a.w && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(gx, gy, a.ctus_w);
+            s.avail[pl][i] = ok;
+            s.ref_raw[pl][i] = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
+        }
+        if (tid == 0) {   // 8.4.2 candModeList
+            int ma = 1, mb = 1;
+            if (gx > 0) {
+                const mihevc_cu_rec &r = cx > 0 ? s.cu_acc[(cy >> 3) * 4 + ((cx - 1) >> 3)] : a.cu[(size_t)(gy >> 3) * (a.w >> 3) + ((gx - 1) >> 3)];
+                if (!(r.flags & CU_INTER)) ma = r.intra_mode[0];
+            }
+            if (cy > 0) {
+                const mihevc_cu_rec &r = s.cu_acc[((cy - 1) >> 3) * 4 + (cx >> 3)];
+                if (!(r.flags & CU_INTER)) mb = r.intra_mode[0];
+            }
+            if (ma == mb) {
+                if (ma < 2) { s.cand[0] = 0; s.cand[1] = 1; s.cand[2] = 26; }
+                else { s.cand[0] = ma; s.cand[1] = 2 + ((ma + 29) & 31); s.cand[2] = 2 + ((ma - 2 + 1) & 31); }
+            } else {
+                s.cand[0] = ma; s.cand[1] = mb;
+                s.cand[2] = (ma != 0 && mb != 0) ? 0 : (ma != 1 && mb != 1) ? 1 : 26;
+            }
+            s.sse = 0; s.bits[0] = s.bits[1] = s.bits[2] = 0;
+        }
+    });
+    // substitution (8.4.4.2.2): nearest available sample at a lower index, else the first available above
+    ex.phase([&](int tid) {
+        for (int u = tid; u < 3 * 129; u += NT) {
+            int pl = u / 129, i = u % 129, np = pl ? n >> 1 : n, total = 4 * np + 1;
+            if (i >= total) continue;
+            int j = i;
+            while (j >= 0 && !s.avail[pl][j]) j--;
+            if (j < 0) { j = i + 1; while (j < total && !s.avail[pl][j]) j++; }
+            s.ref[pl][i] = j < total ? s.ref_raw[pl][j] : (T)(1 << (bd - 1));
+        }
+    });
+    // smoothing filter for luma (8.4.4.2.3) + DC values
+    ex.phase([&](int tid) {
+        const T *L = s.ref[0];
+        const int total = 4 * n + 1;
+        bool strong = false;
+        if (n == 32) {
+            int thr = 1 << (bd - 5), c = L[64];
+            strong = iabs(c + L[128] - 2 * L[96]) < thr && iabs(c + L[0] - 2 * L[32]) < thr;
+        }
+        for (int i = tid; i < total; i += NT) {
+            int v;
+            if (i == 0 || i == total - 1) v = L[i];
+            else if (strong) v = i == 64 ? L[64] : i < 64 ? (i * L[64] + (64 - i) * L[0] + 32) >> 6 : ((128 - i) * L[64] + (i - 64) * L[128] + 32) >> 6;
+            else v = (L[i - 1] + 2 * L[i] + L[i + 1] + 2) >> 2;
+            s.filt[i] = (T)v;
+        }
+        if (tid < 3) {
+            int np = tid ? n >> 1 : n, lg = tid ? log2n - 1 : log2n, sum = np;
+            for (int i = 0; i < np; i++) sum += ref_top(s.ref[tid], np, i) + ref_left(s.ref[tid], np, i);
+            s.dc_val[tid] = sum >> (lg + 1);
+        }
+    });
+    // 35 modes x 8x8 tiles: prediction and SATD against the source
+    ex.phase([&](int tid) {
+        for (int u = tid; u < 35 * ntile; u += NT) {
+            int mode = u / ntile, t = u % ntile, tx = (t % tiles) * 8, ty = (t / tiles) * 8;
+            const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
+            int m[8][8];
+            for (int j = 0; j < 8; j++)
+                for (int i = 0; i < 8; i++)
+                    m[j][i] = (int)s.src[(cy + ty + j) * 32 + cx + tx + i] - intra_sample<T>(L, log2n, mode, tx + i, ty + j, 0, bd, s.dc_val[0]);
+            s.satd[mode][t] = hadamard8_satd(m);
+        }
+    });
+    ex.phase([&](int tid) {
+        if (tid < 35) {
+            unsigned satd = 0;
+            for (int t = 0; t < ntile; t++) satd += (unsigned)s.satd[tid][t];
+            int bits = tid == s.cand[0] ? 2 : (tid == s.cand[1] || tid == s.cand[2]) ? 3 : 6;
+            s.mode_cost[tid] = (satd << 4) + (unsigned)(a.prm.lambda_sad_q4 * bits);
+        }
+    });
+    ex.phase([&](int tid) {
+        if (tid == 0) {
+            unsigned long long best = ~0ull;
+            for (int m = 0; m < 35; m++) {
+                unsigned long long key = ((unsigned long long)s.mode_cost[m] << 6) | (unsigned)m;
+                if (key < best) best = key;
+            }
+            s.best_mode = (int)(best & 63);
+        }
+        if (tid < 16) {
+            int tx = tid & 3, ty = tid >> 2;
+            bool in = tx * 8 >= cx && tx * 8 < cx + n && ty * 8 >= cy && ty * 8 < cy + n;
+            s.rs.tu_log2[tid] = in ? (uint8_t)log2n : 0;
+            s.rs.tu_intra[tid] = 1;
+        }
+        if (tid < 3) s.rs.cbf[tid] = 0;
+    });
+    // prediction of the chosen mode (luma) and DM chroma, residual
+    ex.phase([&](int tid) {
+        const int mode = s.best_mode;
+        const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
+        for (int i = tid; i < 1536; i += NT) {
+            SampleLoc l = locate(s.rs, i);
+            if (!l.log2n) continue;
+            int v;
+            if (l.plane == 0) v = intra_sample<T>(L, log2n, mode, l.x - cx, l.y - cy, 0, bd, s.dc_val[0]);
+            else v = intra_sample<T>(s.ref[l.plane], log2n - 1, mode, l.x - (cx >> 1), l.y - (cy >> 1), l.plane, bd, s.dc_val[l.plane]);
+            s.pred[i] = (T)v;
+            s.rs.res[i] = (int16_t)((int)s.src[i] - v);
+        }
+    });
+    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd);
+    // reconstruction into the LDS neighbourhood, distortion, rate estimate
+    ex.phase([&](int tid) {
+        const int maxv = (1 << bd) - 1;
+        unsigned sse = 0;
+        for (int i = tid; i < 1536; i += NT) {
+            SampleLoc l = locate(s.rs, i);
+            if (!l.log2n) continue;
+            int v = clip3(0, maxv, (int)s.pred[i] + s.rs.res[i]);
+            if (l.plane == 0) s.rec_y[(l.y + 1) * RY_STRIDE + l.x + 1] = (T)v;
+            else s.rec_c[l.plane - 1][(l.y + 1) * RC_STRIDE + l.x + 1] = (T)v;
+            int d = (int)s.src[i] - v;
+            sse += (unsigned)(d * d);
+            s.coef_acc[i] = s.rs.lvl[i];
+        }
+        if (sse) ex.atomic_add(&s.sse, sse);
+        for (int sb = tid; sb < 96; sb += NT) {       // 64 luma + 16 + 16 chroma 4x4 sub-blocks
+            int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
+            int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
+            int sh = pl ? 2 : 3;
+            if (!s.rs.tu_log2[(by >> sh) * 4 + (bx >> sh)]) continue;
+            int b = subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
+            if (b) ex.atomic_add(&s.bits[pl], b);
+        }
+    });
+    ex.phase([&](int tid) {
+        const int mode = s.best_mode;
+        int t0 = (cy >> 3) * 4 + (cx >> 3);
+        if (tid < 16 && s.rs.tu_log2[tid]) {
+            mihevc_cu_rec r;
+            r.log2_size = (uint8_t)log2n;
+            r.flags = (uint8_t)(((s.rs.cbf[0] >> t0) & 1 ? CU_CBF_Y : 0) | ((s.rs.cbf[1] >> t0) & 1 ? CU_CBF_CB : 0) | ((s.rs.cbf[2] >> t0) & 1 ? CU_CBF_CR : 0));
+            r.chroma_mode = (uint8_t)mode; r.qp = (uint8_t)a.prm.qp;
+            r.intra_mode[0] = r.intra_mode[1] = r.intra_mode[2] = r.intra_mode[3] = (uint8_t)mode;
+            r.mvx = r.mvy = 0; r.cbf_y4 = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
+            s.cu_acc[tid] = r;
+        }
+        if (tid == 0) {
+            int mb = mode == s.cand[0] ? 2 : (mode == s.cand[1] || mode == s.cand[2]) ? 3 : 6;
+            int bits = 16 * mb + 16 + 24;
+            for (int p = 0; p < 3; p++) bits += s.bits[p] ? s.bits[p] + 16 : 0;
+            s.j_cu = ((unsigned long long)s.sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)bits) >> 4);
+        }
+    });
+}
+
+// copy the region (cx,cy,n) of the accumulated state to the save area (dir = 0) or back (dir = 1)
+template <typename T, class Ex> DEV void intra_save_restore(Ex &ex, IntraShared<T> &s, int cx, int cy, int n, int dir)
+{
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1536; i += NT) {
+            int pl, x, y;
+            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
+            int sh = pl ? 1 : 0;
+            if (x < (cx >> sh) || x >= ((cx + n) >> sh) || y < (cy >> sh) || y >= ((cy + n) >> sh)) continue;
+            T *live = pl ? &s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : &s.rec_y[(y + 1) * RY_STRIDE + x + 1];
+            T *save = pl ? &s.save_c[pl - 1][y * 16 + x] : &s.save_y[y * 32 + x];
+            if (dir == 0) { *save = *live; s.coef_save[i] = s.coef_acc[i]; }
+            else { *live = *save; s.coef_acc[i] = s.coef_save[i]; }
+        }
+        if (tid < 16) {
+            int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
+            if (tx >= cx && tx < cx + n && ty >= cy && ty < cy + n) {
+                if (dir == 0) s.cu_save[tid] = s.cu_acc[tid]; else s.cu_acc[tid] = s.cu_save[tid];
+            }
+        }
+    });
+}
+
+template <typename T, class Ex>
+DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int ctu_x, int ctu_y)
+{
+    const int x0 = ctu_x * CTU, y0 = ctu_y * CTU;
+    const unsigned long long lam_split = (unsigned long long)a.prm.lambda_q4;     // (lambda_q4 * 16) >> 4
+    residual_init(ex, s.rs);
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1536; i += NT) {
+            int pl, x, y;
+            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
+            int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
+            s.src[i] = (gx < pw && gy < ph) ? a.src[pl].p[(size_t)gy * a.src[pl].stride + gx] : (T)0;
+            s.coef_acc[i] = 0;
+        }
+        // neighbourhood: row -1 (cols -1..63 luma / -1..31 chroma) and column -1 (rows 0..31 / 0..15) from the picture
+        for (int u = tid; u < 65 + 32 + 2 * (33 + 16); u += NT) {
+            int pl, k, row_len, col_len;
+            if (u < 97) { pl = 0; k = u; row_len = 65; col_len = 32; }
+            else { pl = 1 + (u - 97) / 49; k = (u - 97) % 49; row_len = 33; col_len = 16; }
+            int xn, yn;
+            if (k < row_len) { xn = k - 1; yn = -1; } else { xn = -1; yn = k - row_len; }
+            (void)col_len;
+            int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
+            int gx = (pl ? x0 >> 1 : x0) + xn, gy = (pl ? y0 >> 1 : y0) + yn;
+            T v = 0;
+            if (gx >= 0 && gy >= 0 && gx < pw && gy < ph) v = a.rec[pl].p[(ptrdiff_t)gy * a.rec[pl].stride + gx];
+            if (pl == 0) s.rec_y[(yn + 1) * RY_STRIDE + xn + 1] = v; else s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] = v;
+        }
+    });
+    unsigned long long j16[4];
+    for (int q = 0; q < 4; q++) {
+        const int qx = (q & 1) * 16, qy = (q >> 1) * 16;
+        j16[q] = 0;
+        if (x0 + qx >= a.w || y0 + qy >= a.h) continue;
+        unsigned long long jsplit = lam_split;
+        for (int b = 0; b < 4; b++) {
+            const int bx = qx + (b & 1) * 8, by = qy + (b >> 1) * 8;
+            if (x0 + bx >= a.w || y0 + by >= a.h) continue;
+            intra_cu(ex, s, a, x0, y0, bx, by, 3);
+            jsplit += s.j_cu;
+        }
+        const bool fits = x0 + qx + 16 <= a.w && y0 + qy + 16 <= a.h;
+        if (!fits) { j16[q] = jsplit; continue; }
+        intra_save_restore(ex, s, qx, qy, 16, 0);
+        intra_cu(ex, s, a, x0, y0, qx, qy, 4);
+        const unsigned long long jwhole = s.j_cu + lam_split;
+        if (jwhole <= jsplit) j16[q] = jwhole;
+        else { intra_save_restore(ex, s, qx, qy, 16, 1); j16[q] = jsplit; }
+    }
+    if (x0 + 32 <= a.w && y0 + 32 <= a.h) {
+        const unsigned long long jsplit = lam_split + j16[0] + j16[1] + j16[2] + j16[3];
+        intra_save_restore(ex, s, 0, 0, 32, 0);
+        intra_cu(ex, s, a, x0, y0, 0, 0, 5);
+        if (s.j_cu + lam_split > jsplit) intra_save_restore(ex, s, 0, 0, 32, 1);
+    }
+    // the CTU is final: reconstruction, levels and CU records to memory
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1536; i += NT) {
+            int pl, x, y;
+            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
+            int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
+            if (gx >= pw || gy >= ph) continue;
+            a.rec[pl].p[(ptrdiff_t)gy * a.rec[pl].stride + gx] = pl ? s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : s.rec_y[(y + 1) * RY_STRIDE + x + 1];
+            a.coef[pl][(size_t)gy * pw + gx] = s.coef_acc[i];
+        }
+        if (tid < 16) {
+            int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
+            if (x0 + tx < a.w && y0 + ty < a.h) a.cu[(size_t)((y0 + ty) >> 3) * (a.w >> 3) + ((x0 + tx) >> 3)] = s.cu_acc[tid];
+        }
+    });
+}
+
+}  // namespace mihevc

@@ -1,0 +1,252 @@
+// hevc_amd/csrc/kernels/loopfilter.h — K4: deblocking (H.265 8.7.2) and sample adaptive offset (8.7.3).
+//
+// These are the streaming stencils of the path — the HBM-shaped kernels.  Deblocking runs as
+// two passes over the picture (all vertical edges, then all horizontal edges); within a pass every 8-sample edge is
+// independent (filters read 4 and write 3 samples either side of edges 8 apart), so one thread owns one 4-sample
+// edge segment and the picture is filtered in place.  Algorithmic traffic: one read + one write of the picture
+// per pass.  SAO gathers per-CTU statistics with LDS atomics, decides offsets (oracle sao_eval, exactly), then a
+// second kernel applies them while writing the final reference picture.
+#pragma once
+#include "common.h"
+
+namespace mihevc {
+
+template <typename T> struct DeblockArgs {
+    Plane<T> rec[3];
+    int w, h;
+    const mihevc_cu_rec *cu;
+    int bit_depth, dir;          // dir 0: vertical edges, 1: horizontal edges
+};
+
+DEV int edge_bs(const mihevc_cu_rec &p, const mihevc_cu_rec &q)      // 8.7.2.4 with CU = PU = TU
+{
+    if (!(p.flags & CU_INTER) || !(q.flags & CU_INTER)) return 2;
+    if ((p.flags & CU_CBF_Y) || (q.flags & CU_CBF_Y)) return 1;
+    if (iabs(p.mvx - q.mvx) >= 4 || iabs(p.mvy - q.mvy) >= 4) return 1;
+    return 0;
+}
+
+// one thread = one 4-sample luma segment (and the co-located 2 chroma samples per plane when the edge is a chroma edge)
+template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_index)
+{
+    const int w8 = a.w >> 3, segs = w8 * (a.h >> 3) * 2;
+    if (seg_index >= segs) return;
+    const int blk = seg_index >> 1, seg = seg_index & 1, bx = blk % w8, by = blk / w8, x = bx * 8, y = by * 8, dir = a.dir;
+    const mihevc_cu_rec q = a.cu[blk];
+    const int mask = (1 << q.log2_size) - 1;
+    if (dir == 0 ? (x == 0 || (x & mask)) : (y == 0 || (y & mask))) return;
+    const mihevc_cu_rec p = a.cu[dir == 0 ? blk - 1 : blk - w8];
+    const int bs = edge_bs(p, q);
+    if (!bs) return;
+    const int maxv = (1 << a.bit_depth) - 1, sc = 1 << (a.bit_depth - 8);
+    const int qpl = (p.qp + q.qp + 1) >> 1;
+    const int beta = g_tab.beta[clip3(0, 51, qpl)] * sc, tc = g_tab.tc[clip3(0, 53, qpl + 2 * (bs - 1))] * sc;
+    {
+        const int s = dir == 0 ? 1 : a.rec[0].stride, t = dir == 0 ? a.rec[0].stride : 1;
+        T *e = a.rec[0].p + (ptrdiff_t)y * a.rec[0].stride + x + (ptrdiff_t)seg * 4 * t;
+        int P[4][4], Q[4][4];      // [distance from edge][line]
+        for (int k = 0; k < 4; k++)
+            for (int i = 0; i < 4; i++) { P[i][k] = e[-(i + 1) * (ptrdiff_t)s + k * (ptrdiff_t)t]; Q[i][k] = e[i * (ptrdiff_t)s + k * (ptrdiff_t)t]; }
+        int dp0 = iabs(P[2][0] - 2 * P[1][0] + P[0][0]), dp3 = iabs(P[2][3] - 2 * P[1][3] + P[0][3]);
+        int dq0 = iabs(Q[2][0] - 2 * Q[1][0] + Q[0][0]), dq3 = iabs(Q[2][3] - 2 * Q[1][3] + Q[0][3]);
+        int dpq0 = dp0 + dq0, dpq3 = dp3 + dq3, dp = dp0 + dp3, dq = dq0 + dq3;
+        if (dpq0 + dpq3 < beta) {
+            bool sam0 = 2 * dpq0 < (beta >> 2) && iabs(P[3][0] - P[0][0]) + iabs(Q[0][0] - Q[3][0]) < (beta >> 3) && iabs(P[0][0] - Q[0][0]) < ((5 * tc + 1) >> 1);
+            bool sam3 = 2 * dpq3 < (beta >> 2) && iabs(P[3][3] - P[0][3]) + iabs(Q[0][3] - Q[3][3]) < (beta >> 3) && iabs(P[0][3] - Q[0][3]) < ((5 * tc + 1) >> 1);
+            bool strong = sam0 && sam3, dep = dp < ((beta + (beta >> 1)) >> 3), deq = dq < ((beta + (beta >> 1)) >> 3);
+            for (int k = 0; k < 4; k++) {
+                int p0 = P[0][k], p1 = P[1][k], p2 = P[2][k], p3 = P[3][k], q0 = Q[0][k], q1 = Q[1][k], q2 = Q[2][k], q3 = Q[3][k];
+                T *c = e + k * (ptrdiff_t)t;
+                if (strong) {
+                    c[-1 * (ptrdiff_t)s] = (T)clip3(p0 - 2 * tc, p0 + 2 * tc, (p2 + 2 * p1 + 2 * p0 + 2 * q0 + q1 + 4) >> 3);
+                    c[-2 * (ptrdiff_t)s] = (T)clip3(p1 - 2 * tc, p1 + 2 * tc, (p2 + p1 + p0 + q0 + 2) >> 2);
+                    c[-3 * (ptrdiff_t)s] = (T)clip3(p2 - 2 * tc, p2 + 2 * tc, (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3);
+                    c[0] = (T)clip3(q0 - 2 * tc, q0 + 2 * tc, (p1 + 2 * p0 + 2 * q0 + 2 * q1 + q2 + 4) >> 3);
+                    c[s] = (T)clip3(q1 - 2 * tc, q1 + 2 * tc, (p0 + q0 + q1 + q2 + 2) >> 2);
+                    c[2 * (ptrdiff_t)s] = (T)clip3(q2 - 2 * tc, q2 + 2 * tc, (p0 + q0 + q1 + 3 * q2 + 2 * q3 + 4) >> 3);
+                } else {
+                    int delta = (9 * (q0 - p0) - 3 * (q1 - p1) + 8) >> 4;
+                    if (iabs(delta) >= tc * 10) continue;
+                    delta = clip3(-tc, tc, delta);
+                    c[-1 * (ptrdiff_t)s] = (T)clip3(0, maxv, p0 + delta);
+                    c[0] = (T)clip3(0, maxv, q0 - delta);
+                    if (dep) c[-2 * (ptrdiff_t)s] = (T)clip3(0, maxv, p1 + clip3(-(tc >> 1), tc >> 1, (((p2 + p0 + 1) >> 1) - p1 + delta) >> 1));
+                    if (deq) c[s] = (T)clip3(0, maxv, q1 + clip3(-(tc >> 1), tc >> 1, (((q2 + q0 + 1) >> 1) - q1 - delta) >> 1));
+                }
+            }
+        }
+    }
+    if (bs == 2 && ((dir == 0 ? x : y) & 15) == 0) {      // chroma edge on the 8-sample chroma grid (8.7.2.5.5)
+        const int tcc = g_tab.tc[clip3(0, 53, chroma_qp_of(qpl) + 2)] * sc;
+        for (int ci = 1; ci < 3; ci++) {
+            const int s = dir == 0 ? 1 : a.rec[ci].stride, t = dir == 0 ? a.rec[ci].stride : 1;
+            T *e = a.rec[ci].p + (ptrdiff_t)(y >> 1) * a.rec[ci].stride + (x >> 1) + (ptrdiff_t)seg * 2 * t;
+            for (int k = 0; k < 2; k++) {
+                T *c = e + k * (ptrdiff_t)t;
+                int p0 = c[-1 * (ptrdiff_t)s], p1 = c[-2 * (ptrdiff_t)s], q0 = c[0], q1 = c[s];
+                int delta = clip3(-tcc, tcc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+                c[-1 * (ptrdiff_t)s] = (T)clip3(0, maxv, p0 + delta);
+                c[0] = (T)clip3(0, maxv, q0 - delta);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ SAO
+template <typename T> struct SaoArgs {
+    Plane<const T> src[3];
+    Plane<const T> dbk[3];       // deblocked picture
+    Plane<T> out[3];             // final reconstruction (padded reference planes)
+    int w, h, ctus_w;
+    CostParams prm;
+    mihevc_sao_ctu *sao;
+    unsigned long long *sse;     // optional: 3 x u64 sum of squared error (source vs out), see k_frame_sse
+};
+
+struct SaoShared {
+    int eo_n[3][4][5], eo_s[3][4][5], bo_n[3][32], bo_s[3][32];
+    int8_t bo_off[3][32];
+    long long bo_cost[3][32];
+    int8_t eo_off[3][4][4];
+    long long eo_cost[3][4];
+};
+
+DEVCONST int8_t kEoDx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};
+DEVCONST int8_t kEoDy[4][2] = {{0, 0}, {-1, 1}, {-1, 1}, {-1, 1}};
+DEV int sgn3(int v) { return (v > 0) - (v < 0); }
+// edgeIdx of 8.7.3.2 remapped to the SaoOffsetVal index; 0 when a neighbour lies outside the picture
+template <typename T> DEV int eo_category(const Plane<const T> &p, int x, int y, int w, int h, int cls)
+{
+    int xa = x + kEoDx[cls][0], ya = y + kEoDy[cls][0], xb = x + kEoDx[cls][1], yb = y + kEoDy[cls][1];
+    if (xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= w || xb >= w || ya >= h || yb >= h) return 0;
+    int c = p.p[(ptrdiff_t)y * p.stride + x];
+    int e = 2 + sgn3(c - p.p[(ptrdiff_t)ya * p.stride + xa]) + sgn3(c - p.p[(ptrdiff_t)yb * p.stride + xb]);
+    return e == 2 ? 0 : e < 2 ? e + 1 : e;
+}
+
+// offset minimising (n o^2 - 2 o s) * 16 + lambda * rate, walking from the rounded mean toward 0 (oracle sao_offset_rd)
+DEV int sao_offset_rd(int n, int s, int sign_rule, int lam_q4, int band, int maxoff, long long &cost)
+{
+    if (n == 0) { cost += lam_q4; return 0; }
+    int o = (int)((2 * (long long)iabs(s) + n) / (2 * n));
+    if (s < 0) o = -o;
+    if (sign_rule > 0 && o < 0) o = 0;
+    if (sign_rule < 0 && o > 0) o = 0;
+    o = clip3(-maxoff, maxoff, o);
+    int best_o = 0;
+    long long best = lam_q4;
+    int step = o > 0 ? 1 : -1;
+    for (int t = step; o != 0 && t != o + step; t += step) {
+        int av = iabs(t), rate = (av < maxoff ? av + 1 : maxoff) + (band ? 1 : 0);
+        long long c = (((long long)n * t * t - 2 * (long long)t * s) << 4) + (long long)lam_q4 * rate;
+        if (c < best) { best = c; best_o = t; }
+    }
+    cost += best;
+    return best_o;
+}
+
+template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, const SaoArgs<T> &a, int ctu)
+{
+    const int cx = ctu % a.ctus_w, cy = ctu / a.ctus_w, bd = a.prm.bit_depth, lam = a.prm.lambda_q4;
+    const int maxoff = (1 << (imin(bd, 10) - 5)) - 1;
+    ex.phase([&](int tid) {
+        int *z = &s.eo_n[0][0][0];
+        for (int i = tid; i < (int)(sizeof(SaoShared) / sizeof(int)); i += NT) z[i] = 0;   // whole struct is int-aligned
+    });
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1536; i += NT) {
+            int pl, x, y;
+            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
+            int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
+            if (gx >= pw || gy >= ph) continue;
+            int r = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+            int d = (int)a.src[pl].p[(ptrdiff_t)gy * a.src[pl].stride + gx] - r;
+            int b = r >> (bd - 5);
+            ex.atomic_add(&s.bo_n[pl][b], 1);
+            ex.atomic_add(&s.bo_s[pl][b], d);
+            for (int c = 0; c < 4; c++) {
+                int k = eo_category<T>(a.dbk[pl], gx, gy, pw, ph, c);
+                ex.atomic_add(&s.eo_n[pl][c][k], 1);
+                ex.atomic_add(&s.eo_s[pl][c][k], d);
+            }
+        }
+    });
+    ex.phase([&](int tid) {
+        if (tid < 96) {
+            int pl = tid >> 5, b = tid & 31;
+            long long c = 0;
+            s.bo_off[pl][b] = (int8_t)sao_offset_rd(s.bo_n[pl][b], s.bo_s[pl][b], 0, lam, 1, maxoff, c);
+            s.bo_cost[pl][b] = c;
+        } else if (tid < 96 + 12) {
+            int pl = (tid - 96) >> 2, c = (tid - 96) & 3;
+            long long cost = (long long)lam * 4;
+            for (int k = 1; k <= 4; k++) s.eo_off[pl][c][k - 1] = (int8_t)sao_offset_rd(s.eo_n[pl][c][k], s.eo_s[pl][c][k], k <= 2 ? 1 : -1, lam, 0, maxoff, cost);
+            s.eo_cost[pl][c] = cost;
+        }
+    });
+    ex.phase([&](int tid) {
+        if (tid != 0) return;
+        // candidates per plane in fixed order: 0 off, 1 band (best of 29 positions), 2..5 edge classes
+        long long cost[3][6];
+        int band[3];
+        for (int pl = 0; pl < 3; pl++) {
+            long long bestb = 0;
+            int pos = -1;
+            for (int p = 0; p <= 28; p++) {
+                long long c = s.bo_cost[pl][p] + s.bo_cost[pl][p + 1] + s.bo_cost[pl][p + 2] + s.bo_cost[pl][p + 3];
+                if (pos < 0 || c < bestb) { bestb = c; pos = p; }
+            }
+            band[pl] = pos;
+            cost[pl][0] = 0;
+            cost[pl][1] = bestb + (long long)lam * 7;
+            for (int c = 0; c < 4; c++) cost[pl][2 + c] = s.eo_cost[pl][c];
+        }
+        int bl = 0, bc = 0;
+        for (int k = 1; k < 6; k++) {
+            if (cost[0][k] < cost[0][bl]) bl = k;
+            if (cost[1][k] + cost[2][k] < cost[1][bc] + cost[2][bc]) bc = k;
+        }
+        mihevc_sao_ctu o;
+        for (unsigned i = 0; i < sizeof o; i++) ((uint8_t *)&o)[i] = 0;
+        const int sel[3] = {bl, bc, bc};
+        for (int pl = 0; pl < 3; pl++) {
+            int k = sel[pl], type = k == 0 ? 0 : k == 1 ? 1 : 2;
+            if (pl < 2) { o.type[pl] = (uint8_t)type; o.eo_class[pl] = (uint8_t)(type == 2 ? k - 2 : 0); }
+            o.band_pos[pl] = (uint8_t)(type == 1 ? band[pl] : 0);
+            for (int i = 0; i < 4; i++) o.offset[pl][i] = type == 1 ? s.bo_off[pl][band[pl] + i] : type == 2 ? s.eo_off[pl][k - 2][i] : 0;
+        }
+        a.sao[ctu] = o;
+    });
+}
+
+// apply (8.7.3): one thread per sample of a plane-row segment; also usable with sao == nullptr (plain copy)
+template <typename T> DEV void sao_apply_sample(const SaoArgs<T> &a, int pl, int gx, int gy)
+{
+    const int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h, bd = a.prm.bit_depth, maxv = (1 << bd) - 1;
+    int v = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+    if (a.sao) {
+        const int csh = pl ? 4 : 5;
+        const mihevc_sao_ctu &o = a.sao[(gy >> csh) * a.ctus_w + (gx >> csh)];
+        int type = o.type[pl ? 1 : 0];
+        if (type == 2) {
+            int k = eo_category<T>(a.dbk[pl], gx, gy, pw, ph, o.eo_class[pl ? 1 : 0]);
+            if (k) v = clip3(0, maxv, v + o.offset[pl][k - 1]);
+        } else if (type == 1) {
+            int k = ((v >> (bd - 5)) - o.band_pos[pl]) & 31;
+            if (k < 4) v = clip3(0, maxv, v + o.offset[pl][k]);
+        }
+    }
+    a.out[pl].p[(ptrdiff_t)gy * a.out[pl].stride + gx] = (T)v;
+}
+
+// border extension of a padded plane: thread per border sample
+template <typename T> DEV void pad_sample(Plane<T> p, int w, int h, int pad, int idx)
+{
+    const int pw = w + 2 * pad, ph = h + 2 * pad;
+    if (idx >= pw * ph) return;
+    int x = idx % pw - pad, y = idx / pw - pad;
+    if (x >= 0 && x < w && y >= 0 && y < h) return;
+    p.p[(ptrdiff_t)y * p.stride + x] = p.p[(ptrdiff_t)clip3(0, h - 1, y) * p.stride + clip3(0, w - 1, x)];
+}
+
+}  // namespace mihevc

@@ -1,0 +1,143 @@
+// hevc_amd/csrc/kernels/residual.h — K3: forward transform, quantisation, scaling, inverse transform and
+// reconstruction of all transform units of one CTU, executed by the CTU's workgroup on its LDS image.
+//
+// Index space: 1536 samples per CTU = 1024 luma (32x32) + 256 Cb (16x16) + 256 Cr.  The TU a sample belongs to is
+// looked up in `tu_log2[16]` (CU size per 8x8 luma tile, 0 = no TU there); chroma TUs are the co-located half-size
+// blocks.  Arithmetic: H.265 8.6.2-8.6.4 (scaling, transformation) for the decoder side; the conventional
+// two-stage integer forward transform and dead-zone quantiser for the encoder side — identical, term for term, to
+// oracle/hevc_oracle.c (orc_fwd_transform, orc_quant, orc_dequant, orc_inv_transform).
+// Roofline note: 4 matrix passes of <=32 MACs per sample; the working set never leaves LDS (12 KiB per CTU).
+#pragma once
+#include "common.h"
+
+namespace mihevc {
+
+struct ResidualShared {
+    int8_t mat[32][32];        // LDS copy of the transform matrix
+    int16_t res[1536];         // residual in, reconstructed residual out
+    int32_t tmp[1536];         // stage intermediates
+    int16_t coef[1536];        // transform coefficients / scaled coefficients
+    int16_t lvl[1536];         // quantised levels (TU-local raster at CTU coordinates)
+    uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
+    uint8_t tu_intra[16];      // per tile: 1 = intra rounding
+    unsigned cbf[3];           // bit t set: tile t's TU has a non-zero level in that plane (all tiles of a TU set the TU's first tile bit)
+};
+
+struct SampleLoc {
+    int plane, x, y;           // coordinates inside the CTU's plane (luma 0..31, chroma 0..15)
+    int log2n, tx0, ty0;       // TU geometry in the same coordinates; log2n == 0: not covered
+    int tile0;                 // 8x8 tile index of the TU origin (for the cbf word)
+    int intra;
+    int stride, base;          // row stride and base offset of the plane inside the 1536-sample arrays
+};
+
+DEV SampleLoc locate(const ResidualShared &s, int idx)
+{
+    SampleLoc l;
+    if (idx < 1024) { l.plane = 0; l.x = idx & 31; l.y = idx >> 5; l.stride = 32; l.base = 0; }
+    else { int i = idx - 1024; l.plane = 1 + (i >> 8); i &= 255; l.x = i & 15; l.y = i >> 4; l.stride = 16; l.base = 1024 + (l.plane - 1) * 256; }
+    int sh = l.plane ? 2 : 3;                       // samples per tile edge: 8 luma, 4 chroma
+    int tile = (l.y >> sh) * 4 + (l.x >> sh);
+    int lg = s.tu_log2[tile];
+    l.intra = s.tu_intra[tile];
+    if (!lg) { l.log2n = 0; l.tx0 = l.ty0 = l.tile0 = 0; return l; }
+    int lgp = l.plane ? lg - 1 : lg;
+    l.log2n = lgp;
+    l.tx0 = l.x & ~((1 << lgp) - 1);
+    l.ty0 = l.y & ~((1 << lgp) - 1);
+    l.tile0 = (l.ty0 >> sh) * 4 + (l.tx0 >> sh);
+    return l;
+}
+
+// forward + quant + scaling + inverse for every TU described by s.tu_log2; qp / qp_c are syntax QPs
+template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth)
+{
+    ex.phase([&](int tid) {      // forward stage 1: rows
+        for (int idx = tid; idx < 1536; idx += NT) {
+            SampleLoc l = locate(s, idx);
+            if (!l.log2n) continue;
+            int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0, row = l.base + l.y * l.stride + l.tx0;
+            const int8_t *m = s.mat[u << (5 - l.log2n)];
+            int acc = 0;
+            for (int i = 0; i < n; i++) acc += m[i] * s.res[row + i];
+            s.tmp[idx] = sh1 > 0 ? (acc + (1 << (sh1 - 1))) >> sh1 : acc;
+        }
+    });
+    ex.phase([&](int tid) {      // forward stage 2: columns
+        for (int idx = tid; idx < 1536; idx += NT) {
+            SampleLoc l = locate(s, idx);
+            if (!l.log2n) continue;
+            int n = 1 << l.log2n, sh2 = l.log2n + 6, v = l.y - l.ty0, col = l.base + l.ty0 * l.stride + l.x;
+            const int8_t *m = s.mat[v << (5 - l.log2n)];
+            long long acc = 0;
+            for (int j = 0; j < n; j++) acc += (long long)m[j] * s.tmp[col + j * l.stride];
+            acc = (acc + (1 << (sh2 - 1))) >> sh2;
+            s.coef[idx] = (int16_t)(acc < -32768 ? -32768 : acc > 32767 ? 32767 : acc);
+        }
+    });
+    ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16)
+        for (int idx = tid; idx < 1536; idx += NT) {
+            SampleLoc l = locate(s, idx);
+            if (!l.log2n) { s.lvl[idx] = 0; continue; }
+            int q = (l.plane ? qp_c : qp) + 6 * (bit_depth - 8);
+            int qbits = 14 + q / 6 + (15 - bit_depth - l.log2n);
+            long long add = (long long)(l.intra ? 171 : 85) << (qbits - 9);
+            int c = s.coef[idx];
+            long long a = ((long long)iabs(c) * g_tab.quant_scale[q % 6] + add) >> qbits;
+            if (a > 32767) a = 32767;
+            int lev = (int)(c < 0 ? -a : a);
+            s.lvl[idx] = (int16_t)lev;
+            if (lev) ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
+            int bd_shift = bit_depth + l.log2n - 5;
+            long long scale = (long long)16 * g_tab.level_scale[q % 6] << (q / 6);
+            long long d = (lev * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
+            s.coef[idx] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
+        }
+    });
+    ex.phase([&](int tid) {      // inverse stage 1: columns, shift 7, clip to 16 bit (8.6.4.2)
+        for (int idx = tid; idx < 1536; idx += NT) {
+            SampleLoc l = locate(s, idx);
+            if (!l.log2n) continue;
+            int n = 1 << l.log2n, yy = l.y - l.ty0, col = l.base + l.ty0 * l.stride + l.x, step = 1 << (5 - l.log2n);
+            long long acc = 0;
+            for (int j = 0; j < n; j++) acc += (long long)s.mat[j * step][yy] * s.coef[col + j * l.stride];
+            acc = (acc + 64) >> 7;
+            s.tmp[idx] = (int)(acc < -32768 ? -32768 : acc > 32767 ? 32767 : acc);
+        }
+    });
+    ex.phase([&](int tid) {      // inverse stage 2: rows, shift 20 - bitDepth
+        for (int idx = tid; idx < 1536; idx += NT) {
+            SampleLoc l = locate(s, idx);
+            if (!l.log2n) { s.res[idx] = 0; continue; }
+            int n = 1 << l.log2n, xx = l.x - l.tx0, row = l.base + l.y * l.stride + l.tx0, step = 1 << (5 - l.log2n), sh = 20 - bit_depth;
+            long long acc = 0;
+            for (int j = 0; j < n; j++) acc += (long long)s.mat[j * step][xx] * s.tmp[row + j];
+            s.res[idx] = (int16_t)((acc + (1 << (sh - 1))) >> sh);
+        }
+    });
+}
+
+template <class Ex> DEV void residual_init(Ex &ex, ResidualShared &s)
+{
+    ex.phase([&](int tid) {
+        for (int i = tid; i < 1024; i += NT) s.mat[i >> 5][i & 31] = g_tab.mat[i >> 5][i & 31];
+        if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
+        if (tid < 3) s.cbf[tid] = 0;
+    });
+}
+
+// coefficient-rate estimate of one 4x4 sub-block of levels, in 1/16 bit (oracle/hevc_oracle.c code_tu)
+DEV int subblock_bits_q4(const int16_t *lv, int stride)
+{
+    int bits = 0, any = 0;
+    for (int y = 0; y < 4; y++)
+        for (int x = 0; x < 4; x++) {
+            int a = iabs(lv[y * stride + x]);
+            if (!a) continue;
+            any = 1;
+            bits += a == 1 ? 40 : a == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(a - 1));
+        }
+    return any ? bits + 24 : 0;
+}
+
+}  // namespace mihevc

@@ -1,0 +1,579 @@
+// hevc_amd/csrc/session.cpp — the encoder session behind mihevc_open / send_frame / receive_packet.
+//
+// Pipeline: source pictures are collected in HBM; every `gops_in_flight * keyint` pictures
+// (or at flush) the chunk is encoded.  Closed GOPs are independent, so the chunk's GOPs run in LOCK-STEP: step t
+// launches each stage once for picture t of every GOP (blockIdx.y = GOP lane).  Per step: intra anti-diagonals
+// (t = 0) or ME + inter CTU (t > 0) -> deblock V/H -> SAO decide/apply -> border pad -> SSE, then one D2H copy of
+// the step's symbols into pinned memory on a second stream, and one CABAC job per picture on the host pool.
+// The device never waits for CABAC except when the 4-deep symbol ring wraps.
+// Replaces, for the selected files, the `ffmpeg -c:v libx265` child of the reference (core/transcoder.py:506).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bitstream.h"
+#include "device.h"
+
+using namespace mihevc;
+
+namespace {
+
+constexpr int kRing = 4;      // symbol ring depth (steps in flight between device and CABAC workers)
+
+class ThreadPool {
+public:
+    explicit ThreadPool(int n)
+    {
+        for (int i = 0; i < n; i++) threads_.emplace_back([this] { run(); });
+    }
+    ~ThreadPool()
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void submit(std::function<void()> f)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            q_.push_back(std::move(f));
+        }
+        cv_.notify_one();
+    }
+
+private:
+    void run()
+    {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> l(m_);
+                cv_.wait(l, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::deque<std::function<void()>> q_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool stop_ = false;
+};
+
+struct Packet {
+    std::vector<uint8_t> data;
+    int64_t pts = 0;
+    bool key = false, ready = false;
+};
+
+// symbol block of one picture: [cu | coef Y | coef U | coef V | sao | sse]
+struct SymLayout {
+    size_t cu, cy, cu_, cv, sao, sse, total;
+    SymLayout(int w, int h)
+    {
+        size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h, nctu = (size_t)((w + 31) / 32) * ((h + 31) / 32);
+        auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+        cu = 0;
+        cy = al(cu + n8 * sizeof(mihevc_cu_rec));
+        cu_ = al(cy + ny * 2);
+        cv = al(cu_ + ny / 2);
+        sao = al(cv + ny / 2);
+        sse = al(sao + nctu * sizeof(mihevc_sao_ctu));
+        total = al(sse + 3 * sizeof(unsigned long long));
+    }
+};
+
+}  // namespace
+
+struct mihevc_session {
+    mihevc_config cfg;
+    int device = 0;
+    int w = 0, h = 0, ctus_w = 0, ctus_h = 0, n_ctu = 0;      // coded size
+    int keyint = 90, lanes = 4, me_range = 16, qp_p = 22, qp_i = 19;
+    bool is16 = false, keep_recon = false, flushed = false, failed = false;
+    std::string err;
+    hipStream_t st_compute = nullptr, st_copy = nullptr;
+    // source pictures of the current chunk (device), in display order
+    struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; };
+    std::vector<Src> pending;
+    std::vector<Src> free_src;
+    // per lane
+    struct Lane {
+        void *rec_base[2][3], *rec_p[2][3]; int rec_stride[3];       // padded final reconstructions (ping-pong)
+        void *work_base[3], *work_p[3]; int work_stride[3];           // pre-deblock / deblocked picture (unpadded)
+        int32_t *me = nullptr;
+        uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
+    };
+    std::vector<Lane> lane;
+    void *d_args = nullptr;           // argument blocks of a whole chunk
+    uint8_t *h_args = nullptr;        // pinned staging for the same
+    size_t args_cap = 0;
+    hipEvent_t ev_compute[kRing], ev_copy[kRing];
+    std::vector<hipEvent_t> ev_time;
+    // host side
+    ThreadPool *pool = nullptr;
+    std::mutex m;
+    std::condition_variable cv;
+    int jobs_open[kRing] = {0, 0, 0, 0};
+    std::map<int64_t, Packet> packets;     // by output index
+    int64_t next_out = 0, frames_in = 0, frames_done = 0;
+    std::vector<uint8_t> headers, cur_packet;
+    std::map<int64_t, std::vector<uint16_t>> recon;   // keep_recon: final pictures by index (Y,U,V concatenated)
+    mihevc_stats stats{};
+    std::atomic<long long> entropy_ns{0};
+};
+
+namespace {
+
+#define HIPCK(s, expr)                                                                    \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (s)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
+            (s)->failed = true;                                                           \
+            return MIHEVC_EDEVICE;                                                        \
+        }                                                                                 \
+    } while (0)
+
+size_t esize(const mihevc_session *s) { return s->is16 ? 2 : 1; }
+
+int alloc_planes(mihevc_session *s, void *base[3], void *p[3], int stride[3], bool padded)
+{
+    for (int i = 0; i < 3; i++) {
+        int w = i ? s->w / 2 : s->w, h = i ? s->h / 2 : s->h, pad = padded ? (i ? PAD_C : PAD_Y) : 0;
+        stride[i] = (w + 2 * pad + 63) & ~63;
+        HIPCK(s, hipMalloc(&base[i], (size_t)stride[i] * (h + 2 * pad) * esize(s)));
+        p[i] = (uint8_t *)base[i] + ((size_t)pad * stride[i] + pad) * esize(s);
+    }
+    return 0;
+}
+
+int get_src(mihevc_session *s, mihevc_session::Src &out)
+{
+    if (!s->free_src.empty()) { out = s->free_src.back(); s->free_src.pop_back(); return 0; }
+    return alloc_planes(s, out.base, out.p, out.stride, false);
+}
+
+int ensure_lanes(mihevc_session *s, int n)
+{
+    SymLayout sl(s->w, s->h);
+    while ((int)s->lane.size() < n) {
+        mihevc_session::Lane L;
+        memset(&L, 0, sizeof L);
+        for (int k = 0; k < 2; k++)
+            if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, true)) return e;
+        if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, false)) return e;
+        HIPCK(s, hipMalloc((void **)&L.me, (size_t)s->n_ctu * 63 * sizeof(int32_t)));
+        for (int k = 0; k < kRing; k++) {
+            HIPCK(s, hipMalloc((void **)&L.sym_dev[k], sl.total));
+            HIPCK(s, hipHostMalloc((void **)&L.sym_host[k], sl.total, hipHostMallocDefault));
+        }
+        s->lane.push_back(L);
+    }
+    return 0;
+}
+
+// argument blocks of one lock-step step: five arrays of `gops` entries each, so one launch per stage covers all lanes
+template <typename T> struct StepLayout {
+    size_t intra, inter, dbk_v, dbk_h, sao, total;
+    explicit StepLayout(int gops)
+    {
+        auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
+        intra = 0;
+        inter = al(intra + gops * sizeof(IntraArgs<T>));
+        dbk_v = al(inter + gops * sizeof(InterArgs<T>));
+        dbk_h = al(dbk_v + gops * sizeof(DeblockArgs<T>));
+        sao = al(dbk_h + gops * sizeof(DeblockArgs<T>));
+        total = al(sao + gops * sizeof(SaoArgs<T>));
+    }
+};
+template <typename T> struct StepView {
+    IntraArgs<T> *intra; InterArgs<T> *inter; DeblockArgs<T> *dbk_v, *dbk_h; SaoArgs<T> *sao;
+    StepView(uint8_t *base, const StepLayout<T> &l, int t)
+    {
+        uint8_t *b = base + (size_t)t * l.total;
+        intra = (IntraArgs<T> *)(b + l.intra); inter = (InterArgs<T> *)(b + l.inter);
+        dbk_v = (DeblockArgs<T> *)(b + l.dbk_v); dbk_h = (DeblockArgs<T> *)(b + l.dbk_h); sao = (SaoArgs<T> *)(b + l.sao);
+    }
+};
+
+template <typename T> Plane<T> mk(void *p, int stride) { return Plane<T>{(T *)p, stride}; }
+template <typename T> Plane<const T> mkc(void *p, int stride) { return Plane<const T>{(const T *)p, stride}; }
+
+// CABAC job: wait for the step's copy, code the picture, publish the packet
+void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t pts, int slice_type, int poc, int qp, bool first_of_stream)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    SymLayout sl(s->w, s->h);
+    const uint8_t *b = s->lane[lane_i].sym_host[slot];
+    PictureSyms pic;
+    pic.slice_type = slice_type; pic.poc = poc; pic.qp = qp;
+    pic.cu = (const mihevc_cu_rec *)(b + sl.cu);
+    pic.coef[0] = (const int16_t *)(b + sl.cy); pic.coef[1] = (const int16_t *)(b + sl.cu_); pic.coef[2] = (const int16_t *)(b + sl.cv);
+    pic.sao = s->cfg.sao ? (const mihevc_sao_ctu *)(b + sl.sao) : nullptr;
+    Packet pk;
+    pk.pts = pts; pk.key = slice_type == 2;
+    if (slice_type == 2 && (first_of_stream || s->cfg.repeat_headers)) pk.data = s->headers;
+    encode_picture(s->cfg, pic, pk.data);
+    const unsigned long long *sse = (const unsigned long long *)(b + sl.sse);
+    pk.ready = true;
+    auto t1 = std::chrono::steady_clock::now();
+    s->entropy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    {
+        std::lock_guard<std::mutex> l(s->m);
+        s->stats.sse_y += (double)sse[0]; s->stats.sse_u += (double)sse[1]; s->stats.sse_v += (double)sse[2];
+        s->stats.bytes_out += (int64_t)pk.data.size();
+        s->packets[index] = std::move(pk);
+        s->frames_done++;
+        s->jobs_open[slot]--;
+    }
+    s->cv.notify_all();
+}
+
+template <typename T> int encode_chunk(mihevc_session *s)
+{
+    const int n = (int)s->pending.size();
+    if (!n) return 0;
+    const int gops = (n + s->keyint - 1) / s->keyint;
+    if (int e = ensure_lanes(s, gops)) return e;
+    SymLayout sl(s->w, s->h);
+    const int steps = std::min(n, s->keyint);
+    // ---- build every step's argument blocks, upload once ----
+    const StepLayout<T> lay(gops);
+    const size_t need = (size_t)steps * lay.total;
+    if (need > s->args_cap) {
+        if (s->d_args) (void)hipFree(s->d_args);
+        if (s->h_args) (void)hipHostFree(s->h_args);
+        HIPCK(s, hipMalloc(&s->d_args, need));
+        HIPCK(s, hipHostMalloc((void **)&s->h_args, need, hipHostMallocDefault));
+        s->args_cap = need;
+    }
+    uint8_t *ha = s->h_args, *da = (uint8_t *)s->d_args;
+    mihevc_cost_params cp_i, cp_p;
+    mihevc_cost_params_for_qp(s->qp_i, s->cfg.bit_depth, s->me_range, &cp_i);
+    mihevc_cost_params_for_qp(s->qp_p, s->cfg.bit_depth, s->me_range, &cp_p);
+    auto prm = [](const mihevc_cost_params &c) { return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range}; };
+    std::vector<int> batch(steps, 0);
+    for (int t = 0; t < steps; t++)
+        for (int g = 0; g < gops; g++) {
+            int fi = g * s->keyint + t;
+            if (fi >= n) continue;
+            // lanes with a picture at step t are a prefix [0, batch) because only the last GOP can be short
+            batch[t] = g + 1;
+            mihevc_session::Lane &L = s->lane[g];
+            mihevc_session::Src &src = s->pending[fi];
+            StepView<T> hv(ha, lay, t);
+            struct { IntraArgs<T> &intra; InterArgs<T> &inter; DeblockArgs<T> &dbk_v, &dbk_h; SaoArgs<T> &sao; } A{hv.intra[g], hv.inter[g], hv.dbk_v[g], hv.dbk_h[g], hv.sao[g]};
+            uint8_t *sym = L.sym_dev[t % kRing];
+            const int cur = t & 1, prev = cur ^ 1;
+            const CostParams P = prm(t == 0 ? cp_i : cp_p);
+            for (int i = 0; i < 3; i++) {
+                A.intra.src[i] = mkc<T>(src.p[i], src.stride[i]); A.intra.rec[i] = mk<T>(L.work_p[i], L.work_stride[i]);
+                A.inter.src[i] = mkc<T>(src.p[i], src.stride[i]); A.inter.ref[i] = mkc<T>(L.rec_p[prev][i], L.rec_stride[i]);
+                A.inter.rec[i] = mk<T>(L.work_p[i], L.work_stride[i]);
+                A.dbk_v.rec[i] = A.dbk_h.rec[i] = mk<T>(L.work_p[i], L.work_stride[i]);
+                A.sao.src[i] = mkc<T>(src.p[i], src.stride[i]); A.sao.dbk[i] = mkc<T>(L.work_p[i], L.work_stride[i]);
+                A.sao.out[i] = mk<T>(L.rec_p[cur][i], L.rec_stride[i]);
+            }
+            A.intra.w = A.inter.w = A.dbk_v.w = A.dbk_h.w = A.sao.w = s->w;
+            A.intra.h = A.inter.h = A.dbk_v.h = A.dbk_h.h = A.sao.h = s->h;
+            A.intra.ctus_w = A.inter.ctus_w = A.sao.ctus_w = s->ctus_w; A.intra.ctus_h = s->ctus_h;
+            A.intra.prm = A.inter.prm = A.sao.prm = P;
+            A.intra.cu = A.inter.cu = (mihevc_cu_rec *)(sym + sl.cu);
+            A.dbk_v.cu = A.dbk_h.cu = (const mihevc_cu_rec *)(sym + sl.cu);
+            int16_t *c3[3] = {(int16_t *)(sym + sl.cy), (int16_t *)(sym + sl.cu_), (int16_t *)(sym + sl.cv)};
+            for (int i = 0; i < 3; i++) A.intra.coef[i] = A.inter.coef[i] = c3[i];
+            A.intra.diagonal = 0;
+            A.inter.centers = nullptr; A.inter.me = L.me;
+            A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
+            A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
+            A.sao.sse = (unsigned long long *)(sym + sl.sse);
+        }
+    HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
+    // ---- lock-step over the GOPs ----
+    hipEvent_t t_begin, t_end;
+    HIPCK(s, hipEventCreate(&t_begin)); HIPCK(s, hipEventCreate(&t_end));
+    HIPCK(s, hipEventRecord(t_begin, s->st_compute));
+    for (int t = 0; t < steps; t++) {
+        const int slot = t % kRing, B = batch[t];
+        {   // ring wrap: the slot's previous CABAC jobs must be done before the device overwrites its symbols
+            std::unique_lock<std::mutex> l(s->m);
+            s->cv.wait(l, [&] { return s->jobs_open[slot] == 0; });
+        }
+        // the copy of step t - kRing has completed (its jobs waited for it); compute may now reuse the device slot
+        StepView<T> dv(da, lay, t);
+        for (int g = 0; g < B; g++)      // zero the slot's SSE accumulators
+            HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot] + sl.sse, 0, 3 * sizeof(unsigned long long), s->st_compute));
+        if (t == 0) HIPCK(s, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B));
+        else {
+            HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            HIPCK(s, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+        }
+        HIPCK(s, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
+        HIPCK(s, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
+        HIPCK(s, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
+        HIPCK(s, launch_frame_sse<T>(s->st_compute, dv.sao, B));
+        HIPCK(s, hipEventRecord(s->ev_compute[slot], s->st_compute));
+        HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot], 0));
+        for (int g = 0; g < B; g++)
+            HIPCK(s, hipMemcpyAsync(s->lane[g].sym_host[slot], s->lane[g].sym_dev[slot], sl.total, hipMemcpyDeviceToHost, s->st_copy));
+        if (s->keep_recon) {
+            for (int g = 0; g < B; g++) {
+                int fi = g * s->keyint + t;
+                std::vector<uint16_t> &dst = s->recon[s->frames_in - n + fi];
+                dst.assign((size_t)s->w * s->h * 3 / 2, 0);
+                std::vector<uint8_t> tmp((size_t)s->w * s->h * 3 / 2 * esize(s));
+                size_t off = 0;
+                HIPCK(s, hipStreamSynchronize(s->st_compute));
+                for (int i = 0; i < 3; i++) {
+                    int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h;
+                    HIPCK(s, hipMemcpy2D(tmp.data() + off * esize(s), pw * esize(s), s->lane[g].rec_p[t & 1][i], s->lane[g].rec_stride[i] * esize(s),
+                                         pw * esize(s), ph, hipMemcpyDeviceToHost));
+                    off += (size_t)pw * ph;
+                }
+                for (size_t k = 0; k < dst.size(); k++) dst[k] = s->is16 ? ((uint16_t *)tmp.data())[k] : tmp[k];
+            }
+        }
+        HIPCK(s, hipEventRecord(s->ev_copy[slot], s->st_copy));
+        {
+            std::lock_guard<std::mutex> l(s->m);
+            s->jobs_open[slot] += B;
+        }
+        for (int g = 0; g < B; g++) {
+            int fi = g * s->keyint + t;
+            int64_t index = s->frames_in - n + fi, pts = s->pending[fi].pts;
+            hipEvent_t ev = s->ev_copy[slot];
+            int st = t == 0 ? 2 : 1, qp = t == 0 ? s->qp_i : s->qp_p;
+            bool first = index == 0;
+            s->pool->submit([s, slot, g, index, pts, st, t, qp, first, ev] {
+                (void)hipEventSynchronize(ev);
+                entropy_job(s, slot, g, index, pts, st, t, qp, first);
+            });
+        }
+    }
+    HIPCK(s, hipEventRecord(t_end, s->st_compute));
+    HIPCK(s, hipStreamSynchronize(s->st_compute));
+    HIPCK(s, hipStreamSynchronize(s->st_copy));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, t_begin, t_end);
+    s->stats.device_ms += ms;
+    (void)hipEventDestroy(t_begin); (void)hipEventDestroy(t_end);
+    {   // all CABAC jobs of the chunk
+        std::unique_lock<std::mutex> l(s->m);
+        s->cv.wait(l, [&] { return s->jobs_open[0] + s->jobs_open[1] + s->jobs_open[2] + s->jobs_open[3] == 0; });
+    }
+    for (auto &src : s->pending) s->free_src.push_back(src);
+    s->pending.clear();
+    return 0;
+}
+
+int run_chunk(mihevc_session *s)
+{
+    if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
+    return s->is16 ? encode_chunk<uint16_t>(s) : encode_chunk<uint8_t>(s);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
+{
+    if (!cfg || !out) return MIHEVC_EINVAL;
+    *out = nullptr;
+    if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 1) || (cfg->height & 1) || cfg->width > 8192 || cfg->height > 4352) return MIHEVC_EINVAL;
+    if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return MIHEVC_EINVAL;
+    if (cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->keyint < 1 || cfg->keyint > 240) return MIHEVC_EINVAL;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIHEVC_ENODEV;
+    if (device < 0 || device >= n) return MIHEVC_EINVAL;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return MIHEVC_EDEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MIHEVC_ENODEV;      // the code objects are gfx950 only
+    if (hipSetDevice(device) != hipSuccess) return MIHEVC_EDEVICE;
+    mihevc_session *s = new (std::nothrow) mihevc_session();
+    if (!s) return MIHEVC_ENOMEM;
+    s->cfg = *cfg;
+    if (s->cfg.sao < 0) s->cfg.sao = 1;
+    s->device = device;
+    CodedSize cs = coded_size(cfg->width, cfg->height);
+    s->w = cs.w; s->h = cs.h;
+    s->ctus_w = (s->w + CTU - 1) / CTU; s->ctus_h = (s->h + CTU - 1) / CTU; s->n_ctu = s->ctus_w * s->ctus_h;
+    s->is16 = cfg->bit_depth > 8;
+    s->keyint = cfg->keyint;
+    s->lanes = cfg->gops_in_flight > 0 ? std::min(cfg->gops_in_flight, 16) : 4;
+    s->me_range = cfg->me_range > 0 ? std::min(cfg->me_range, MAX_RANGE) : 16;
+    // constant-quality operating point: P pictures at crf + 2, IDR pictures 3 below (x265's ipratio 1.4 ~ 3 QP)
+    s->qp_p = cfg->qp >= 0 ? cfg->qp : std::min(51, std::max(0, cfg->crf + 2));
+    s->qp_i = std::max(0, s->qp_p - 3);
+    s->stats.last_qp = s->qp_p;
+    write_parameter_sets(s->cfg, s->headers);
+    bool ok = hipStreamCreateWithFlags(&s->st_compute, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < kRing; i++)
+        ok = hipEventCreateWithFlags(&s->ev_compute[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { delete s; return MIHEVC_EDEVICE; }
+    int threads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
+    s->pool = new ThreadPool(threads);
+    *out = s;
+    return MIHEVC_OK;
+}
+
+static int ingest(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts, bool device_src)
+{
+    if (!s || !y || !u || !v) return MIHEVC_EINVAL;
+    if (s->failed) return MIHEVC_EDEVICE;
+    if (s->flushed) return MIHEVC_ESTATE;
+    if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
+    mihevc_session::Src src;
+    if (int e = get_src(s, src)) return e;
+    src.pts = pts;
+    const void *in[3] = {y, u, v};
+    const size_t es = esize(s);
+    for (int i = 0; i < 3; i++) {
+        int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h;               // coded plane size
+        int sw = i ? s->cfg.width / 2 : s->cfg.width, sh = i ? s->cfg.height / 2 : s->cfg.height, pitch = i ? pitch_c : pitch_y;
+        if (pitch < sw) return MIHEVC_EINVAL;
+        if (device_src) {
+            HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, hipMemcpyDeviceToDevice, s->st_compute));
+        } else {
+            HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, hipMemcpyHostToDevice, s->st_compute));
+        }
+        // replicate the last column/row into the coded-size margin (the conformance window crops it again)
+        if (pw > sw || ph > sh) {
+            if (s->is16) HIPCK(s, launch_extend_margin<uint16_t>(s->st_compute, Plane<uint16_t>{(uint16_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
+            else HIPCK(s, launch_extend_margin<uint8_t>(s->st_compute, Plane<uint8_t>{(uint8_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
+        }
+    }
+    if (!device_src) HIPCK(s, hipStreamSynchronize(s->st_compute));     // caller's buffers may be reused on return
+    s->pending.push_back(src);
+    s->frames_in++;
+    s->stats.frames_in = s->frames_in;
+    if ((int)s->pending.size() >= s->lanes * s->keyint) return run_chunk(s);
+    return MIHEVC_OK;
+}
+
+int mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts)
+{
+    return ingest(s, y, u, v, pitch_y, pitch_c, pts, false);
+}
+int mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts)
+{
+    return ingest(s, y, u, v, pitch_y, pitch_c, pts, true);
+}
+
+int mihevc_flush(mihevc_session *s)
+{
+    if (!s) return MIHEVC_EINVAL;
+    if (s->failed) return MIHEVC_EDEVICE;
+    if (s->flushed) return MIHEVC_OK;
+    int e = run_chunk(s);
+    s->flushed = true;
+    return e;
+}
+
+int mihevc_receive_packet(mihevc_session *s, const uint8_t **data, size_t *size, int64_t *pts, int64_t *dts, int *keyframe)
+{
+    if (!s || !data || !size) return MIHEVC_EINVAL;
+    std::lock_guard<std::mutex> l(s->m);
+    auto it = s->packets.find(s->next_out);
+    if (it == s->packets.end() || !it->second.ready) return (s->flushed && s->next_out >= s->frames_in) ? MIHEVC_EOF : MIHEVC_EAGAIN;
+    s->cur_packet = std::move(it->second.data);
+    if (pts) *pts = it->second.pts;
+    if (dts) *dts = it->second.pts;        // no reordering: decode order == display order
+    if (keyframe) *keyframe = it->second.key;
+    s->packets.erase(it);
+    s->next_out++;
+    s->stats.frames_out = s->next_out;
+    *data = s->cur_packet.data();
+    *size = s->cur_packet.size();
+    return MIHEVC_OK;
+}
+
+int mihevc_get_headers(mihevc_session *s, const uint8_t **data, size_t *size)
+{
+    if (!s || !data || !size) return MIHEVC_EINVAL;
+    *data = s->headers.data();
+    *size = s->headers.size();
+    return MIHEVC_OK;
+}
+
+int mihevc_get_stats(const mihevc_session *s, mihevc_stats *out)
+{
+    if (!s || !out) return MIHEVC_EINVAL;
+    std::lock_guard<std::mutex> l(const_cast<mihevc_session *>(s)->m);
+    *out = s->stats;
+    out->entropy_ms = (double)s->entropy_ns.load() / 1e6;
+    return MIHEVC_OK;
+}
+
+int mihevc_set_keep_recon(mihevc_session *s, int keep)
+{
+    if (!s) return MIHEVC_EINVAL;
+    s->keep_recon = keep != 0;
+    return MIHEVC_OK;
+}
+
+int mihevc_get_recon(mihevc_session *s, int64_t index, uint16_t *y, uint16_t *u, uint16_t *v)
+{
+    if (!s || !y || !u || !v) return MIHEVC_EINVAL;
+    auto it = s->recon.find(index);
+    if (it == s->recon.end()) return MIHEVC_ESTATE;
+    size_t ny = (size_t)s->w * s->h;
+    memcpy(y, it->second.data(), ny * 2);
+    memcpy(u, it->second.data() + ny, ny / 2);
+    memcpy(v, it->second.data() + ny + ny / 4, ny / 2);
+    return MIHEVC_OK;
+}
+
+int mihevc_coded_size(const mihevc_session *s, int *w, int *h)
+{
+    if (!s || !w || !h) return MIHEVC_EINVAL;
+    *w = s->w; *h = s->h;
+    return MIHEVC_OK;
+}
+
+const char *mihevc_last_error(const mihevc_session *s) { return s ? s->err.c_str() : "null session"; }
+
+void mihevc_close(mihevc_session *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    delete s->pool;      // joins workers
+    if (s->st_compute) (void)hipStreamSynchronize(s->st_compute);
+    if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
+    auto free3 = [](void *b[3]) { for (int i = 0; i < 3; i++) if (b[i]) (void)hipFree(b[i]); };
+    for (auto &x : s->pending) free3(x.base);
+    for (auto &x : s->free_src) free3(x.base);
+    for (auto &L : s->lane) {
+        free3(L.rec_base[0]); free3(L.rec_base[1]); free3(L.work_base);
+        if (L.me) (void)hipFree(L.me);
+        for (int k = 0; k < kRing; k++) { if (L.sym_dev[k]) (void)hipFree(L.sym_dev[k]); if (L.sym_host[k]) (void)hipHostFree(L.sym_host[k]); }
+    }
+    if (s->d_args) (void)hipFree(s->d_args);
+    if (s->h_args) (void)hipHostFree(s->h_args);
+    for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
+    if (s->st_compute) (void)hipStreamDestroy(s->st_compute);
+    if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
+    delete s;
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""Python driver of the native MI355X encoder (C ABI in include/mihevc.h, loaded by hevc_amd._lib).
+
+`Encoder` is a thin object wrapper over one `mihevc_session`; `encode_file` is what `convert_video` calls for the
+'MI355X' backend: probe -> operating point (the same numbers the reference hands to libx265,
+core/transcoder.py:357-412) -> read frames -> session -> Annex-B packets -> MP4 (hvc1).  ctypes releases the GIL
+during every call, so N worker threads can each drive their own session like the reference's N QThreads each
+block on their own ffmpeg child (gui/worker.py:30-52).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import threading
+from fractions import Fraction
+from pathlib import Path
+from typing import Callable, Iterator, Optional, Tuple
+
+import numpy as np
+
+from . import _lib
+from .probe import VideoInfo
+
+logger = logging.getLogger(__name__)
+
+_COLOUR_CODES = {  # ffprobe names -> H.265 Table E.3/E.4/E.5 code points
+    "primaries": {"bt709": 1, "bt470bg": 5, "smpte170m": 6, "bt2020": 9},
+    "transfer": {"bt709": 1, "smpte170m": 6, "smpte2084": 16, "pq": 16, "arib-std-b67": 18, "bt2020-10": 14},
+    "matrix": {"bt709": 1, "bt470bg": 5, "smpte170m": 6, "bt2020nc": 9, "bt2020-ncl": 9, "bt2020": 9},
+}
+
+
+def config_for(info: VideoInfo, crf: int, vbv_maxrate: int, vbv_bufsize: int, gop: int, level: str, tier: str,
+               master_display: str = "", max_cll: str = "") -> _lib.Config:
+    """Map the reference's libx265 operating point (build_ffmpeg_params CPU branch) onto a mihevc_config."""
+    from .utils import parse_master_display, parse_max_cll
+    cfg = _lib.default_config()
+    cfg.width, cfg.height = int(info.width), int(info.height)
+    fr = Fraction(str(info.fps or 30.0)).limit_denominator(1001)
+    cfg.fps_num, cfg.fps_den = fr.numerator, fr.denominator
+    hdr = bool(info.hdr)
+    cfg.bit_depth = 10 if hdr else 8
+    cfg.level_idc = int(round(float(level) * 30))
+    cfg.tier = 1 if tier == "high" else 0
+    cfg.crf, cfg.qp = int(crf), -1
+    cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = int(vbv_maxrate), int(vbv_bufsize)
+    cfg.keyint, cfg.min_keyint = int(gop), max(2, int(gop) // 2)
+    if hdr:   # the HDR10 set of core/utils.py:58-69
+        cfg.colour_primaries, cfg.transfer, cfg.matrix = 9, 16, 9
+        cfg.chroma_loc, cfg.aud, cfg.repeat_headers, cfg.hdr10 = 0, 1, 1, 1
+        md = parse_master_display(master_display or info.master_display)
+        for i, (x, y) in enumerate((md.g, md.b, md.r)):
+            cfg.md_primaries[i][0], cfg.md_primaries[i][1] = x, y
+        cfg.md_white[0], cfg.md_white[1] = md.wp
+        cfg.md_max_lum, cfg.md_min_lum = md.lum
+        cfg.max_cll, cfg.max_fall = parse_max_cll(max_cll or info.max_cll)
+    else:
+        cfg.colour_primaries = _COLOUR_CODES["primaries"].get(info.color_primaries, 1)
+        cfg.transfer = _COLOUR_CODES["transfer"].get(info.color_transfer, 1)
+        cfg.matrix = _COLOUR_CODES["matrix"].get(info.color_space, 1)
+    return cfg
+
+
+class Encoder:
+    """One encode session on one MI355X.  Raises _lib.MihevcError on any native failure (never falls back)."""
+
+    def __init__(self, cfg: _lib.Config, device: int = 0, keep_recon: bool = False):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        self._s = C.c_void_p()
+        rc = self._lib.mihevc_open(C.byref(cfg), device, C.byref(self._s))
+        if rc != 0:
+            raise _lib.MihevcError(rc, "mihevc_open")
+        if keep_recon:
+            self._lib.mihevc_set_keep_recon(self._s, 1)
+        self._pts = 0
+
+    # -- lifecycle
+    def close(self):
+        if self._s:
+            self._lib.mihevc_close(self._s)
+            self._s = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            detail = self._lib.mihevc_last_error(self._s).decode() if self._s else ""
+            raise _lib.MihevcError(rc, f"{what} {detail}".strip())
+
+    # -- data path
+    def send(self, y: np.ndarray, u: np.ndarray, v: np.ndarray, pts: Optional[int] = None):
+        """Planes as uint8 (8 bit) or uint16 (10 bit) arrays of the DISPLAY size."""
+        dt = np.uint8 if self.cfg.bit_depth == 8 else np.uint16
+        y, u, v = (np.ascontiguousarray(p, dtype=dt) for p in (y, u, v))
+        pts = self._pts if pts is None else pts
+        self._pts = pts + 1
+        self._check(self._lib.mihevc_send_frame(self._s, y.ctypes.data, u.ctypes.data, v.ctypes.data, y.shape[1], u.shape[1], pts), "send_frame")
+
+    def send_device(self, y_ptr: int, u_ptr: int, v_ptr: int, pitch_y: int, pitch_c: int, pts: Optional[int] = None):
+        pts = self._pts if pts is None else pts
+        self._pts = pts + 1
+        self._check(self._lib.mihevc_send_frame_device(self._s, y_ptr, u_ptr, v_ptr, pitch_y, pitch_c, pts), "send_frame_device")
+
+    def flush(self):
+        self._check(self._lib.mihevc_flush(self._s), "flush")
+
+    def packets(self) -> Iterator[Tuple[bytes, int, bool]]:
+        """Drain every packet that is ready: (annexb bytes, pts, keyframe)."""
+        data, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+        pts, dts, key = C.c_int64(), C.c_int64(), C.c_int()
+        while True:
+            rc = self._lib.mihevc_receive_packet(self._s, C.byref(data), C.byref(size), C.byref(pts), C.byref(dts), C.byref(key))
+            if rc in (_lib.EAGAIN, _lib.EOF):
+                return
+            self._check(rc, "receive_packet")
+            yield C.string_at(data, size.value), pts.value, bool(key.value)
+
+    def headers(self) -> bytes:
+        data, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+        self._check(self._lib.mihevc_get_headers(self._s, C.byref(data), C.byref(size)), "get_headers")
+        return C.string_at(data, size.value)
+
+    def stats(self) -> _lib.Stats:
+        st = _lib.Stats()
+        self._check(self._lib.mihevc_get_stats(self._s, C.byref(st)), "get_stats")
+        return st
+
+    def coded_size(self) -> Tuple[int, int]:
+        w, h = C.c_int(), C.c_int()
+        self._lib.mihevc_coded_size(self._s, C.byref(w), C.byref(h))
+        return w.value, h.value
+
+    def recon(self, index: int):
+        w, h = self.coded_size()
+        y, u, v = np.zeros((h, w), np.uint16), np.zeros((h // 2, w // 2), np.uint16), np.zeros((h // 2, w // 2), np.uint16)
+        self._check(self._lib.mihevc_get_recon(self._s, index, y.ctypes.data, u.ctypes.data, v.ctypes.data), "get_recon")
+        return y, u, v
+
+    def psnr_y(self) -> float:
+        st = self.stats()
+        n = max(1, st.frames_out) * self.coded_size()[0] * self.coded_size()[1]
+        peak = (1 << self.cfg.bit_depth) - 1
+        mse = st.sse_y / n
+        return 99.0 if mse <= 0 else float(10 * np.log10(peak * peak / mse))
+
+
+def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callback: Optional[Callable[[str, int, int], None]] = None,
+                total_frames: int = 1, stop_event: Optional[threading.Event] = None, device: Optional[int] = None, debug: bool = False) -> int:
+    """Encode `file_path` to `out_path` (MP4/hvc1) on an MI355X.  Returns 0 on success, 1 on failure/cancel —
+    the same (returncode) shape `run_ffmpeg` gives `convert_video` (core/transcoder.py:497-535)."""
+    from . import mp4, yuvio
+    from .transcoder import calculate_apple_hevc_level, calculate_dynamic_values
+
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
+    level, tier = calculate_apple_hevc_level(info)
+    cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
+    clip = yuvio.open_any(Path(file_path), info)
+    try:
+        total = clip.n_frames or total_frames
+        mux = mp4.Mp4Writer(Path(out_path), cfg)
+        with Encoder(cfg, device=device or 0) as enc:
+            n_out = 0
+            for i, (y, u, v) in enumerate(clip.frames()):
+                if stop_event is not None and stop_event.is_set():
+                    mux.abort()
+                    return 1
+                enc.send(y, u, v, pts=i)
+                for data, pts, key in enc.packets():
+                    mux.add_sample(data, pts, key)
+                    n_out += 1
+                if progress_callback:
+                    try:
+                        progress_callback(Path(file_path).name, n_out, total)
+                    except Exception:
+                        logger.debug("progress_callback raised", exc_info=True)
+            enc.flush()
+            for data, pts, key in enc.packets():
+                mux.add_sample(data, pts, key)
+                n_out += 1
+            if progress_callback:
+                try:
+                    progress_callback(Path(file_path).name, n_out, total)
+                except Exception:
+                    logger.debug("progress_callback raised", exc_info=True)
+            mux.finish(enc.headers())
+        return 0 if n_out > 0 else 1
+    finally:
+        clip.close()

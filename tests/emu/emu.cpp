@@ -1,0 +1,162 @@
+// tests/emu/emu.cpp — TEST HARNESS, NOT PRODUCT.  Steps the phase programs of hevc_amd/csrc/kernels/*.h on the
+// CPU with the sequential executor (one "thread" at a time, barrier = end of loop), so the kernel SOURCE can be
+// checked against the oracle on machines without a GPU.  It proves the kernels' logic, not the GPU execution:
+// the -m gpu tests run the real gfx950 binaries through the C ABI.  hevc_amd/ never loads this library.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../hevc_amd/csrc/kernels/common.h"
+#include "../../hevc_amd/csrc/kernels/inter.h"
+#include "../../hevc_amd/csrc/kernels/intra.h"
+#include "../../hevc_amd/csrc/kernels/loopfilter.h"
+
+using namespace mihevc;
+
+template <typename T> struct Padded {
+    std::vector<T> buf;
+    int stride, pad;
+    Plane<T> plane;
+    Padded(int w, int h, int pad_) : pad(pad_)
+    {
+        stride = w + 2 * pad;
+        buf.assign((size_t)stride * (h + 2 * pad), 0);
+        plane.p = buf.data() + (size_t)pad * stride + pad;
+        plane.stride = stride;
+    }
+    void load(const T *src, int w, int h)
+    {
+        for (int y = 0; y < h; y++) memcpy(plane.p + (ptrdiff_t)y * stride, src + (size_t)y * w, w * sizeof(T));
+        for (int i = 0; i < (w + 2 * pad) * (h + 2 * pad); i++) pad_sample<T>(plane, w, h, pad, i);
+    }
+    void store(T *dst, int w, int h) const
+    {
+        for (int y = 0; y < h; y++) memcpy(dst + (size_t)y * w, plane.p + (ptrdiff_t)y * stride, w * sizeof(T));
+    }
+};
+
+static CostParams to_prm(const mihevc_cost_params *p)
+{
+    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range};
+}
+
+template <typename T>
+static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const T *ru, const T *rv, int w, int h,
+                       const mihevc_cost_params *prm, const int16_t *centers, T *oy, T *ou, T *ov, mihevc_cu_rec *cu,
+                       int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump)
+{
+    Padded<T> ref0(w, h, PAD_Y), ref1(w / 2, h / 2, PAD_C), ref2(w / 2, h / 2, PAD_C);
+    ref0.load(ry, w, h); ref1.load(ru, w / 2, h / 2); ref2.load(rv, w / 2, h / 2);
+    InterArgs<T> a;
+    a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
+    a.ref[0] = {ref0.plane.p, ref0.stride}; a.ref[1] = {ref1.plane.p, ref1.stride}; a.ref[2] = {ref2.plane.p, ref2.stride};
+    a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU;
+    a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv;
+    int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU), R = a.prm.me_range;
+    std::vector<int32_t> me((size_t)n_ctu * 63);
+    a.me = me.data();
+    SeqExec ex;
+    std::vector<T> win((size_t)(32 + 2 * R) * me_win_stride(R));
+    std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R)), wu((size_t)mc_win_c(R) * mc_win_c_stride(R)), wv(wu.size());
+    for (int c = 0; c < n_ctu; c++) {
+        MeShared<T> *ms = new MeShared<T>();
+        me_search_program<T>(ex, *ms, win.data(), a, c);
+        delete ms;
+    }
+    if (me_dump) memcpy(me_dump, me.data(), me.size() * sizeof(int32_t));
+    for (int c = 0; c < n_ctu; c++) {
+        InterShared<T> *is = new InterShared<T>();
+        inter_ctu_program<T>(ex, *is, wy.data(), wu.data(), wv.data(), a, c);
+        delete is;
+    }
+    return 0;
+}
+
+template <typename T>
+static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, const mihevc_cost_params *prm, T *oy, T *ou, T *ov,
+                       mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+{
+    IntraArgs<T> a;
+    a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
+    a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU;
+    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv;
+    SeqExec ex;
+    // same launch order as the device: one anti-diagonal (cx + 2 cy) at a time
+    for (int d = 0; d <= (a.ctus_w - 1) + 2 * (a.ctus_h - 1); d++) {
+        a.diagonal = d;
+        for (int cyi = 0; cyi < a.ctus_h; cyi++) {
+            int cxi = d - 2 * cyi;
+            if (cxi < 0 || cxi >= a.ctus_w) continue;
+            IntraShared<T> *is = new IntraShared<T>();
+            intra_ctu_program<T>(ex, *is, a, cxi, cyi);
+            delete is;
+        }
+    }
+    return 0;
+}
+
+template <typename T> static int deblock(T *y, T *u, T *v, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
+{
+    DeblockArgs<T> a;
+    a.rec[0] = {y, w}; a.rec[1] = {u, w / 2}; a.rec[2] = {v, w / 2};
+    a.w = w; a.h = h; a.cu = cu; a.bit_depth = bit_depth;
+    for (int dir = 0; dir < 2; dir++) {
+        a.dir = dir;
+        for (int i = 0; i < (w / 8) * (h / 8) * 2; i++) deblock_segment<T>(a, i);
+    }
+    return 0;
+}
+
+template <typename T>
+static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, const T *dv, int w, int h, const mihevc_cost_params *prm,
+               T *oy, T *ou, T *ov, mihevc_sao_ctu *out)
+{
+    SaoArgs<T> a;
+    a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
+    a.dbk[0] = {dy, w}; a.dbk[1] = {du, w / 2}; a.dbk[2] = {dv, w / 2};
+    a.out[0] = {oy, w}; a.out[1] = {ou, w / 2}; a.out[2] = {ov, w / 2};
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.prm = to_prm(prm); a.sao = out; a.sse = nullptr;
+    SeqExec ex;
+    int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU);
+    for (int c = 0; c < n_ctu; c++) { SaoShared s; sao_ctu_program<T>(ex, s, a, c); }
+    for (int pl = 0; pl < 3; pl++)
+        for (int yy = 0; yy < (pl ? h / 2 : h); yy++)
+            for (int xx = 0; xx < (pl ? w / 2 : w); xx++) sao_apply_sample<T>(a, pl, xx, yy);
+    return 0;
+}
+
+extern "C" {
+int emu_inter_frame(const void *sy, const void *su, const void *sv, const void *ry, const void *ru, const void *rv, int w, int h,
+                    const mihevc_cost_params *prm, const int16_t *centers, void *oy, void *ou, void *ov, mihevc_cu_rec *cu,
+                    int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump)
+{
+    if (prm->bit_depth == 8)
+        return inter_frame<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (const uint8_t *)ry, (const uint8_t *)ru,
+                                    (const uint8_t *)rv, w, h, prm, centers, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv, me_dump);
+    return inter_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)ry, (const uint16_t *)ru,
+                                 (const uint16_t *)rv, w, h, prm, centers, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv, me_dump);
+}
+int emu_intra_frame(const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *oy, void *ou, void *ov,
+                    mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+{
+    if (prm->bit_depth == 8)
+        return intra_frame<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, w, h, prm, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv);
+    return intra_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, w, h, prm, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv);
+}
+int emu_deblock(void *y, void *u, void *v, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
+{
+    if (bit_depth == 8) return deblock<uint8_t>((uint8_t *)y, (uint8_t *)u, (uint8_t *)v, w, h, cu, bit_depth);
+    return deblock<uint16_t>((uint16_t *)y, (uint16_t *)u, (uint16_t *)v, w, h, cu, bit_depth);
+}
+int emu_sao(const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int h,
+            const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *out)
+{
+    if (prm->bit_depth == 8)
+        return sao<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (const uint8_t *)dy, (const uint8_t *)du, (const uint8_t *)dv, w, h, prm,
+                            (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, out);
+    return sao<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)dy, (const uint16_t *)du, (const uint16_t *)dv, w, h, prm,
+                         (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, out);
+}
+}

@@ -1,0 +1,152 @@
+"""GPU (-m gpu): the gfx950 kernels, called through the C ABI, against the oracle — bit exact.
+Also the whole session: bitstream -> oracle decoder == encoder reconstruction == oracle pipeline."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hevc_amd import _lib
+    L = _lib.load()
+    assert L.mihevc_device_count() >= 1, "no gfx950 device visible: the GPU tests need an MI355X"
+    return L
+
+
+@pytest.fixture(scope="module")
+def api(lib):
+    return util.StageApi(lib, "mihevc_k_", device=0)
+
+
+def lib_params(lib, qp, bd, rng):
+    from hevc_amd import _lib
+    p = _lib.cost_params(qp, bd, rng)
+    return O.Params(p.qp, p.qp_c, p.bit_depth, p.lambda_sad_q4, p.lambda_q4, p.me_range), p
+
+
+@pytest.mark.parametrize("log2n", [3, 4, 5])
+@pytest.mark.parametrize("qp,bd,intra", [(22, 8, 1), (37, 8, 0), (27, 10, 1)])
+def test_k3_transform_quant_roundtrip(lib, log2n, qp, bd, intra):
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n * 100 + qp)
+    nb = 70
+    amp = (1 << bd) - 1
+    res = rng.integers(-amp, amp + 1, (nb, n, n)).astype(np.int16)
+    res[0] = 0
+    res[1] = 7                       # DC only
+    res[2] = rng.integers(-3, 4, (n, n))
+    lv = np.zeros_like(res)
+    rc = np.zeros_like(res)
+    assert lib.mihevc_k_transform(0, util.ptr(res), util.ptr(lv), util.ptr(rc), nb, log2n, qp, bd, intra, 0) == 0
+    for b in range(nb):
+        coef = O.fwd_transform(res[b], bit_depth=bd)
+        want_l = O.quant(coef, qp, bit_depth=bd, intra=bool(intra))
+        want_r = O.inv_transform(O.dequant(want_l, qp, bit_depth=bd), bit_depth=bd)
+        assert np.array_equal(lv[b], want_l), (b, log2n)
+        assert np.array_equal(rc[b], want_r), (b, log2n)
+    assert not lv[0].any() and not rc[0].any()
+
+
+CASES = [
+    (64, 64, 30, 8, 8),
+    (96, 80, 22, 8, 8),
+    (136, 72, 35, 8, 16),
+    (72, 104, 26, 10, 8),
+    (160, 96, 14, 8, 12),
+    (320, 192, 24, 8, 32),
+]
+
+
+@pytest.mark.parametrize("w,h,qp,bd,rng", CASES)
+def test_stage_parity_i_p_p(lib, api, w, h, qp, bd, rng):
+    """K2+K3 (intra), K1+K3 (inter), K4a (deblock), K4b (SAO) each against the oracle on the same inputs."""
+    prm_i, cp_i = lib_params(lib, max(0, qp - 3), bd, rng)
+    prm_p, cp_p = lib_params(lib, qp, bd, rng)
+    srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
+    want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
+    ref = None
+    for i, (src, (a, d, f, sp)) in enumerate(zip(srcs, want)):
+        cp = cp_i if i == 0 else cp_p
+        got = api.intra(src, cp) if i == 0 else api.inter(src, ref, cp)
+        if i:
+            assert np.array_equal(a.me, got.me), f"picture {i}: integer search differs"
+        assert util.same_analysis(a, got), f"picture {i}: " + util.describe_diff(a, got)
+        assert api.deblock(a.rec, a.cu, bd).same(d), f"deblock picture {i}"
+        gf, gsp = api.sao(src, d, cp)
+        assert np.array_equal(gsp, sp), f"sao params picture {i}"
+        assert gf.same(f), f"sao picture {i}"
+        ref = f
+
+
+def test_search_centres(lib, api):
+    w, h = 96, 64
+    prm, cp = lib_params(lib, 26, 8, 8)
+    a, b = util.synth_frame(h, w, 5), util.synth_frame(h, w, 5, shift=(11, -6))
+    cen = np.zeros((util.n_ctus(w, h), 2), np.int16)
+    cen[:, 0], cen[:, 1] = 10, -5
+    want = O.analyze_inter(b, a, prm, centers=cen, dump_me=True)
+    got = api.inter(b, a, cp, centers=cen)
+    assert np.array_equal(want.me, got.me) and util.same_analysis(want, got)
+
+
+def _encode(cfg, frames, keep=True):
+    from hevc_amd.encoder import Encoder
+    out = b""
+    with Encoder(cfg, device=0, keep_recon=keep) as enc:
+        for f in frames:
+            y, u, v = util.planes(f, cfg.bit_depth)
+            enc.send(y, u, v)
+            for data, pts, key in enc.packets():
+                out += data
+        enc.flush()
+        n = 0
+        pk = []
+        for data, pts, key in enc.packets():
+            out += data
+            pk.append((len(data), pts, key))
+        recs = [enc.recon(i) for i in range(len(frames))] if keep else []
+        st = enc.stats()
+        return out, recs, st, enc.coded_size()
+
+
+@pytest.mark.parametrize("w,h,bd,keyint,n", [(96, 80, 8, 4, 10), (132, 76, 8, 5, 7), (64, 64, 10, 3, 7)])
+def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint, n):
+    """End to end: session -> Annex-B -> oracle decoder must equal the encoder's own reconstruction AND the oracle
+    pipeline run with the same QPs; includes non-multiple-of-8 sizes (conformance window) and a short last GOP."""
+    from hevc_amd import _lib
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint = w, h, bd, keyint, 2
+    cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud = 27, 8, 2, 1
+    if bd == 10:
+        cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers = 1, 9, 16, 9, 0, 1
+    frames = [util.synth_frame(h, w, seed=9, shift=(i, i // 2), bit_depth=bd) for i in range(n)]
+    stream, recs, st, (cw, ch) = _encode(cfg, frames)
+    assert st.frames_out == n and cw % 8 == 0 and ch % 8 == 0
+    dec, info = O.decode(stream)
+    assert len(dec) == n and info["width"] == cw and info["conf_width"] == w and info["conf_height"] == h
+    assert info["count.aud"] == n
+    # oracle pipeline on the padded source with the session's QPs
+    qp_p, qp_i = st.last_qp, max(0, st.last_qp - 3)
+    prm_i, _ = lib_params(lib, qp_i, bd, 8)
+    prm_p, _ = lib_params(lib, qp_p, bd, 8)
+    ref = None
+    for i, f in enumerate(frames):
+        pad = O.Frame(np.pad(f.y, ((0, ch - h), (0, cw - w)), mode="edge"), np.pad(f.u, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"),
+                      np.pad(f.v, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"))
+        if i % keyint == 0:
+            a = O.analyze_intra(pad, prm_i)
+        else:
+            a = O.analyze_inter(pad, ref, prm_p)
+        prm = prm_i if i % keyint == 0 else prm_p
+        ref, _ = O.sao(pad, O.deblock(a.rec, a.cu, bd), prm)
+        enc_rec = O.Frame(*recs[i])
+        assert enc_rec.same(ref), f"frame {i}: session reconstruction != oracle pipeline"
+        assert dec[i].same(enc_rec), f"frame {i}: decoded picture != encoder reconstruction"
+    if bd == 10:
+        assert info["sei.mdcv.gx"] == 13250 and info["sei.cll.max_cll"] == 1000 and info["sps.profile_idc"] == 2
