@@ -22,12 +22,16 @@ class Config(C.Structure):
         "aud", "repeat_headers", "hdr10")] +
         [("md_primaries", (C.c_uint16 * 2) * 3), ("md_white", C.c_uint16 * 2), ("md_max_lum", C.c_uint32), ("md_min_lum", C.c_uint32),
          ("max_cll", C.c_uint16), ("max_fall", C.c_uint16)] +
-        [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao")] + [("reserved", C.c_int32 * 8)])
+        [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages")] + [("reserved", C.c_int32 * 7)])
 
 
 class Stats(C.Structure):
     _fields_ = [("frames_in", C.c_int64), ("frames_out", C.c_int64), ("bytes_out", C.c_int64), ("sse_y", C.c_double), ("sse_u", C.c_double),
-                ("sse_v", C.c_double), ("device_ms", C.c_double), ("entropy_ms", C.c_double), ("last_qp", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("sse_v", C.c_double), ("device_ms", C.c_double), ("entropy_ms", C.c_double), ("last_qp", C.c_int32), ("reserved", C.c_int32 * 7),
+                ("stage_ms", C.c_double * 8), ("stage_launches", C.c_int64 * 8), ("stage_pictures", C.c_int64 * 8)]
+
+
+STAGE_NAMES = ("intra", "me_search", "inter_ctu", "deblock", "sao", "pad", "sse", "unused")
 
 
 class CostParams(C.Structure):

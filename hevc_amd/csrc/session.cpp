@@ -126,7 +126,9 @@ struct mihevc_session {
     uint8_t *h_args = nullptr;        // pinned staging for the same
     size_t args_cap = 0;
     hipEvent_t ev_compute[kRing], ev_copy[kRing];
-    std::vector<hipEvent_t> ev_time;
+    std::vector<hipEvent_t> ev_pool;   // profile_stages: start/stop pairs
+    struct Mark { int stage, pictures; size_t ev; };
+    std::vector<Mark> marks;
     // host side
     ThreadPool *pool = nullptr;
     std::mutex m;
@@ -321,15 +323,25 @@ template <typename T> int encode_chunk(mihevc_session *s)
         StepView<T> dv(da, lay, t);
         for (int g = 0; g < B; g++)      // zero the slot's SSE accumulators
             HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot] + sl.sse, 0, 3 * sizeof(unsigned long long), s->st_compute));
-        if (t == 0) HIPCK(s, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B));
+        auto mark = [&](int stage, bool begin) -> int {       // bracket a stage with events when profiling
+            if (!s->cfg.profile_stages) return 0;
+            size_t need_ev = s->marks.size() * 2 + 2;
+            while (s->ev_pool.size() < need_ev) { hipEvent_t e; HIPCK(s, hipEventCreate(&e)); s->ev_pool.push_back(e); }
+            if (begin) { s->marks.push_back({stage, B, s->marks.size() * 2}); HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev], s->st_compute)); }
+            else HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev + 1], s->st_compute));
+            return 0;
+        };
+#define STAGE(idx, call) do { if (int e_ = mark(idx, true)) return e_; HIPCK(s, call); if (int e_ = mark(idx, false)) return e_; } while (0)
+        if (t == 0) STAGE(0, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B));
         else {
-            HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
-            HIPCK(s, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            STAGE(1, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            STAGE(2, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
         }
-        HIPCK(s, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
-        HIPCK(s, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
-        HIPCK(s, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
-        HIPCK(s, launch_frame_sse<T>(s->st_compute, dv.sao, B));
+        STAGE(3, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
+        STAGE(4, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
+        STAGE(5, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
+        STAGE(6, launch_frame_sse<T>(s->st_compute, dv.sao, B));
+#undef STAGE
         HIPCK(s, hipEventRecord(s->ev_compute[slot], s->st_compute));
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot], 0));
         for (int g = 0; g < B; g++)
@@ -374,6 +386,13 @@ template <typename T> int encode_chunk(mihevc_session *s)
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t_begin, t_end);
     s->stats.device_ms += ms;
+    for (auto &mk : s->marks) {
+        float e = 0;
+        if (hipEventElapsedTime(&e, s->ev_pool[mk.ev], s->ev_pool[mk.ev + 1]) == hipSuccess) {
+            s->stats.stage_ms[mk.stage] += e; s->stats.stage_launches[mk.stage]++; s->stats.stage_pictures[mk.stage] += mk.pictures;
+        }
+    }
+    s->marks.clear();
     (void)hipEventDestroy(t_begin); (void)hipEventDestroy(t_end);
     {   // all CABAC jobs of the chunk
         std::unique_lock<std::mutex> l(s->m);
@@ -571,6 +590,7 @@ void mihevc_close(mihevc_session *s)
     if (s->d_args) (void)hipFree(s->d_args);
     if (s->h_args) (void)hipHostFree(s->h_args);
     for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
+    for (auto e : s->ev_pool) (void)hipEventDestroy(e);
     if (s->st_compute) (void)hipStreamDestroy(s->st_compute);
     if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
     delete s;

@@ -60,7 +60,8 @@ typedef struct mihevc_config {
     int32_t gops_in_flight;           /* closed GOPs encoded in lock-step on the device; 0 = default */
     int32_t host_threads;             /* CABAC worker threads; 0 = default */
     int32_t sao;                      /* 1 (default -1 -> 1) enable SAO */
-    int32_t reserved[8];
+    int32_t profile_stages;           /* 1: bracket every stage launch with HIP events on the compute stream (mihevc_stats.stage_ms) */
+    int32_t reserved[7];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -71,6 +72,12 @@ typedef struct mihevc_stats {
     double  device_ms, entropy_ms;    /* accumulated device time (HIP events) and host CABAC time (sum over threads) */
     int32_t last_qp;
     int32_t reserved[7];
+    /* per-stage device time, filled when cfg.profile_stages: sum of HIP-event intervals and number of launches.
+     * index: 0 intra (all anti-diagonals of a step), 1 me_search, 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
+     * 5 border pad, 6 sse, 7 unused.  One launch covers `pictures` pictures (the lock-step batch). */
+    double  stage_ms[8];
+    int64_t stage_launches[8];
+    int64_t stage_pictures[8];
 } mihevc_stats;
 
 int  mihevc_abi_version(void);
