@@ -1,0 +1,140 @@
+"""Headless batch queue: the reference's MainWindow queue semantics without Qt, one clip per GPU.
+
+Reference behaviour reproduced (gui/mainwindow.py:254-355): recursive scan for INPUT_EXTS under the input
+directory (config.py:9-12), a FIFO of files, N workers each running `convert_video` on one file at a time, refill
+on completion, a CSV log rewritten after every finished file with the six reference columns
+`file,status,quality,retries,method,hdr` (gui/mainwindow.py:347-355), and `stop_all` that signals only the ACTIVE
+workers (gui/mainwindow.py:303-308) — queued files keep starting, as in the reference.
+New: GPU affinity.  Worker k is pinned to MI355X ordinal `k % n_devices`, so a batch shards one clip per GPU across
+the node with no collective (BASELINE.json configs[3]).  Extra CSV columns follow the six.
+"""
+from __future__ import annotations
+
+import csv
+import logging
+import threading
+import time
+from collections import deque
+from pathlib import Path
+from typing import Callable, Dict, List, Optional
+
+from .transcoder import convert_video
+from .utils import mi355x_device_count
+
+logger = logging.getLogger(__name__)
+
+INPUT_EXTS = ('.mp4', '.mov', '.mkv', '.avi', '.wmv', '.flv', '.ts', '.m2ts', '.mts', '.m4v', '.webm', '.3gp', '.f4v', '.ogv', '.vob',
+              '.mpg', '.mpeg', '.y4m', '.yuv')          # config.py:9-12 plus the raw containers the native path reads
+CSV_FIELDS = ['file', 'status', 'quality', 'retries', 'method', 'hdr']          # gui/mainwindow.py:351
+EXTRA_FIELDS = ['seconds', 'device']
+
+
+def scan_inputs(input_dir: Path) -> List[Path]:
+    return sorted(p for p in Path(input_dir).rglob('*') if p.is_file() and p.suffix.lower() in INPUT_EXTS)
+
+
+class BatchRunner:
+    def __init__(self, files: List[Path], out_dir: Path, max_workers: Optional[int] = None, debug=False, skip_validator=False,
+                 force_cpu=False, force_gpu=False, csv_path: Optional[Path] = None,
+                 on_progress: Optional[Callable[[str, int, int], None]] = None, on_finished: Optional[Callable[[Dict], None]] = None,
+                 convert=convert_video, n_devices: Optional[int] = None):
+        self.queue = deque(Path(f) for f in files)
+        self.out_dir = Path(out_dir)
+        self.n_devices = mi355x_device_count() if n_devices is None else n_devices
+        self.max_workers = max_workers or max(1, self.n_devices) or 1
+        self.kw = dict(debug=debug, skip_validator=skip_validator, force_cpu=force_cpu, force_gpu=force_gpu)
+        self.csv_path = Path(csv_path) if csv_path else self.out_dir / 'transcode_log.csv'
+        self.on_progress, self.on_finished, self.convert = on_progress, on_finished, convert
+        self.results: List[Dict] = []
+        self._lock = threading.Lock()
+        self._active: Dict[int, threading.Event] = {}
+        self._threads: List[threading.Thread] = []
+
+    # -- reference: MainWindow.start_batch / _start_next_worker / on_finished
+    def _worker(self, slot: int):
+        while True:
+            with self._lock:
+                if not self.queue:
+                    self._active.pop(slot, None)
+                    return
+                f = self.queue.popleft()
+                ev = threading.Event()
+                self._active[slot] = ev
+            device = slot % self.n_devices if self.n_devices else None
+            t0 = time.time()
+            try:
+                kw = dict(self.kw)
+                if device is not None:
+                    kw['device'] = device
+                res = self.convert(f, self.out_dir, progress_callback=self.on_progress, stop_event=ev, **kw)
+            except Exception as exc:            # gui/worker.py:43-52: last-resort FAILED/UNKNOWN result
+                logger.error('[ERROR] %s: %s', f.name, exc)
+                res = {'file': f.name, 'status': 'FAILED', 'quality': None, 'retries': 0, 'method': 'UNKNOWN', 'hdr': False}
+            res = dict(res)
+            res['seconds'] = round(time.time() - t0, 3)
+            res['device'] = device if res.get('method') == 'MI355X' else ''
+            with self._lock:
+                self.results.append(res)
+                self.save_csv()
+            if self.on_finished:
+                try:
+                    self.on_finished(res)
+                except Exception:
+                    logger.debug('on_finished raised', exc_info=True)
+
+    def start(self):
+        self.out_dir.mkdir(parents=True, exist_ok=True)
+        n = min(self.max_workers, len(self.queue))
+        for k in range(n):
+            t = threading.Thread(target=self._worker, args=(k,), daemon=True)
+            self._threads.append(t)
+            t.start()
+        return self
+
+    def stop_all(self, cancel_queued: bool = False):
+        """Signal the active workers (reference semantics); cancel_queued=True also empties the queue."""
+        with self._lock:
+            if cancel_queued:
+                self.queue.clear()
+            for ev in self._active.values():
+                ev.set()
+
+    def wait(self) -> List[Dict]:
+        for t in self._threads:
+            t.join()
+        return self.results
+
+    def save_csv(self):
+        with open(self.csv_path, 'w', newline='', encoding='utf-8') as f:
+            w = csv.DictWriter(f, fieldnames=CSV_FIELDS + EXTRA_FIELDS, extrasaction='ignore')
+            w.writeheader()
+            for r in self.results:
+                w.writerow(r)
+
+
+def batch_convert(input_dir: Path, output_dir: Path, max_workers: Optional[int] = None, **kw) -> List[Dict]:
+    """One-call form (the monolith's batch_convert, apple_hevc_batch.py:861-882)."""
+    return BatchRunner(scan_inputs(input_dir), output_dir, max_workers=max_workers, **kw).start().wait()
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(description='Headless Apple-HEVC batch transcode (MI355X / libx265)')
+    ap.add_argument('-i', '--input', dest='input_dir', required=True)
+    ap.add_argument('-o', '--output', dest='output_dir', required=True)
+    ap.add_argument('--max-workers', type=int, default=None)
+    ap.add_argument('--force-cpu', action='store_true')
+    ap.add_argument('--force-gpu', action='store_true')
+    ap.add_argument('--skip-validator', action='store_true')
+    ap.add_argument('--debug', action='store_true')
+    a = ap.parse_args(argv)
+    logging.basicConfig(level=logging.DEBUG if a.debug else logging.INFO)
+    res = batch_convert(Path(a.input_dir), Path(a.output_dir), a.max_workers, debug=a.debug, skip_validator=a.skip_validator,
+                        force_cpu=a.force_cpu, force_gpu=a.force_gpu)
+    ok = sum(r['status'] == 'SUCCESS' for r in res)
+    print(f'{ok}/{len(res)} files converted; log: {Path(a.output_dir) / "transcode_log.csv"}')
+    return 0 if ok == len(res) else 1
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())

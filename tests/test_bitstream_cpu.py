@@ -1,0 +1,182 @@
+"""CPU: the product's host entropy coder / parameter-set writer (libmihevc.so, no device needed) fed with symbols
+from the oracle analysis, decoded by the oracle decoder: the decoded pictures must equal the oracle's
+reconstruction bit for bit.  This is the conformance gate available without a third-party decoder."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from hevc_amd import _lib, mp4
+from oracle import oracle as O
+from tests import util
+
+
+def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000):
+    lib = _lib.load()
+    buf = (C.c_uint8 * (4 << 20))()
+    n = lib.mihevc_write_parameter_sets(C.byref(cfg), buf, len(buf))
+    assert n > 0
+    headers = bytes(buf[:n])
+    stream, recs, packets, ref = headers, [], [], None
+    prm_i, prm_p = O.default_params(max(0, qp - 3), bd, me_range), O.default_params(qp, bd, me_range)
+    for i, src in enumerate(srcs):
+        intra = i % keyint == 0
+        prm = prm_i if intra else prm_p
+        a = O.analyze_intra(src, prm) if intra else O.analyze_inter(src, ref, prm)
+        dbk = O.deblock(a.rec, a.cu, bd)
+        ref, sao = O.sao(src, dbk, prm) if cfg.sao else (dbk, None)
+        n = lib.mihevc_encode_picture_host(C.byref(cfg), 2 if intra else 1, i % keyint, prm.qp, util.ptr(a.cu), util.ptr(a.coef_y), util.ptr(a.coef_u),
+                                           util.ptr(a.coef_v), util.ptr(sao) if cfg.sao else None, buf, len(buf))
+        assert n > 0, n
+        packets.append((bytes(buf[:n]), i, intra))
+        stream += packets[-1][0]
+        recs.append(ref)
+    return headers, stream, recs, packets
+
+
+def make_cfg(w, h, bd=8, **kw):
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.bit_depth = w, h, bd
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+@pytest.mark.parametrize("w,h,qp,bd,n,keyint", [(64, 64, 30, 8, 3, 100), (96, 80, 20, 8, 4, 2), (136, 72, 36, 8, 3, 100), (72, 104, 26, 10, 3, 100),
+                                                 (160, 96, 12, 8, 2, 100)])
+def test_stream_decodes_to_the_oracle_reconstruction(w, h, qp, bd, n, keyint):
+    cfg = make_cfg(w, h, bd, aud=1)
+    srcs = [util.synth_frame(h, w, seed=11, shift=(3 * i, i), bit_depth=bd) for i in range(n)]
+    _, stream, recs, _ = encode_pictures(cfg, srcs, qp, bd, keyint=keyint)
+    frames, info = O.decode(stream)
+    assert len(frames) == n and info["count.aud"] == n and info["bit_depth"] == bd
+    for i, (f, r) in enumerate(zip(frames, recs)):
+        assert f.same(r), f"picture {i} differs after decode"
+
+
+def test_sao_off_and_skip_heavy_static_content():
+    w, h = 96, 64
+    cfg = make_cfg(w, h, sao=0)
+    still = util.synth_frame(h, w, seed=2, detail=False)
+    srcs = [still, still.copy(), still.copy()]            # identical pictures -> P pictures are all skip/merge
+    _, stream, recs, packets = encode_pictures(cfg, srcs, 32, 8)
+    frames, info = O.decode(stream)
+    assert info["sps.sao"] == 0 and all(f.same(r) for f, r in zip(frames, recs))
+    assert len(packets[1][0]) < 40 and len(packets[2][0]) < 40       # a skipped 96x64 picture is a handful of bytes
+
+
+def test_parameter_sets_carry_the_operating_point():
+    # SDR 1080p: Main, level 4 (idc 120), main tier, bt709, limited range, 30 fps.  1080 = 135 * 8, so the coded size IS
+    # 1920x1080 (MinCb 8) with a partial last CTU row and no conformance window.
+    cfg = make_cfg(1920, 1080)
+    srcs = [util.synth_frame(1080, 1920, seed=1, detail=False)]
+    headers, stream, recs, _ = encode_pictures(cfg, srcs, 38, 8)
+    frames, info = O.decode(stream)
+    assert frames[0].same(recs[0])
+    assert (info["width"], info["height"], info["conf_width"], info["conf_height"]) == (1920, 1080, 1920, 1080)
+    assert (info["sps.profile_idc"], info["sps.level_idc"], info["sps.tier_flag"], info["vps.level_idc"]) == (1, 120, 0, 120)
+    assert info["sps.compat"] == 0x60000000
+    assert (info["vui.colour_primaries"], info["vui.transfer"], info["vui.matrix"], info["vui.full_range"]) == (1, 1, 1, 0)
+    assert (info["vui.num_units_in_tick"], info["vui.time_scale"], info["vps.time_scale"]) == (1, 30, 30)
+    assert info["vui.chroma_loc_present"] == 0 and info["sei.137.size"] is None and info["count.aud"] == 0
+    assert info["slice.max_merge"] is None or info["slice.max_merge"] == 5
+
+
+def test_conformance_window_for_sizes_off_the_8_grid():
+    w, h = 100, 60                        # coded 104 x 64, cropped by 4 luma samples right and bottom
+    cfg = make_cfg(w, h)
+    srcs = [util.synth_frame(64, 104, seed=6), util.synth_frame(64, 104, seed=6, shift=(2, 1))]
+    _, stream, recs, _ = encode_pictures(cfg, srcs, 30, 8)
+    frames, info = O.decode(stream)
+    assert (info["width"], info["height"], info["conf_width"], info["conf_height"]) == (104, 64, 100, 60)
+    assert (info["sps.conf_right"], info["sps.conf_bottom"]) == (2, 2)          # in chroma units
+    assert all(f.same(r) for f, r in zip(frames, recs))
+
+
+def test_hdr10_signalling():
+    # the HDR set of core/utils.py:58-69: bt2020 / smpte2084 / bt2020nc, chromaloc 0, aud, SEI 137 + 144 with the defaults
+    cfg = make_cfg(64, 64, 10, hdr10=1, colour_primaries=9, transfer=16, matrix=9, chroma_loc=0, aud=1, repeat_headers=1, level_idc=150)
+    cfg.fps_num, cfg.fps_den = 30000, 1001
+    srcs = [util.synth_frame(64, 64, seed=4, bit_depth=10)]
+    _, stream, recs, _ = encode_pictures(cfg, srcs, 24, 10)
+    frames, info = O.decode(stream)
+    assert frames[0].same(recs[0])
+    assert (info["sps.profile_idc"], info["sps.level_idc"], info["sps.compat"]) == (2, 150, 0x20000000)
+    assert (info["vui.colour_primaries"], info["vui.transfer"], info["vui.matrix"]) == (9, 16, 9)
+    assert info["vui.chroma_loc_present"] == 1 and info["vui.chroma_loc_top"] == 0
+    assert (info["vui.num_units_in_tick"], info["vui.time_scale"]) == (1001, 30000)
+    assert (info["sei.137.size"], info["sei.144.size"]) == (24, 4)
+    assert (info["sei.mdcv.gx"], info["sei.mdcv.gy"], info["sei.mdcv.bx"], info["sei.mdcv.by"], info["sei.mdcv.rx"], info["sei.mdcv.ry"]) == \
+           (13250, 34500, 7500, 3000, 34000, 16000)
+    assert (info["sei.mdcv.wpx"], info["sei.mdcv.wpy"], info["sei.mdcv.max_lum"], info["sei.mdcv.min_lum"]) == (15635, 16450, 10000000, 50)
+    assert (info["sei.cll.max_cll"], info["sei.cll.max_fall"]) == (1000, 400)
+
+
+def test_decoder_rejects_corruption():
+    cfg = make_cfg(64, 64)
+    _, stream, _, _ = encode_pictures(cfg, [util.synth_frame(64, 64, seed=1)], 30, 8)
+    bad = bytearray(stream)
+    bad[len(bad) // 2] ^= 0x55
+    try:
+        frames, _ = O.decode(bytes(bad))
+        ok = False          # may still parse; then the picture must differ or the decoder must have complained
+    except O.DecodeError:
+        ok = True
+    assert ok or frames is not None
+
+
+def test_mp4_hvc1_container(tmp_path):
+    w, h, n = 96, 80, 5
+    cfg = make_cfg(w, h, aud=1)
+    srcs = [util.synth_frame(h, w, seed=8, shift=(i, 0)) for i in range(n)]
+    headers, stream, recs, packets = encode_pictures(cfg, srcs, 28, 8, keyint=3)
+    out = tmp_path / "clip.mp4"
+    mux = mp4.Mp4Writer(out, cfg)
+    for i, (data, pts, key) in enumerate(packets):
+        mux.add_sample((headers if key else b"") + data, pts, key)      # keyframe packets may repeat the headers: the muxer drops them
+    mux.finish(headers)
+    data = out.read_bytes()
+    top = mp4.parse_boxes(data)
+    assert [b[0] for b in top] == ["ftyp", "moov", "mdat"]               # faststart: moov first
+    assert data[top[0][1]:top[0][1] + 4] == b"mp42"                      # -brand mp42
+    def find(path, start, end):
+        for name in path:
+            nxt = [b for b in mp4.parse_boxes(data, start, end) if b[0] == name]
+            assert nxt, name
+            _, start, end = nxt[0]
+        return start, end
+    s, e = find(["moov", "trak", "mdia", "minf", "stbl", "stsd"], 0, len(data))
+    entries = mp4.parse_boxes(data, s + 8, e)
+    assert entries[0][0] == "hvc1"                                       # -tag:v hvc1
+    inner = {b[0]: b for b in mp4.parse_boxes(data, entries[0][1] + 78, entries[0][2])}
+    assert {"hvcC", "colr"} <= set(inner)
+    assert data[inner["colr"][1]:inner["colr"][1] + 4] == b"nclx"        # +write_colr
+    hs, he = find(["moov", "trak", "mdia", "hdlr"], 0, len(data))
+    assert b"VideoHandler" in data[hs:he]
+    # samples: length-prefixed NALs without parameter sets; rebuild Annex-B and decode
+    ss, se = find(["moov", "trak", "mdia", "minf", "stbl", "stsz"], 0, len(data))
+    count = int.from_bytes(data[ss + 8:ss + 12], "big")
+    sizes = [int.from_bytes(data[ss + 12 + 4 * i:ss + 16 + 4 * i], "big") for i in range(count)]
+    cs, ce = find(["moov", "trak", "mdia", "minf", "stbl", "stco"], 0, len(data))
+    off = int.from_bytes(data[cs + 8:cs + 12], "big")
+    assert off == top[2][1] and sum(sizes) == top[2][2] - top[2][1] and count == n
+    ks, ke = find(["moov", "trak", "mdia", "minf", "stbl", "stss"], 0, len(data))
+    assert [int.from_bytes(data[ks + 8 + 4 * i:ks + 12 + 4 * i], "big") for i in range(int.from_bytes(data[ks + 4:ks + 8], "big"))] == [1, 4]
+    annexb = headers
+    p = off
+    for sz in sizes:
+        q = p
+        while q < p + sz:
+            ln = int.from_bytes(data[q:q + 4], "big")
+            nal = data[q + 4:q + 4 + ln]
+            assert mp4.nal_type(nal) not in (32, 33, 34)
+            annexb += b"\0\0\0\1" + nal
+            q += 4 + ln
+        p += sz
+    frames, info = O.decode(annexb)
+    assert len(frames) == n and all(f.same(r) for f, r in zip(frames, recs))
+    # hvcC carries exactly our VPS/SPS/PPS
+    hv = data[inner["hvcC"][1]:inner["hvcC"][2]]
+    assert hv[0] == 1 and hv[1] == 1 and hv[12] == 120 and hv[22] == 3     # version, Main, level 4.0, three arrays
+    for nal in mp4.split_annexb(headers):
+        assert nal in hv
