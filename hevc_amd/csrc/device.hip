@@ -38,9 +38,9 @@ template <typename T> __global__ __launch_bounds__(NT) void k_inter_ctu(const In
     InterShared<T> &s = *reinterpret_cast<InterShared<T> *>(smem);
     size_t off = round16(sizeof(InterShared<T>));
     T *wy = reinterpret_cast<T *>(smem + off);
-    off += round16((size_t)mc_win_y(R) * mc_win_y_stride(R) * sizeof(T));
+    off += round16(((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16) * sizeof(T));
     T *wu = reinterpret_cast<T *>(smem + off);
-    off += round16((size_t)mc_win_c(R) * mc_win_c_stride(R) * sizeof(T));
+    off += round16(((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16) * sizeof(T));
     T *wv = reinterpret_cast<T *>(smem + off);
     GpuExec ex;
     inter_ctu_program<T>(ex, s, wy, wu, wv, a, ctu);
@@ -150,7 +150,7 @@ template <typename K> static hipError_t ensure_smem(K kernel, size_t bytes)
 
 template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
 {
-    size_t smem = round16(sizeof(MeShared<T>)) + (size_t)(32 + 2 * R) * me_win_stride(R) * sizeof(T);
+    size_t smem = round16(sizeof(MeShared<T>)) + round16((size_t)me_win_elems(R) * sizeof(T));
     hipError_t e = ensure_smem(k_me_search<T>, smem);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);
@@ -160,8 +160,8 @@ template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArg
 
 template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
 {
-    size_t smem = round16(sizeof(InterShared<T>)) + round16((size_t)mc_win_y(R) * mc_win_y_stride(R) * sizeof(T)) +
-                  2 * round16((size_t)mc_win_c(R) * mc_win_c_stride(R) * sizeof(T));
+    size_t smem = round16(sizeof(InterShared<T>)) + round16(((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16) * sizeof(T)) +
+                  2 * round16(((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16) * sizeof(T));
     hipError_t e = ensure_smem(k_inter_ctu<T>, smem);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);

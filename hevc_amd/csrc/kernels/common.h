@@ -175,6 +175,66 @@ DEV uint32_t sad_row8(const uint16_t *a, const uint16_t *b, uint32_t acc)
     return acc;
 }
 
+// v_qsad_pk_u16_u8: four SADs of 4 packed bytes `cur` against the 4-byte windows of `ref8` at byte offsets 0..3,
+// each accumulated into its own 16-bit field of `acc` (the instruction motion estimation was given on GCN/CDNA)
+DEV uint64_t qsad_u8(uint64_t ref8, uint32_t cur, uint64_t acc)
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_qsad_pk_u16_u8(ref8, cur, acc);
+#else
+    uint64_t out = 0;
+    for (int j = 0; j < 4; j++) {
+        uint32_t w = (uint32_t)(ref8 >> (8 * j)), a = (uint32_t)((acc >> (16 * j)) & 0xffff);
+        for (int i = 0; i < 4; i++) a += (uint32_t)iabs((int)((w >> (8 * i)) & 255) - (int)((cur >> (8 * i)) & 255));
+        out |= (uint64_t)(a & 0xffff) << (16 * j);
+    }
+    return out;
+#endif
+}
+DEV uint32_t align_bytes(uint32_t hi, uint32_t lo, int shift_bytes)     // ({hi,lo} >> 8*shift) & 0xffffffff, shift 0..3
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)shift_bytes);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * shift_bytes));
+#endif
+}
+DEV uint32_t load_u32_aligned(const void *p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, __builtin_assume_aligned(p, 4), 4);
+    return v;
+}
+// 15 consecutive samples base[idx .. idx+14] from an LDS image whose `base` is 4-byte aligned, fetched with aligned
+// dword reads + v_alignbyte (unaligned ds_read_b64 stalls: SQ_LDS_UNALIGNED_STALL, profiles/r01_a_first)
+DEV void load_row15(const uint8_t *base, int idx, int (&px)[15])
+{
+    const int off = idx & 3;
+    const uint8_t *p = base + (idx - off);
+    uint32_t d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = load_u32_aligned(p + 4 * k);
+    uint32_t r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = align_bytes(d[k + 1], d[k], off);
+#pragma unroll
+    for (int i = 0; i < 15; i++) px[i] = (int)((r[i >> 2] >> (8 * (i & 3))) & 255);
+}
+DEV void load_row15(const uint16_t *base, int idx, int (&px)[15])
+{
+    const int off = idx & 1;
+    const uint16_t *p = base + (idx - off);
+    uint32_t d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = load_u32_aligned(p + 2 * k);
+    uint32_t r[8];
+#pragma unroll
+    for (int k = 0; k < 7; k++) r[k] = align_bytes(d[k + 1], d[k], 2 * off);
+    r[7] = align_bytes(0, d[7], 2 * off);
+#pragma unroll
+    for (int i = 0; i < 15; i++) px[i] = (int)((r[i >> 1] >> (16 * (i & 1))) & 65535);
+}
+
 // in-place 8x8 Hadamard SATD of a difference block held in registers: (sum |H d H| + 2) >> 2
 DEV int hadamard8_satd(int (&m)[8][8])
 {

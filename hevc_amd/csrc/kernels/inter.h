@@ -37,12 +37,44 @@ template <typename T> struct MeShared {
     uint8_t valid[21];
     // followed in LDS by the search window: T win[(32 + 2R) * wstride]
 };
-HDI int me_win_stride(int R) { return 32 + 2 * R + 4; }    // +4 keeps rows 4-byte aligned for 8-bit samples
+HDI int me_spanx(int R) { return ((2 * R + 1) + 3) & ~3; }   // horizontal positions, rounded up to whole quads
+HDI int me_win_w(int R) { return 32 + me_spanx(R); }           // columns a quad's 8-byte windows can touch
+HDI int me_win_stride(int R) { return me_win_w(R) + 4; }       // rows stay 4-sample aligned
+HDI int me_win_elems(int R) { return (32 + 2 * R) * me_win_stride(R) + 16; }
+
+// SADs of the four 8x8 blocks of one block row (8 CTU rows x 32 samples) at the 4 horizontal positions of a quad.
+// src: CTU source rows (stride 32); ref: window at (row + dy, 4 * quad) — 4-byte aligned; out[block][position]
+DEV void quad_block_row(const uint8_t *src, const uint8_t *ref, int ws, unsigned (&out)[4][4])
+{
+    uint64_t acc[4] = {0, 0, 0, 0};
+    for (int r = 0; r < 8; r++) {
+        uint32_t rr[9], cc[8];
+#pragma unroll
+        for (int d = 0; d < 9; d++) rr[d] = load_u32_aligned(ref + r * ws + 4 * d);
+#pragma unroll
+        for (int d = 0; d < 8; d++) cc[d] = load_u32_aligned(src + r * 32 + 4 * d);
+#pragma unroll
+        for (int d = 0; d < 8; d++) acc[d >> 1] = qsad_u8(((uint64_t)rr[d + 1] << 32) | rr[d], cc[d], acc[d >> 1]);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[b][j] = (unsigned)((acc[b] >> (16 * j)) & 0xffff);
+}
+DEV void quad_block_row(const uint16_t *src, const uint16_t *ref, int ws, unsigned (&out)[4][4])
+{
+    for (int b = 0; b < 4; b++)
+        for (int j = 0; j < 4; j++) {
+            unsigned a = 0;
+            for (int r = 0; r < 8; r++) a = sad_row8(src + r * 32 + 8 * b, ref + r * ws + 8 * b + j, a);
+            out[b][j] = a;
+        }
+}
 
 template <typename T, class Ex>
 DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a, int ctu)
 {
-    const int R = a.prm.me_range, span = 2 * R + 1, ws = me_win_stride(R), wn = 32 + 2 * R;
+    const int R = a.prm.me_range, spany = 2 * R + 1, spanx = me_spanx(R), quads = spanx >> 2, ws = me_win_stride(R), ww = me_win_w(R), wh = 32 + 2 * R;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
     const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
     ex.phase([&](int tid) {
@@ -50,8 +82,8 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
             int x = x0 + (i & 31), y = y0 + (i >> 5);
             s.src[i] = (x < a.w && y < a.h) ? a.src[0].p[(size_t)y * a.src[0].stride + x] : (T)0;
         }
-        for (int i = tid; i < wn * wn; i += NT) {
-            int wx = i % wn, wy = i / wn;
+        for (int i = tid; i < ww * wh; i += NT) {
+            int wx = i % ww, wy = i / ww;
             int x = clip3(-PAD_Y, a.w + PAD_Y - 1, x0 + sx - R + wx), y = clip3(-PAD_Y, a.h + PAD_Y - 1, y0 + sy - R + wy);
             win[wy * ws + wx] = a.ref[0].p[(ptrdiff_t)y * a.ref[0].stride + x];
         }
@@ -65,34 +97,41 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
     ex.phase([&](int tid) {
         unsigned long long best[21];
         for (int n = 0; n < 21; n++) best[n] = ~0ull;
-        for (int p = tid; p < span * span; p += NT) {
-            int dx = p % span - R, dy = p / span - R;
-            unsigned sad8[16];
-            for (int b = 0; b < 16; b++) {           // b in z-order: node 5 + b
-                sad8[b] = 0;
-                if (!s.valid[5 + b]) continue;
-                int bx, by, bl;
-                node_geom(5 + b, bx, by, bl);
-                const T *sp = s.src + by * 32 + bx;
-                const T *rp = win + (by + dy + R) * ws + bx + dx + R;
-                unsigned acc = 0;
-                for (int r = 0; r < 8; r++) acc = sad_row8(sp + r * 32, rp + r * ws, acc);
-                sad8[b] = acc;
-            }
-            unsigned bits = (unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * dx) + mvd_bits(4 * dy)));
-            unsigned s32 = 0;
-            for (int q = 0; q < 4; q++) {
-                unsigned s16 = sad8[4 * q] + sad8[4 * q + 1] + sad8[4 * q + 2] + sad8[4 * q + 3];
-                s32 += s16;
-                unsigned long long k16 = ((unsigned long long)((s16 << 4) + bits) << 16) | (unsigned)p;
-                if (k16 < best[1 + q]) best[1 + q] = k16;
-                for (int t = 0; t < 4; t++) {
-                    unsigned long long k8 = ((unsigned long long)((sad8[4 * q + t] << 4) + bits) << 16) | (unsigned)p;
-                    if (k8 < best[5 + 4 * q + t]) best[5 + 4 * q + t] = k8;
+        for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
+            const int q = item % quads, dyi = item / quads;
+            unsigned sad8[16][4];                                         // [z-order block][position in quad]
+            for (int br = 0; br < 4; br++) {
+                unsigned o[4][4];
+                quad_block_row(s.src + br * 8 * 32, win + (br * 8 + dyi) * ws + 4 * q, ws, o);
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const int z = ((br >> 1) * 2 + (b >> 1)) * 4 + (br & 1) * 2 + (b & 1);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) sad8[z][j] = o[b][j];
                 }
             }
-            unsigned long long k32 = ((unsigned long long)((s32 << 4) + bits) << 16) | (unsigned)p;
-            if (k32 < best[0]) best[0] = k32;
+            const int by = mvd_bits(4 * (dyi - R));
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int dx = 4 * q + j - R;
+                const unsigned p = (unsigned)(dyi * spanx + 4 * q + j);
+                const unsigned bits = (unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * dx) + by));
+                unsigned s32 = 0;
+#pragma unroll
+                for (int qd = 0; qd < 4; qd++) {
+                    unsigned s16 = sad8[4 * qd][j] + sad8[4 * qd + 1][j] + sad8[4 * qd + 2][j] + sad8[4 * qd + 3][j];
+                    s32 += s16;
+                    unsigned long long k16 = ((unsigned long long)((s16 << 4) + bits) << 16) | p;
+                    if (k16 < best[1 + qd]) best[1 + qd] = k16;
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        unsigned long long k8 = ((unsigned long long)((sad8[4 * qd + t][j] << 4) + bits) << 16) | p;
+                        if (k8 < best[5 + 4 * qd + t]) best[5 + 4 * qd + t] = k8;
+                    }
+                }
+                unsigned long long k32 = ((unsigned long long)((s32 << 4) + bits) << 16) | p;
+                if (k32 < best[0]) best[0] = k32;
+            }
         }
         for (int n = 0; n < 21; n++)
             if (s.valid[n] && best[n] != ~0ull) ex.atomic_min(&s.best[n], best[n]);
@@ -102,7 +141,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
             int32_t *o = a.me + ((size_t)ctu * 21 + tid) * 3;
             if (s.valid[tid]) {
                 int p = (int)(s.best[tid] & 0xffff);
-                o[0] = 4 * (sx + p % span - R); o[1] = 4 * (sy + p / span - R); o[2] = (int32_t)(s.best[tid] >> 16);
+                o[0] = 4 * (sx + p % spanx - R); o[1] = 4 * (sy + p / spanx - R); o[2] = (int32_t)(s.best[tid] >> 16);
             } else { o[0] = 0; o[1] = 0; o[2] = -1; }
         }
     });
@@ -117,20 +156,22 @@ template <typename T> struct InterShared {
     unsigned cost[21];           // current best cost of each node (SATD << 4 + lambda * mvd bits)
     uint8_t valid[21];
     int satd[3][9][16];          // [level][candidate][tile]
+    uint8_t alias[3][16];        // level whose SATDs stand for (level, tile): a coarser node with the SAME vector as a finer one is not recomputed
     int tile_mvx[16], tile_mvy[16];
     uint8_t tile_node[16];
     // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
 };
-HDI int mc_win_y(int R) { return 32 + 2 * R + 8; }
+// motion-compensation windows cover every vector the search can return: |mv| <= R + 3 (widened horizontal span)
+HDI int mc_win_y(int R) { return 32 + 2 * (R + 3) + 8; }
 HDI int mc_win_y_stride(int R) { return mc_win_y(R) + 4; }
-HDI int mc_win_c(int R) { return 16 + R + 8; }
+HDI int mc_win_c(int R) { return 16 + (R + 3) + 8; }
 HDI int mc_win_c_stride(int R) { return mc_win_c(R) + 4; }
 
 // quarter-sample luma prediction of one 8x8 tile from the LDS window (8.5.3.3.3.1; the general 2-D form with the
 // {0,0,0,64,0,0,0,0} tap set for a zero fraction is exact for every case).  p00 = window sample at the tile's
-// integer position.  When diff_src != nullptr returns the 8x8 Hadamard SATD of (src - pred), else writes pred.
+// integer position (element index i00 into the 4-byte aligned window image `win`).  When diff_src != nullptr returns the 8x8 Hadamard SATD of (src - pred), else writes pred.
 template <typename T>
-DEV int luma_tile(const T *p00, int ws, int fx, int fy, int bit_depth, const T *diff_src, int src_stride, T *pred_out, int pred_stride)
+DEV int luma_tile(const T *win, int i00, int ws, int fx, int fy, int bit_depth, const T *diff_src, int src_stride, T *pred_out, int pred_stride)
 {
     const int8_t *tx = g_tab.luma_tap[fx], *ty = g_tab.luma_tap[fy];
     const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
@@ -140,10 +181,8 @@ DEV int luma_tile(const T *p00, int ws, int fx, int fy, int bit_depth, const T *
 #pragma unroll
         for (int i = 0; i < 8; i++) acc[j][i] = 0;
     for (int r = 0; r < 15; r++) {                 // intermediate row r corresponds to reference row r - 3
-        const T *row = p00 + (r - 3) * ws - 3;
         int px[15];
-#pragma unroll
-        for (int i = 0; i < 15; i++) px[i] = row[i];
+        load_row15(win, i00 + (r - 3) * ws - 3, px);
         int hv[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) {
@@ -191,10 +230,10 @@ DEV int chroma_sample(const T *p00, int ws, int fx, int fy, int bit_depth)
 template <typename T, class Ex>
 DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win_v, const InterArgs<T> &a, int ctu)
 {
-    const int R = a.prm.me_range, bd = a.prm.bit_depth, lam = a.prm.lambda_sad_q4;
+    const int R0 = a.prm.me_range, R = R0 + 3, bd = a.prm.bit_depth, lam = a.prm.lambda_sad_q4;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
     const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
-    const int wy = mc_win_y(R), wys = mc_win_y_stride(R), wc = mc_win_c(R), wcs = mc_win_c_stride(R);
+    const int wy = mc_win_y(R0), wys = mc_win_y_stride(R0), wc = mc_win_c(R0), wcs = mc_win_c_stride(R0);
     const int oy_x = x0 + sx - R - 4, oy_y = y0 + sy - R - 4;                                  // luma window origin
     const int oc_x = (x0 >> 1) + ((4 * sx - 4 * R - 3) >> 3) - 1, oc_y = (y0 >> 1) + ((4 * sy - 4 * R - 3) >> 3) - 1;
 
@@ -230,9 +269,17 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                 if (k < k0) continue;
                 int txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
                 if (!s.valid[node]) continue;
+                // identical vectors give identical tile SATDs: let the finest level that shares the vector do the work
+                int al = level;
+                for (int fl = 2; fl > level; fl--) {
+                    int fn = node_of_tile(fl, txp, typ);
+                    if (s.valid[fn] && s.mvx[fn] == s.mvx[node] && s.mvy[fn] == s.mvy[node]) { al = fl; break; }
+                }
+                if (k == k0) s.alias[level][t] = (uint8_t)al;
+                if (al != level) continue;
                 int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
                 int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                s.satd[level][k][t] = luma_tile<T>(win_y + py * wys + px, wys, mx & 3, my & 3, bd, s.src + typ * 8 * 32 + txp * 8, 32, nullptr, 0);
+                s.satd[level][k][t] = luma_tile<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, s.src + typ * 8 * 32 + txp * 8, 32, nullptr, 0);
             }
         });
         ex.phase([&](int tid) {
@@ -244,7 +291,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             for (int k = k0; k < 9; k++) {
                 unsigned satd = 0;
                 for (int j = 0; j < tiles; j++)
-                    for (int i = 0; i < tiles; i++) satd += (unsigned)s.satd[level][k][((ny >> 3) + j) * 4 + (nx >> 3) + i];
+                    for (int i = 0; i < tiles; i++) { int t = ((ny >> 3) + j) * 4 + (nx >> 3) + i; satd += (unsigned)s.satd[s.alias[level][t]][k][t]; }
                 int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
                 unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
                 unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
@@ -288,7 +335,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             if (s.rs.tu_log2[t]) {
                 int mx = s.tile_mvx[t], my = s.tile_mvy[t];
                 int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                luma_tile<T>(win_y + py * wys + px, wys, mx & 3, my & 3, bd, nullptr, 0, s.pred + typ * 8 * 32 + txp * 8, 32);
+                luma_tile<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, nullptr, 0, s.pred + typ * 8 * 32 + txp * 8, 32);
             }
         } else if (tid >= 64) {
             for (int i = tid - 64; i < 512; i += NT - 64) {

@@ -81,6 +81,74 @@ template <typename T> DEV int intra_sample(const T *L, int log2n, int mode, int 
     return f ? ((32 - f) * v0 + f * r(b + idx + 2) + 16) >> 5 : v0;
 }
 
+// difference (source - prediction) of one 8x8 tile of an NxN luma block for `mode`: the same arithmetic as
+// intra_sample, with everything that depends only on the mode / row hoisted out of the sample loop (the SATD mode
+// search runs 35 x (N/8)^2 of these per CU and dominated k_intra_diag: profiles/r01_a_first)
+template <typename T>
+DEV void intra_tile_diff(const T *L, int log2n, int mode, int tx, int ty, int bit_depth, int dc, const T *src, int src_stride, int (&m)[8][8])
+{
+    const int n = 1 << log2n;
+    if (mode == 0) {
+        const int tr = ref_top(L, n, n), bl = ref_left(L, n, n);
+        int top[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) top[i] = ref_top(L, n, tx + i);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int y = ty + j, lf = ref_left(L, n, y);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int x = tx + i;
+                m[j][i] = (int)src[j * src_stride + i] - (((n - 1 - x) * lf + (x + 1) * tr + (n - 1 - y) * top[i] + (y + 1) * bl + n) >> (log2n + 1));
+            }
+        }
+        return;
+    }
+    if (mode == 1) {
+        const bool edge = n < 32;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int x = tx + i, y = ty + j;
+                int v = dc;
+                if (edge && (x == 0 || y == 0)) {
+                    if (x == 0 && y == 0) v = (ref_left(L, n, 0) + 2 * dc + ref_top(L, n, 0) + 2) >> 2;
+                    else if (y == 0) v = (ref_top(L, n, x) + 3 * dc + 2) >> 2;
+                    else v = (ref_left(L, n, y) + 3 * dc + 2) >> 2;
+                }
+                m[j][i] = (int)src[j * src_stride + i] - v;
+            }
+        return;
+    }
+    const int angle = g_tab.intra_angle[mode], vertical = mode >= 18, inv = angle < 0 ? g_tab.inv_angle[mode - 11] : 0;
+    const int a0 = vertical ? ty : tx, b0 = vertical ? tx : ty;
+    const int maxv = (1 << bit_depth) - 1;
+#pragma unroll
+    for (int ai = 0; ai < 8; ai++) {                 // along the prediction direction
+        const int a = a0 + ai, idx = ((a + 1) * angle) >> 5, f = ((a + 1) * angle) & 31;
+        int r[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            const int i = b0 + e + idx + 1;
+            if (i >= 0) r[e] = vertical ? L[2 * n + i] : L[2 * n - i];
+            else { const int k = -1 + ((i * inv + 128) >> 8); r[e] = vertical ? L[2 * n - 1 - k] : L[2 * n + 1 + k]; }
+            if (e == 8 && !f) r[e] = 0;              // never read when the fraction is zero (may lie past the array)
+        }
+#pragma unroll
+        for (int bi = 0; bi < 8; bi++) {
+            int v = f ? ((32 - f) * r[bi] + f * r[bi + 1] + 16) >> 5 : r[bi];
+            if (angle == 0 && n < 32 && b0 + bi == 0) {
+                const int corner = L[2 * n];
+                v = vertical ? ref_top(L, n, 0) + ((ref_left(L, n, a) - corner) >> 1) : ref_left(L, n, 0) + ((ref_top(L, n, a) - corner) >> 1);
+                v = clip3(0, maxv, v);
+            }
+            if (vertical) m[ai][bi] = (int)src[ai * src_stride + bi] - v;
+            else m[bi][ai] = (int)src[bi * src_stride + ai] - v;
+        }
+    }
+}
+
 DEV bool intra_filter_on(int log2n, int mode)
 {
     if (mode == 1 || log2n == 2) return false;
@@ -166,9 +234,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             int mode = u / ntile, t = u % ntile, tx = (t % tiles) * 8, ty = (t / tiles) * 8;
             const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
             int m[8][8];
-            for (int j = 0; j < 8; j++)
-                for (int i = 0; i < 8; i++)
-                    m[j][i] = (int)s.src[(cy + ty + j) * 32 + cx + tx + i] - intra_sample<T>(L, log2n, mode, tx + i, ty + j, 0, bd, s.dc_val[0]);
+            intra_tile_diff<T>(L, log2n, mode, tx, ty, bd, s.dc_val[0], s.src + (cy + ty) * 32 + cx + tx, 32, m);
             s.satd[mode][t] = hadamard8_satd(m);
         }
     });

@@ -3,7 +3,7 @@
  * Scalar restatement of the per-CTU encode loop the reference obtains from libx265
  * (reference call sites: core/transcoder.py:398-412 operating point, :463 `-c:v`, :506 spawn).
  * Normative parts cite their H.265 clause; encoder-side choices are defined here and mirrored by
- * hevc_amd/csrc/kernels/*.hip.  PARITY UNPINNED vs libx265 (no golden vectors exist; see header).
+ * hevc_amd/csrc/kernels/ (HIP).  PARITY UNPINNED vs libx265 (no golden vectors exist; see header).
  */
 #include "hevc_oracle.h"
 #include <stdlib.h>
@@ -480,9 +480,11 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                              pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
                              orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump)
 {
-    const int R = prm->me_range, span = 2 * R + 1, bd = prm->bit_depth, lam = prm->lambda_sad_q4;
+    /* search domain: dy in [-R, R]; dx in [-R, -R + spanx - 1] with spanx = 2R+1 rounded UP to a multiple of 4 (the
+     * device evaluates four horizontal positions per v_qsad_pk_u16_u8, so the row is widened instead of masked) */
+    const int R = prm->me_range, spany = 2 * R + 1, spanx = (spany + 3) & ~3, bd = prm->bit_depth, lam = prm->lambda_sad_q4;
     const int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU, w8 = w >> 3;
-    uint32_t *sad8 = (uint32_t *)malloc(sizeof(uint32_t) * 16 * span * span);
+    uint32_t *sad8 = (uint32_t *)malloc(sizeof(uint32_t) * 16 * spanx * spany);
     for (int cy = 0; cy < hc; cy++)
         for (int cx = 0; cx < wc; cx++) {
             int ctu = cy * wc + cx, x0 = cx * ORC_CTU, y0 = cy * ORC_CTU;
@@ -497,8 +499,8 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                 int nd = 5 + b;
                 if (!valid[nd]) continue;
                 for (int dy = -R; dy <= R; dy++)
-                    for (int dx = -R; dx <= R; dx++)
-                        sad8[(b * span + dy + R) * span + dx + R] = (uint32_t)orc_sad(
+                    for (int dx = -R; dx < -R + spanx; dx++)
+                        sad8[(b * spany + dy + R) * spanx + dx + R] = (uint32_t)orc_sad(
                             src_y + (y0 + ny[nd]) * src_stride + x0 + nx[nd], src_stride,
                             ref_y + (y0 + ny[nd] + sy + dy) * ref_stride + x0 + nx[nd] + sx + dx, ref_stride, 8, 8);
             }
@@ -509,18 +511,18 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                 if (!valid[nd]) continue;
                 uint64_t best = ~0ull;
                 for (int dy = -R; dy <= R; dy++)
-                    for (int dx = -R; dx <= R; dx++) {
+                    for (int dx = -R; dx < -R + spanx; dx++) {
                         uint32_t s = 0;
-                        int p = (dy + R) * span + dx + R;
-                        if (nd == 0) for (int b = 0; b < 16; b++) s += sad8[b * span * span + p];
-                        else if (nd < 5) for (int b = 0; b < 4; b++) s += sad8[((nd - 1) * 4 + b) * span * span + p];
-                        else s = sad8[(nd - 5) * span * span + p];
+                        int p = (dy + R) * spanx + dx + R;
+                        if (nd == 0) for (int b = 0; b < 16; b++) s += sad8[b * spanx * spany + p];
+                        else if (nd < 5) for (int b = 0; b < 4; b++) s += sad8[((nd - 1) * 4 + b) * spanx * spany + p];
+                        else s = sad8[(nd - 5) * spanx * spany + p];
                         uint32_t c = (s << 4) + (uint32_t)(lam * (orc_mvd_bits(4 * dx) + orc_mvd_bits(4 * dy)));
                         uint64_t key = ((uint64_t)c << 16) | (uint32_t)p;
                         if (key < best) best = key;
                     }
                 int p = (int)(best & 0xffff);
-                mvx[nd] = 4 * (sx + p % span - R); mvy[nd] = 4 * (sy + p / span - R);
+                mvx[nd] = 4 * (sx + p % spanx - R); mvy[nd] = 4 * (sy + p / spanx - R);
                 cost[nd] = (uint32_t)(best >> 16);
             }
             if (me_dump)

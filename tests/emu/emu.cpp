@@ -57,8 +57,8 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     std::vector<int32_t> me((size_t)n_ctu * 63);
     a.me = me.data();
     SeqExec ex;
-    std::vector<T> win((size_t)(32 + 2 * R) * me_win_stride(R));
-    std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R)), wu((size_t)mc_win_c(R) * mc_win_c_stride(R)), wv(wu.size());
+    std::vector<T> win((size_t)me_win_elems(R) + 8);
+    std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16), wu((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16), wv(wu.size());
     for (int c = 0; c < n_ctu; c++) {
         MeShared<T> *ms = new MeShared<T>();
         me_search_program<T>(ex, *ms, win.data(), a, c);
