@@ -51,7 +51,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--frames", type=int, default=300)
-    ap.add_argument("--me-range", type=int, default=16)
+    ap.add_argument("--me-range", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

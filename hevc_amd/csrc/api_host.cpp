@@ -54,7 +54,7 @@ void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_
     out->bit_depth = bit_depth;
     out->lambda_sad_q4 = (int)std::lround(16.0 * std::sqrt(lam));
     out->lambda_q4 = (int)std::lround(16.0 * lam);
-    out->me_range = me_range > 0 ? me_range : 16;
+    out->me_range = me_range > 0 ? me_range : 15;
 }
 
 static int copy_out(const std::vector<uint8_t> &v, uint8_t *buf, size_t cap)

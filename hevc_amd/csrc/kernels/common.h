@@ -199,6 +199,15 @@ DEV uint32_t align_bytes(uint32_t hi, uint32_t lo, int shift_bytes)     // ({hi,
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * shift_bytes));
 #endif
 }
+// returns 0 in a way the optimiser cannot see through: stops loop-invariant hoisting of whole LDS tiles into VGPRs
+DEV int opaque_zero()
+{
+    int z = 0;
+#if MIHEVC_GPU
+    asm volatile("" : "+v"(z));
+#endif
+    return z;
+}
 DEV uint32_t load_u32_aligned(const void *p)
 {
     uint32_t v;

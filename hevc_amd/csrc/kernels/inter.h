@@ -95,46 +95,63 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
         }
     });
     ex.phase([&](int tid) {
-        unsigned long long best[21];
-        for (int n = 0; n < 21; n++) best[n] = ~0ull;
+        // a node's candidate goes straight to the workgroup's LDS minimum (filtered by a plain read first), so no
+        // per-thread table of 21 running minima has to stay in registers across the unrolled SAD code
+        auto consider = [&](int node, unsigned cost, unsigned p) {
+            unsigned long long key = ((unsigned long long)cost << 16) | p;
+            if (s.valid[node] && key < s.best[node]) ex.atomic_min(&s.best[node], key);
+        };
         for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
             const int q = item % quads, dyi = item / quads;
-            unsigned sad8[16][4];                                         // [z-order block][position in quad]
-            for (int br = 0; br < 4; br++) {
-                unsigned o[4][4];
-                quad_block_row(s.src + br * 8 * 32, win + (br * 8 + dyi) * ws + 4 * q, ws, o);
-#pragma unroll
-                for (int b = 0; b < 4; b++) {
-                    const int z = ((br >> 1) * 2 + (b >> 1)) * 4 + (br & 1) * 2 + (b & 1);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) sad8[z][j] = o[b][j];
-                }
-            }
             const int by = mvd_bits(4 * (dyi - R));
+            const T *srcp = s.src + opaque_zero();      // keep the 1 KiB source tile in LDS (hoisted into 256 VGPRs otherwise)
+            unsigned bits[4], pos[4], s32[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int dx = 4 * q + j - R;
-                const unsigned p = (unsigned)(dyi * spanx + 4 * q + j);
-                const unsigned bits = (unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * dx) + by));
-                unsigned s32 = 0;
+                pos[j] = (unsigned)(dyi * spanx + 4 * q + j);
+                bits[j] = (unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * (4 * q + j - R)) + by));
+            }
 #pragma unroll
-                for (int qd = 0; qd < 4; qd++) {
-                    unsigned s16 = sad8[4 * qd][j] + sad8[4 * qd + 1][j] + sad8[4 * qd + 2][j] + sad8[4 * qd + 3][j];
-                    s32 += s16;
-                    unsigned long long k16 = ((unsigned long long)((s16 << 4) + bits) << 16) | p;
-                    if (k16 < best[1 + qd]) best[1 + qd] = k16;
+            for (int half = 0; half < 2; half++) {
+                unsigned s16[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        unsigned long long k8 = ((unsigned long long)((sad8[4 * qd + t][j] << 4) + bits) << 16) | p;
-                        if (k8 < best[5 + 4 * qd + t]) best[5 + 4 * qd + t] = k8;
+                for (int r2 = 0; r2 < 2; r2++) {
+                    const int br = half * 2 + r2;
+                    unsigned o[4][4];
+                    quad_block_row(srcp + br * 8 * 32, win + (br * 8 + dyi) * ws + 4 * q, ws, o);
+#pragma unroll
+                    for (int b = 0; b < 4; b++) {
+                        const int node = 5 + (half * 2 + (b >> 1)) * 4 + r2 * 2 + (b & 1);
+                        unsigned long long k = ~0ull;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            s16[b >> 1][j] += o[b][j];
+                            unsigned long long kj = ((unsigned long long)((o[b][j] << 4) + bits[j]) << 16) | pos[j];
+                            k = kj < k ? kj : k;
+                        }
+                        consider(node, (unsigned)(k >> 16), (unsigned)(k & 0xffff));
                     }
                 }
-                unsigned long long k32 = ((unsigned long long)((s32 << 4) + bits) << 16) | p;
-                if (k32 < best[0]) best[0] = k32;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {
+                    unsigned long long k = ~0ull;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        s32[j] += s16[h2][j];
+                        unsigned long long kj = ((unsigned long long)((s16[h2][j] << 4) + bits[j]) << 16) | pos[j];
+                        k = kj < k ? kj : k;
+                    }
+                    consider(1 + half * 2 + h2, (unsigned)(k >> 16), (unsigned)(k & 0xffff));
+                }
             }
+            unsigned long long k = ~0ull;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                unsigned long long kj = ((unsigned long long)((s32[j] << 4) + bits[j]) << 16) | pos[j];
+                k = kj < k ? kj : k;
+            }
+            consider(0, (unsigned)(k >> 16), (unsigned)(k & 0xffff));
         }
-        for (int n = 0; n < 21; n++)
-            if (s.valid[n] && best[n] != ~0ull) ex.atomic_min(&s.best[n], best[n]);
     });
     ex.phase([&](int tid) {
         if (tid < 21) {

@@ -438,7 +438,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->is16 = cfg->bit_depth > 8;
     s->keyint = cfg->keyint;
     s->lanes = cfg->gops_in_flight > 0 ? std::min(cfg->gops_in_flight, 16) : 4;
-    s->me_range = cfg->me_range > 0 ? std::min(cfg->me_range, MAX_RANGE) : 16;
+    s->me_range = cfg->me_range > 0 ? std::min(cfg->me_range, MAX_RANGE) : 15;   // 8 quads x 31 rows = 248 items: one pass of the 256-thread search
     // constant-quality operating point: P pictures at crf + 2, IDR pictures 3 below (x265's ipratio 1.4 ~ 3 QP)
     s->qp_p = cfg->qp >= 0 ? cfg->qp : std::min(51, std::max(0, cfg->crf + 2));
     s->qp_i = std::max(0, s->qp_p - 3);

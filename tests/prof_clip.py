@@ -9,7 +9,7 @@ from hevc_amd.yuvio import SyntheticClip        # noqa: E402
 
 n, keyint = int(sys.argv[1]) if len(sys.argv) > 1 else 24, int(sys.argv[2]) if len(sys.argv) > 2 else 12
 cfg = _lib.default_config()
-cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.me_range, cfg.profile_stages = keyint, 2, 4, 16, 1
+cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.me_range, cfg.profile_stages = keyint, 2, 4, 15, 1
 clip = SyntheticClip("motion", 0, 1920, 1080, n)
 with Encoder(cfg) as enc:
     nb = 0
