@@ -89,19 +89,30 @@ def main():
         vs.append(torch.from_numpy(v).cuda())
     torch.cuda.synchronize()
 
+    phase_s = np.zeros(4)       # open, send, flush+drain, close
+
     def step():
-        with Encoder(cfg, device=local) as enc:
+        t0 = time.perf_counter()
+        enc = Encoder(cfg, device=local)
+        t1 = time.perf_counter()
+        try:
             nbytes = 0
             for i in range(N):
                 enc.send_device(ys[i].data_ptr(), us[i].data_ptr(), vs[i].data_ptr(), W, W // 2, pts=i)
                 for data, _pts, _key in enc.packets():
                     nbytes += len(data)
+            t2 = time.perf_counter()
             enc.flush()
-            n_out = 0
             for data, _pts, _key in enc.packets():
                 nbytes += len(data)
+            t3 = time.perf_counter()
             st = enc.stats()
-            return st, nbytes, enc.psnr_y()
+            psnr = enc.psnr_y()
+        finally:
+            enc.close()
+        t4 = time.perf_counter()
+        phase_s[:] += (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
+        return st, nbytes, psnr
 
     def barrier():
         if dist is not None:
@@ -110,6 +121,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    phase_s[:] = 0
     barrier()
     t0 = time.perf_counter()
     stage_ms = np.zeros(8)
@@ -152,7 +164,9 @@ def main():
             "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1),
                         "libx265_parity": "unavailable: no ffmpeg/libx265 on this host"},
             "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(stage_ms[i] / max(1.0, stage_pics[i]), 4) for i in range(7)},
-            "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count()},
+            "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count(),
+                     "step_phases_ms": dict(zip(("open", "send", "flush_drain", "close"), [round(x / args.steps * 1e3, 2) for x in phase_s])),
+                     "device_ms_per_step": round(st.device_ms, 2)},
             "roofline": {"bound": "hbm", "kernel": _lib.STAGE_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                          "avg_launch_ms": round(avg_ms, 4), "pictures_per_launch": round(stage_pics[dom] / launches, 2),

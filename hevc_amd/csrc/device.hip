@@ -273,7 +273,7 @@ __global__ __launch_bounds__(NT) void k_transform_blocks(const int16_t *res, int
             if (blk < n_blocks) s.res[i] = res[(size_t)blk * n * n + (y & (n - 1)) * n + (x & (n - 1))];
         }
     });
-    residual_pipeline(ex, s, qp, qp, bit_depth);
+    residual_pipeline(ex, s, qp, qp, bit_depth, whole_ctu());
     ex.phase([&](int tid) {
         for (int i = tid; i < 1024; i += NT) {
             int x = i & 31, y = i >> 5, blk = first + (y >> log2n) * (32 >> log2n) + (x >> log2n);

@@ -367,7 +367,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     ex.phase([&](int tid) {
         for (int i = tid; i < 1536; i += NT) s.rs.res[i] = (int16_t)((int)s.src[i] - (int)s.pred[i]);
     });
-    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd);
+    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, whole_ctu());
     // reconstruction + outputs
     ex.phase([&](int tid) {
         const int maxv = (1 << bd) - 1;

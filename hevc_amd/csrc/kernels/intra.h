@@ -39,8 +39,10 @@ template <typename T> struct IntraShared {
     T ref_raw[3][132], ref[3][132], filt[132];   // [plane]: 4N+1 reference samples (raw, substituted); filtered luma
     uint8_t avail[3][132];
     int satd[35][16];
-    unsigned mode_cost[35];
-    int cand[3], best_mode, dc_val[3];
+    int16_t hrow[35][64];        // 8x8 CUs: horizontally transformed difference rows of every mode (row-split SATD)
+    int satd8[35];               // 8x8 CUs: sum |H d H| per mode (before the (s+2)>>2 normalisation)
+    unsigned long long mode_key;  // min over modes of (cost << 6 | mode)
+    int cand[3], dc_val[3];
     unsigned sse;
     int bits[3];
     unsigned long long j_cu;
@@ -160,6 +162,8 @@ template <typename T, class Ex>
 DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int y0, int cx, int cy, int log2n)
 {
     const int n = 1 << log2n, bd = a.prm.bit_depth, tiles = n >> 3, ntile = tiles * tiles;
+    const Region rg{cx, cy, log2n};
+    const int rcnt = rg.count();
     const int gx = x0 + cx, gy = y0 + cy;        // picture coordinates of the CU
     // reference samples: availability + raw values for the three planes
     ex.phase([&](int tid) {
@@ -193,6 +197,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
                 s.cand[2] = (ma != 0 && mb != 0) ? 0 : (ma != 1 && mb != 1) ? 1 : 26;
             }
             s.sse = 0; s.bits[0] = s.bits[1] = s.bits[2] = 0;
+            s.mode_key = ~0ull;
         }
     });
     // substitution (8.4.4.2.2): nearest available sample at a lower index, else the first available above
@@ -229,6 +234,45 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         }
     });
     // 35 modes x 8x8 tiles: prediction and SATD against the source
+    if (log2n == 3) {
+        // an 8x8 CU has one tile per mode: 35 busy lanes would leave the workgroup idle while this CU blocks the rest of
+        // the CTU.  Split every tile by rows: 280 lanes each predict one row and transform it horizontally, then
+        // 280 lanes each finish one column (the 2-D Hadamard is separable, so the sum is unchanged).
+        ex.phase([&](int tid) {
+            for (int u = tid; u < 35 * 8; u += NT) {
+                const int mode = u >> 3, y = u & 7;
+                const T *L = intra_filter_on(3, mode) ? s.filt : s.ref[0];
+                int d[8];
+#pragma unroll
+                for (int x = 0; x < 8; x++) d[x] = (int)s.src[(cy + y) * 32 + cx + x] - intra_sample<T>(L, 3, mode, x, y, 0, bd, s.dc_val[0]);
+#pragma unroll
+                for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (!(i & st)) { int p = d[i], q = d[i + st]; d[i] = p + q; d[i + st] = p - q; }
+#pragma unroll
+                for (int x = 0; x < 8; x++) s.hrow[mode][y * 8 + x] = (int16_t)d[x];
+            }
+            if (tid < 35) s.satd8[tid] = 0;
+        });
+        ex.phase([&](int tid) {
+            for (int u = tid; u < 35 * 8; u += NT) {
+                const int mode = u >> 3, x = u & 7;
+                int d[8];
+#pragma unroll
+                for (int y = 0; y < 8; y++) d[y] = s.hrow[mode][y * 8 + x];
+#pragma unroll
+                for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                    for (int i = 0; i < 8; i++)
+                        if (!(i & st)) { int p = d[i], q = d[i + st]; d[i] = p + q; d[i + st] = p - q; }
+                int sum = 0;
+#pragma unroll
+                for (int y = 0; y < 8; y++) sum += iabs(d[y]);
+                ex.atomic_add(&s.satd8[mode], sum);
+            }
+        });
+    } else {
     ex.phase([&](int tid) {
         for (int u = tid; u < 35 * ntile; u += NT) {
             int mode = u / ntile, t = u % ntile, tx = (t % tiles) * 8, ty = (t / tiles) * 8;
@@ -238,36 +282,30 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             s.satd[mode][t] = hadamard8_satd(m);
         }
     });
+    }
     ex.phase([&](int tid) {
         if (tid < 35) {
             unsigned satd = 0;
-            for (int t = 0; t < ntile; t++) satd += (unsigned)s.satd[tid][t];
+            if (log2n == 3) satd = (unsigned)((s.satd8[tid] + 2) >> 2);
+            else for (int t = 0; t < ntile; t++) satd += (unsigned)s.satd[tid][t];
             int bits = tid == s.cand[0] ? 2 : (tid == s.cand[1] || tid == s.cand[2]) ? 3 : 6;
-            s.mode_cost[tid] = (satd << 4) + (unsigned)(a.prm.lambda_sad_q4 * bits);
+            unsigned cost = (satd << 4) + (unsigned)(a.prm.lambda_sad_q4 * bits);
+            ex.atomic_min(&s.mode_key, ((unsigned long long)cost << 6) | (unsigned)tid);      // ties -> lowest mode
         }
-    });
-    ex.phase([&](int tid) {
-        if (tid == 0) {
-            unsigned long long best = ~0ull;
-            for (int m = 0; m < 35; m++) {
-                unsigned long long key = ((unsigned long long)s.mode_cost[m] << 6) | (unsigned)m;
-                if (key < best) best = key;
-            }
-            s.best_mode = (int)(best & 63);
-        }
-        if (tid < 16) {
-            int tx = tid & 3, ty = tid >> 2;
+        if (tid >= 64 && tid < 80) {
+            int t = tid - 64, tx = t & 3, ty = t >> 2;
             bool in = tx * 8 >= cx && tx * 8 < cx + n && ty * 8 >= cy && ty * 8 < cy + n;
-            s.rs.tu_log2[tid] = in ? (uint8_t)log2n : 0;
-            s.rs.tu_intra[tid] = 1;
+            s.rs.tu_log2[t] = in ? (uint8_t)log2n : 0;
+            s.rs.tu_intra[t] = 1;
         }
-        if (tid < 3) s.rs.cbf[tid] = 0;
+        if (tid >= 80 && tid < 83) s.rs.cbf[tid - 80] = 0;
     });
     // prediction of the chosen mode (luma) and DM chroma, residual
     ex.phase([&](int tid) {
-        const int mode = s.best_mode;
+        const int mode = (int)(s.mode_key & 63);
         const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
-        for (int i = tid; i < 1536; i += NT) {
+        for (int k = tid; k < rcnt; k += NT) {
+            const int i = rg.index(k);
             SampleLoc l = locate(s.rs, i);
             if (!l.log2n) continue;
             int v;
@@ -277,12 +315,13 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             s.rs.res[i] = (int16_t)((int)s.src[i] - v);
         }
     });
-    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd);
+    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, rg);
     // reconstruction into the LDS neighbourhood, distortion, rate estimate
     ex.phase([&](int tid) {
         const int maxv = (1 << bd) - 1;
         unsigned sse = 0;
-        for (int i = tid; i < 1536; i += NT) {
+        for (int k = tid; k < rcnt; k += NT) {
+            const int i = rg.index(k);
             SampleLoc l = locate(s.rs, i);
             if (!l.log2n) continue;
             int v = clip3(0, maxv, (int)s.pred[i] + s.rs.res[i]);
@@ -303,7 +342,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         }
     });
     ex.phase([&](int tid) {
-        const int mode = s.best_mode;
+        const int mode = (int)(s.mode_key & 63);
         int t0 = (cy >> 3) * 4 + (cx >> 3);
         if (tid < 16 && s.rs.tu_log2[tid]) {
             mihevc_cu_rec r;
@@ -326,12 +365,12 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
 // copy the region (cx,cy,n) of the accumulated state to the save area (dir = 0) or back (dir = 1)
 template <typename T, class Ex> DEV void intra_save_restore(Ex &ex, IntraShared<T> &s, int cx, int cy, int n, int dir)
 {
+    const Region rg{cx, cy, n == 32 ? 5 : 4};
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1536; i += NT) {
+        for (int k = tid; k < rg.count(); k += NT) {
+            const int i = rg.index(k);
             int pl, x, y;
-            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
-            int sh = pl ? 1 : 0;
-            if (x < (cx >> sh) || x >= ((cx + n) >> sh) || y < (cy >> sh) || y >= ((cy + n) >> sh)) continue;
+            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int kk = i - 1024; pl = 1 + (kk >> 8); kk &= 255; x = kk & 15; y = kk >> 4; }
             T *live = pl ? &s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : &s.rec_y[(y + 1) * RY_STRIDE + x + 1];
             T *save = pl ? &s.save_c[pl - 1][y * 16 + x] : &s.save_y[y * 32 + x];
             if (dir == 0) { *save = *live; s.coef_save[i] = s.coef_acc[i]; }

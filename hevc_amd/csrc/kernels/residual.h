@@ -31,6 +31,22 @@ struct SampleLoc {
     int stride, base;          // row stride and base offset of the plane inside the 1536-sample arrays
 };
 
+// A square luma region of the CTU (cx, cy, size 2^log2n) plus its two co-located chroma blocks: 1.5 n^2 samples.
+// Phases that only concern one CU enumerate the region instead of all 1536 CTU samples.
+struct Region {
+    int cx, cy, log2n;
+    DEV int count() const { return (1 << (2 * log2n)) + (1 << (2 * log2n - 1)); }
+    DEV int index(int k) const      // k-th sample of the region -> index into the 1536-sample CTU arrays
+    {
+        const int n2 = 1 << (2 * log2n);
+        if (k < n2) return (cy + (k >> log2n)) * 32 + cx + (k & ((1 << log2n) - 1));
+        k -= n2;
+        const int q = n2 >> 2, pl = k >= q, kk = pl ? k - q : k, l2 = log2n - 1;
+        return 1024 + pl * 256 + ((cy >> 1) + (kk >> l2)) * 16 + (cx >> 1) + (kk & ((1 << l2) - 1));
+    }
+};
+DEV Region whole_ctu() { return Region{0, 0, 5}; }
+
 DEV SampleLoc locate(const ResidualShared &s, int idx)
 {
     SampleLoc l;
@@ -50,10 +66,12 @@ DEV SampleLoc locate(const ResidualShared &s, int idx)
 }
 
 // forward + quant + scaling + inverse for every TU described by s.tu_log2; qp / qp_c are syntax QPs
-template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth)
+template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth, Region rg)
 {
+    const int cnt = rg.count();
     ex.phase([&](int tid) {      // forward stage 1: rows
-        for (int idx = tid; idx < 1536; idx += NT) {
+        for (int k = tid; k < cnt; k += NT) {
+            const int idx = rg.index(k);
             SampleLoc l = locate(s, idx);
             if (!l.log2n) continue;
             int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0, row = l.base + l.y * l.stride + l.tx0;
@@ -64,7 +82,8 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
         }
     });
     ex.phase([&](int tid) {      // forward stage 2: columns
-        for (int idx = tid; idx < 1536; idx += NT) {
+        for (int k = tid; k < cnt; k += NT) {
+            const int idx = rg.index(k);
             SampleLoc l = locate(s, idx);
             if (!l.log2n) continue;
             int n = 1 << l.log2n, sh2 = l.log2n + 6, v = l.y - l.ty0, col = l.base + l.ty0 * l.stride + l.x;
@@ -76,7 +95,8 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
         }
     });
     ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16)
-        for (int idx = tid; idx < 1536; idx += NT) {
+        for (int k = tid; k < cnt; k += NT) {
+            const int idx = rg.index(k);
             SampleLoc l = locate(s, idx);
             if (!l.log2n) { s.lvl[idx] = 0; continue; }
             int q = (l.plane ? qp_c : qp) + 6 * (bit_depth - 8);
@@ -95,7 +115,8 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
         }
     });
     ex.phase([&](int tid) {      // inverse stage 1: columns, shift 7, clip to 16 bit (8.6.4.2)
-        for (int idx = tid; idx < 1536; idx += NT) {
+        for (int k = tid; k < cnt; k += NT) {
+            const int idx = rg.index(k);
             SampleLoc l = locate(s, idx);
             if (!l.log2n) continue;
             int n = 1 << l.log2n, yy = l.y - l.ty0, col = l.base + l.ty0 * l.stride + l.x, step = 1 << (5 - l.log2n);
@@ -106,7 +127,8 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
         }
     });
     ex.phase([&](int tid) {      // inverse stage 2: rows, shift 20 - bitDepth
-        for (int idx = tid; idx < 1536; idx += NT) {
+        for (int k = tid; k < cnt; k += NT) {
+            const int idx = rg.index(k);
             SampleLoc l = locate(s, idx);
             if (!l.log2n) { s.res[idx] = 0; continue; }
             int n = 1 << l.log2n, xx = l.x - l.tx0, row = l.base + l.y * l.stride + l.tx0, step = 1 << (5 - l.log2n), sh = 20 - bit_depth;

@@ -29,7 +29,7 @@ using namespace mihevc;
 
 namespace {
 
-constexpr int kRing = 4;      // symbol ring depth (steps in flight between device and CABAC workers)
+constexpr int kRing = 8;      // symbol ring depth (steps in flight between device and CABAC workers)
 
 class ThreadPool {
 public:
@@ -77,6 +77,37 @@ private:
     bool stop_ = false;
 };
 
+// Process-wide cache of device / pinned-host allocations keyed by (device, size): a batch transcodes many clips of
+// the same geometry back to back (gui/mainwindow.py queue), and hipMalloc/hipHostMalloc/hipFree cost tens of ms
+// per session otherwise (bench step_phases: close 51 ms).  Buffers return to the cache at mihevc_close.
+class BufferCache {
+public:
+    static BufferCache &get() { static BufferCache c; return c; }
+    hipError_t alloc(int dev, size_t n, bool pinned, void **out)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            auto &v = free_[key(dev, n, pinned)];
+            if (!v.empty()) { *out = v.back(); v.pop_back(); bytes_ -= n; return hipSuccess; }
+        }
+        return pinned ? hipHostMalloc(out, n, hipHostMallocDefault) : hipMalloc(out, n);
+    }
+    void release(int dev, size_t n, bool pinned, void *p)
+    {
+        if (!p) return;
+        std::lock_guard<std::mutex> l(m_);
+        if (bytes_ + n > kMaxBytes) { if (pinned) (void)hipHostFree(p); else (void)hipFree(p); return; }
+        bytes_ += n;
+        free_[key(dev, n, pinned)].push_back(p);
+    }
+private:
+    static constexpr size_t kMaxBytes = (size_t)24 << 30;      // 24 GiB of 288: plenty for a few clip geometries
+    static std::string key(int dev, size_t n, bool pinned) { return std::to_string(dev) + (pinned ? "h" : "d") + std::to_string(n); }
+    std::mutex m_;
+    std::map<std::string, std::vector<void *>> free_;
+    size_t bytes_ = 0;
+};
+
 struct Packet {
     std::vector<uint8_t> data;
     int64_t pts = 0;
@@ -112,6 +143,7 @@ struct mihevc_session {
     hipStream_t st_compute = nullptr, st_copy = nullptr;
     // source pictures of the current chunk (device), in display order
     struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; };
+    size_t plane_bytes[2][3] = {{0}};   // [padded][plane] allocation sizes (for the buffer cache)
     std::vector<Src> pending;
     std::vector<Src> free_src;
     // per lane
@@ -133,7 +165,7 @@ struct mihevc_session {
     ThreadPool *pool = nullptr;
     std::mutex m;
     std::condition_variable cv;
-    int jobs_open[kRing] = {0, 0, 0, 0};
+    int jobs_open[kRing] = {0};
     std::map<int64_t, Packet> packets;     // by output index
     int64_t next_out = 0, frames_in = 0, frames_done = 0;
     std::vector<uint8_t> headers, cur_packet;
@@ -161,7 +193,8 @@ int alloc_planes(mihevc_session *s, void *base[3], void *p[3], int stride[3], bo
     for (int i = 0; i < 3; i++) {
         int w = i ? s->w / 2 : s->w, h = i ? s->h / 2 : s->h, pad = padded ? (i ? PAD_C : PAD_Y) : 0;
         stride[i] = (w + 2 * pad + 63) & ~63;
-        HIPCK(s, hipMalloc(&base[i], (size_t)stride[i] * (h + 2 * pad) * esize(s)));
+        s->plane_bytes[padded][i] = (size_t)stride[i] * (h + 2 * pad) * esize(s);
+        HIPCK(s, BufferCache::get().alloc(s->device, s->plane_bytes[padded][i], false, &base[i]));
         p[i] = (uint8_t *)base[i] + ((size_t)pad * stride[i] + pad) * esize(s);
     }
     return 0;
@@ -182,10 +215,10 @@ int ensure_lanes(mihevc_session *s, int n)
         for (int k = 0; k < 2; k++)
             if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, true)) return e;
         if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, false)) return e;
-        HIPCK(s, hipMalloc((void **)&L.me, (size_t)s->n_ctu * 63 * sizeof(int32_t)));
+        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         for (int k = 0; k < kRing; k++) {
-            HIPCK(s, hipMalloc((void **)&L.sym_dev[k], sl.total));
-            HIPCK(s, hipHostMalloc((void **)&L.sym_host[k], sl.total, hipHostMallocDefault));
+            HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
+            HIPCK(s, BufferCache::get().alloc(s->device, sl.total, true, (void **)&L.sym_host[k]));
         }
         s->lane.push_back(L);
     }
@@ -396,7 +429,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     (void)hipEventDestroy(t_begin); (void)hipEventDestroy(t_end);
     {   // all CABAC jobs of the chunk
         std::unique_lock<std::mutex> l(s->m);
-        s->cv.wait(l, [&] { return s->jobs_open[0] + s->jobs_open[1] + s->jobs_open[2] + s->jobs_open[3] == 0; });
+        s->cv.wait(l, [&] { int n = 0; for (int k = 0; k < kRing; k++) n += s->jobs_open[k]; return n == 0; });
     }
     for (auto &src : s->pending) s->free_src.push_back(src);
     s->pending.clear();
@@ -579,13 +612,15 @@ void mihevc_close(mihevc_session *s)
     delete s->pool;      // joins workers
     if (s->st_compute) (void)hipStreamSynchronize(s->st_compute);
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
-    auto free3 = [](void *b[3]) { for (int i = 0; i < 3; i++) if (b[i]) (void)hipFree(b[i]); };
-    for (auto &x : s->pending) free3(x.base);
-    for (auto &x : s->free_src) free3(x.base);
+    BufferCache &bc = BufferCache::get();
+    SymLayout sl(s->w, s->h);
+    auto free3 = [&](void *b[3], int padded) { for (int i = 0; i < 3; i++) bc.release(s->device, s->plane_bytes[padded][i], false, b[i]); };
+    for (auto &x : s->pending) free3(x.base, 0);
+    for (auto &x : s->free_src) free3(x.base, 0);
     for (auto &L : s->lane) {
-        free3(L.rec_base[0]); free3(L.rec_base[1]); free3(L.work_base);
-        if (L.me) (void)hipFree(L.me);
-        for (int k = 0; k < kRing; k++) { if (L.sym_dev[k]) (void)hipFree(L.sym_dev[k]); if (L.sym_host[k]) (void)hipHostFree(L.sym_host[k]); }
+        free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
+        bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
+        for (int k = 0; k < kRing; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     if (s->d_args) (void)hipFree(s->d_args);
     if (s->h_args) (void)hipHostFree(s->h_args);
