@@ -42,7 +42,7 @@ class CostParams(C.Structure):
 EXPORTS = (
     "mihevc_abi_version", "mihevc_device_count", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_device",
     "mihevc_receive_packet", "mihevc_flush", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
-    "mihevc_get_recon", "mihevc_coded_size", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_k_transform",
+    "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_k_transform",
     "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_write_parameter_sets",
     "mihevc_encode_picture_host",
 )
@@ -85,11 +85,12 @@ def load() -> C.CDLL:
     lib.mihevc_set_keep_recon.argtypes = [vp, i32]
     lib.mihevc_get_recon.argtypes = [vp, i64, vp, vp, vp]
     lib.mihevc_coded_size.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    lib.mihevc_get_frame_info.argtypes = [vp, i64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
     lib.mihevc_cost_params_for_qp.argtypes = [i32, i32, i32, C.POINTER(CostParams)]
     lib.mihevc_cost_params_for_qp.restype = None
     lib.mihevc_k_transform.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32]
-    lib.mihevc_k_intra_frame.argtypes = [i32, vp, vp, vp, i32, i32, C.POINTER(CostParams), vp, vp, vp, vp, vp, vp, vp]
-    lib.mihevc_k_inter_frame.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CostParams), vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mihevc_k_intra_frame.argtypes = [i32, vp, vp, vp, i32, i32, C.POINTER(CostParams), vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.mihevc_k_inter_frame.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CostParams), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mihevc_k_deblock.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32]
     lib.mihevc_k_sao.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CostParams), vp, vp, vp, vp]
     lib.mihevc_write_parameter_sets.argtypes = [C.POINTER(Config), vp, C.c_size_t]

@@ -335,32 +335,34 @@ bool geometry_ok(int w, int h) { return w >= 16 && h >= 16 && !(w & 7) && !(h & 
 
 template <typename T>
 int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *ry, void *ru, void *rv,
-                mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+                mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv, uint64_t *est)
 {
     Planes3<T> src, rec;
     if (src.alloc(w, h, false) || rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
     if (int e = src.upload(sy, su, sv)) return e;
     const size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h;
-    DevBuf dcu, dc0, dc1, dc2, dargs;
+    DevBuf dcu, dc0, dc1, dc2, dargs, dest;
     CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dc0.alloc(ny * 2)); CK(dc1.alloc(ny / 2)); CK(dc2.alloc(ny / 2)); CK(dargs.alloc(sizeof(IntraArgs<T>)));
+    CK(dest.alloc(8)); CK(hipMemset(dest.p, 0, 8));
     CK(hipMemset(dcu.p, 0, n8 * sizeof(mihevc_cu_rec)));
     IntraArgs<T> a;
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.rec[i] = rec.p[i].pl; }
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
-    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0;
+    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>();
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1));
     CK(hipDeviceSynchronize());
     if (int e = rec.download(ry, ru, rv)) return e;
     CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));
     CK(hipMemcpy(cy, dc0.p, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cu_, dc1.p, ny / 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cv, dc2.p, ny / 2, hipMemcpyDeviceToHost));
+    if (est) CK(hipMemcpy(est, dest.p, 8, hipMemcpyDeviceToHost));
     return MIHEVC_OK;
 }
 
 template <typename T>
 int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, const void *fu, const void *fv, int w, int h,
                 const mihevc_cost_params *prm, const int16_t *centers, void *ry, void *ru, void *rv, mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_,
-                int16_t *cv, int32_t *me_dump)
+                int16_t *cv, int32_t *me_dump, uint64_t *est)
 {
     Planes3<T> src, ref, rec;
     if (src.alloc(w, h, false) || ref.alloc(w, h, true) || rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
@@ -368,7 +370,8 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     if (int e = ref.upload(fy, fu, fv)) return e;
     const int ctus_w = (w + CTU - 1) / CTU, n_ctu = ctus_w * ((h + CTU - 1) / CTU);
     const size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h;
-    DevBuf dcu, dc0, dc1, dc2, dargs, dme, dcen, dpad;
+    DevBuf dcu, dc0, dc1, dc2, dargs, dme, dcen, dpad, dest;
+    CK(dest.alloc(8)); CK(hipMemset(dest.p, 0, 8));
     CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dc0.alloc(ny * 2)); CK(dc1.alloc(ny / 2)); CK(dc2.alloc(ny / 2));
     CK(dargs.alloc(sizeof(InterArgs<T>))); CK(dme.alloc((size_t)n_ctu * 63 * 4)); CK(dcen.alloc((size_t)n_ctu * 4)); CK(dpad.alloc(sizeof(SaoArgs<T>)));
     CK(hipMemset(dcu.p, 0, n8 * sizeof(mihevc_cu_rec)));
@@ -384,6 +387,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.ref[i] = {ref.p[i].pl.p, ref.p[i].pl.stride}; a.rec[i] = rec.p[i].pl; }
     a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.centers = centers ? dcen.as<int16_t>() : nullptr; a.me = dme.as<int32_t>();
     a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>();
+    a.est = dest.as<unsigned long long>();
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
     CK(launch_inter_ctu<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
@@ -392,6 +396,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));
     CK(hipMemcpy(cy, dc0.p, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cu_, dc1.p, ny / 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cv, dc2.p, ny / 2, hipMemcpyDeviceToHost));
     if (me_dump) CK(hipMemcpy(me_dump, dme.p, (size_t)n_ctu * 63 * 4, hipMemcpyDeviceToHost));
+    if (est) CK(hipMemcpy(est, dest.p, 8, hipMemcpyDeviceToHost));
     return MIHEVC_OK;
 }
 
@@ -475,24 +480,24 @@ int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int
 }
 
 int mihevc_k_intra_frame(int device, const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *ry, void *ru,
-                         void *rv, mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+                         void *rv, mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv, uint64_t *est)
 {
     if (!sy || !su || !sv || !prm || !ry || !ru || !rv || !cu || !cy || !cu_ || !cv || !geometry_ok(w, h)) return MIHEVC_EINVAL;
     if (int e = select_device(device)) return e;
-    if (prm->bit_depth == 8) return stage_intra<uint8_t>(sy, su, sv, w, h, prm, ry, ru, rv, cu, cy, cu_, cv);
-    if (prm->bit_depth == 10) return stage_intra<uint16_t>(sy, su, sv, w, h, prm, ry, ru, rv, cu, cy, cu_, cv);
+    if (prm->bit_depth == 8) return stage_intra<uint8_t>(sy, su, sv, w, h, prm, ry, ru, rv, cu, cy, cu_, cv, est);
+    if (prm->bit_depth == 10) return stage_intra<uint16_t>(sy, su, sv, w, h, prm, ry, ru, rv, cu, cy, cu_, cv, est);
     return MIHEVC_EINVAL;
 }
 
 int mihevc_k_inter_frame(int device, const void *sy, const void *su, const void *sv, const void *fy, const void *fu, const void *fv, int w, int h,
                          const mihevc_cost_params *prm, const int16_t *centers, void *ry, void *ru, void *rv, mihevc_cu_rec *cu, int16_t *cy,
-                         int16_t *cu_, int16_t *cv, int32_t *me_dump)
+                         int16_t *cu_, int16_t *cv, int32_t *me_dump, uint64_t *est)
 {
     if (!sy || !su || !sv || !fy || !fu || !fv || !prm || !ry || !ru || !rv || !cu || !cy || !cu_ || !cv || !geometry_ok(w, h)) return MIHEVC_EINVAL;
     if (prm->me_range < 1 || prm->me_range > MAX_RANGE) return MIHEVC_EINVAL;
     if (int e = select_device(device)) return e;
-    if (prm->bit_depth == 8) return stage_inter<uint8_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump);
-    if (prm->bit_depth == 10) return stage_inter<uint16_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump);
+    if (prm->bit_depth == 8) return stage_inter<uint8_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump, est);
+    if (prm->bit_depth == 10) return stage_inter<uint16_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump, est);
     return MIHEVC_EINVAL;
 }
 

@@ -281,6 +281,7 @@ struct GpuExec {
     DEV void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
     DEV void atomic_or(unsigned *p, unsigned v) { atomicOr(p, v); }
     DEV void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
+    DEV void atomic_add_global(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 };
 #endif
 struct SeqExec {      // sequential stepping of a phase program (tests/emu)
@@ -292,6 +293,7 @@ struct SeqExec {      // sequential stepping of a phase program (tests/emu)
     void atomic_add(unsigned *p, unsigned v) { *p += v; }
     void atomic_or(unsigned *p, unsigned v) { *p |= v; }
     void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
+    void atomic_add_global(unsigned long long *p, unsigned long long v) { *p += v; }
 };
 
 }  // namespace mihevc

@@ -25,6 +25,7 @@ template <typename T> struct InterArgs {
     int32_t *me;                 // per CTU 21 x (mvx, mvy, cost): written by me_search, read by inter_ctu
     mihevc_cu_rec *cu;           // (h/8) x (w/8)
     int16_t *coef[3];            // strides w, w/2, w/2
+    unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit), see DESIGN.md rate control
 };
 
 // candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
@@ -176,6 +177,7 @@ template <typename T> struct InterShared {
     uint8_t alias[3][16];        // level whose SATDs stand for (level, tile): a coarser node with the SAME vector as a finer one is not recomputed
     int tile_mvx[16], tile_mvy[16];
     uint8_t tile_node[16];
+    unsigned est;                // CTU rate estimate, 1/16 bit
     // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
 };
 // motion-compensation windows cover every vector the search can return: |mv| <= R + 3 (widened horizontal span)
@@ -322,6 +324,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     // quadtree decision
     ex.phase([&](int tid) {
         if (tid != 0) return;
+        s.est = 0;
         unsigned J[21];
         for (int n = 0; n < 21; n++) J[n] = s.valid[n] ? s.cost[n] + (unsigned)(lam * 4) : 0;
         int use16[4], use32;
@@ -379,6 +382,20 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             a.rec[l.plane].p[(ptrdiff_t)gy * a.rec[l.plane].stride + gx] = (T)v;
             a.coef[l.plane][(size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx] = s.rs.lvl[i];
         }
+        if (a.est) {       // rate estimate: coefficient sub-block costs + a header per CU (oracle: inter estimate)
+            unsigned e = 0;
+            for (int sb = tid; sb < 96; sb += NT) {
+                int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
+                int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0, sh = pl ? 2 : 3;
+                if (s.rs.tu_log2[(by >> sh) * 4 + (bx >> sh)]) e += (unsigned)subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
+            }
+            if (tid < 16 && s.rs.tu_log2[tid]) {
+                int nx, ny, nl;
+                node_geom(s.tile_node[tid], nx, ny, nl);
+                if ((ny >> 3) * 4 + (nx >> 3) == tid) e += 16u * (unsigned)(6 + mvd_bits(s.tile_mvx[tid] - 4 * sx) + mvd_bits(s.tile_mvy[tid] - 4 * sy));
+            }
+            if (e) ex.atomic_add(&s.est, e);
+        }
         if (tid < 16 && s.rs.tu_log2[tid]) {
             int t = tid, txp = t & 3, typ = t >> 2, node = s.tile_node[t], nx, ny, nl;
             node_geom(node, nx, ny, nl);
@@ -394,6 +411,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             a.cu[(size_t)((y0 >> 3) + typ) * (a.w >> 3) + (x0 >> 3) + txp] = r;
         }
     });
+    if (a.est) ex.phase([&](int tid) { if (tid == 0 && s.est) ex.atomic_add_global(a.est, s.est); });
 }
 
 }  // namespace mihevc

@@ -21,6 +21,7 @@ template <typename T> struct IntraArgs {
     mihevc_cu_rec *cu;
     int16_t *coef[3];
     int diagonal;                // CTUs with cx + 2*cy == diagonal are processed by this launch
+    unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit)
 };
 
 constexpr int RY_STRIDE = 68;    // LDS luma neighbourhood: rows -1..31, cols -1..63 (+ pad)
@@ -46,6 +47,7 @@ template <typename T> struct IntraShared {
     unsigned sse;
     int bits[3];
     unsigned long long j_cu;
+    unsigned est;
 };
 
 // p[x][y] accessors on the linear 4N+1 layout: L[0] = p[-1][2N-1] ... L[2N] = p[-1][-1] ... L[4N] = p[2N-1][-1]
@@ -399,6 +401,7 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             s.src[i] = (gx < pw && gy < ph) ? a.src[pl].p[(size_t)gy * a.src[pl].stride + gx] : (T)0;
             s.coef_acc[i] = 0;
         }
+        if (tid == 0) s.est = 0;
         // neighbourhood: row -1 (cols -1..63 luma / -1..31 chroma) and column -1 (rows 0..31 / 0..15) from the picture
         for (int u = tid; u < 65 + 32 + 2 * (33 + 16); u += NT) {
             int pl, k, row_len, col_len;
@@ -454,7 +457,23 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
             if (x0 + tx < a.w && y0 + ty < a.h) a.cu[(size_t)((y0 + ty) >> 3) * (a.w >> 3) + ((x0 + tx) >> 3)] = s.cu_acc[tid];
         }
+        if (a.est) {       // rate estimate of the final CTU: coefficient sub-block costs + 8 bits of header per CU
+            unsigned e = 0;
+            for (int sb = tid; sb < 96; sb += NT) {
+                int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
+                int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
+                int lx = pl ? bx * 2 : bx, ly = pl ? by * 2 : by;
+                if (x0 + lx < a.w && y0 + ly < a.h) e += (unsigned)subblock_bits_q4(s.coef_acc + base + by * stride + bx, stride);
+            }
+            if (tid < 16) {
+                int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
+                const mihevc_cu_rec &r = s.cu_acc[tid];
+                if (x0 + tx < a.w && y0 + ty < a.h && !(tx & ((1 << r.log2_size) - 1)) && !(ty & ((1 << r.log2_size) - 1))) e += 16u * 8u;
+            }
+            if (e) ex.atomic_add(&s.est, e);
+        }
     });
+    if (a.est) ex.phase([&](int tid) { if (tid == 0 && s.est) ex.atomic_add_global(a.est, s.est); });
 }
 
 }  // namespace mihevc

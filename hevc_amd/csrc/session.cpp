@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <condition_variable>
 #include <cstring>
 #include <deque>
@@ -114,9 +115,9 @@ struct Packet {
     bool key = false, ready = false;
 };
 
-// symbol block of one picture: [cu | coef Y | coef U | coef V | sao | sse]
+// symbol block of one picture: [cu | coef Y | coef U | coef V | sao | sse[3] | rate estimate]
 struct SymLayout {
-    size_t cu, cy, cu_, cv, sao, sse, total;
+    size_t cu, cy, cu_, cv, sao, sse, est, total;
     SymLayout(int w, int h)
     {
         size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h, nctu = (size_t)((w + 31) / 32) * ((h + 31) / 32);
@@ -127,7 +128,8 @@ struct SymLayout {
         cv = al(cu_ + ny / 2);
         sao = al(cv + ny / 2);
         sse = al(sao + nctu * sizeof(mihevc_sao_ctu));
-        total = al(sse + 3 * sizeof(unsigned long long));
+        est = sse + 3 * sizeof(unsigned long long);
+        total = al(est + sizeof(unsigned long long));
     }
 };
 
@@ -171,6 +173,11 @@ struct mihevc_session {
     std::vector<uint8_t> headers, cur_packet;
     std::map<int64_t, std::vector<uint16_t>> recon;   // keep_recon: final pictures by index (Y,U,V concatenated)
     mihevc_stats stats{};
+    // rate control (VBV-capped constant quality, one controller per GOP lane): see DESIGN.md §Rate control
+    bool rc_on = false;
+    double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate)
+    struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
+    std::vector<FrameRec> frames;             // by output index
     std::atomic<long long> entropy_ns{0};
 };
 
@@ -275,6 +282,17 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
         std::lock_guard<std::mutex> l(s->m);
         s->stats.sse_y += (double)sse[0]; s->stats.sse_u += (double)sse[1]; s->stats.sse_v += (double)sse[2];
         s->stats.bytes_out += (int64_t)pk.data.size();
+        if ((size_t)index < s->frames.size()) {
+            auto &fr = s->frames[(size_t)index];
+            fr.bits = (long long)pk.data.size() * 8;
+            fr.est_q4 = *(const unsigned long long *)(b + sl.est);
+            fr.est_known = true;
+            if (fr.est_q4 > 0) {
+                double r = (double)fr.bits / ((double)fr.est_q4 / 16.0);
+                double &ratio = slice_type == 2 ? s->ratio_i : s->ratio_p;
+                ratio = 0.75 * ratio + 0.25 * r;
+            }
+        }
         s->packets[index] = std::move(pk);
         s->frames_done++;
         s->jobs_open[slot]--;
@@ -301,10 +319,16 @@ template <typename T> int encode_chunk(mihevc_session *s)
         s->args_cap = need;
     }
     uint8_t *ha = s->h_args, *da = (uint8_t *)s->d_args;
-    mihevc_cost_params cp_i, cp_p;
-    mihevc_cost_params_for_qp(s->qp_i, s->cfg.bit_depth, s->me_range, &cp_i);
-    mihevc_cost_params_for_qp(s->qp_p, s->cfg.bit_depth, s->me_range, &cp_p);
-    auto prm = [](const mihevc_cost_params &c) { return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range}; };
+    auto prm_for = [&](int qp) {
+        mihevc_cost_params c;
+        mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
+        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range};
+    };
+    const int64_t first_index = s->frames_in - n;
+    {
+        std::lock_guard<std::mutex> l(s->m);
+        s->frames.resize((size_t)s->frames_in);
+    }
     std::vector<int> batch(steps, 0);
     for (int t = 0; t < steps; t++)
         for (int g = 0; g < gops; g++) {
@@ -318,7 +342,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             struct { IntraArgs<T> &intra; InterArgs<T> &inter; DeblockArgs<T> &dbk_v, &dbk_h; SaoArgs<T> &sao; } A{hv.intra[g], hv.inter[g], hv.dbk_v[g], hv.dbk_h[g], hv.sao[g]};
             uint8_t *sym = L.sym_dev[t % kRing];
             const int cur = t & 1, prev = cur ^ 1;
-            const CostParams P = prm(t == 0 ? cp_i : cp_p);
+            const CostParams P = prm_for(t == 0 ? s->qp_i : s->qp_p);      // provisional; the controller patches it per step
             for (int i = 0; i < 3; i++) {
                 A.intra.src[i] = mkc<T>(src.p[i], src.stride[i]); A.intra.rec[i] = mk<T>(L.work_p[i], L.work_stride[i]);
                 A.inter.src[i] = mkc<T>(src.p[i], src.stride[i]); A.inter.ref[i] = mkc<T>(L.rec_p[prev][i], L.rec_stride[i]);
@@ -340,8 +364,52 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
             A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
             A.sao.sse = (unsigned long long *)(sym + sl.sse);
+            A.intra.est = A.inter.est = (unsigned long long *)(sym + sl.est);
         }
     HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
+    // ---- per-lane rate controllers ----
+    const double fps = (double)s->cfg.fps_num / s->cfg.fps_den;
+    std::vector<int> qp_prev(gops, s->qp_p), gop_len(gops, 0);
+    std::vector<double> budget(gops, 0.0);
+    for (int g = 0; g < gops; g++) {
+        gop_len[g] = std::min(s->keyint, n - g * s->keyint);
+        budget[g] = s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
+    }
+    const double w_i = 8.0;                   // an IDR picture is budgeted like 8 P pictures
+    auto decide_p = [&](int g, int t) -> int {
+        // bits spent so far in this GOP: CABAC sizes where known, else the device estimate, else a model from the last known picture
+        std::lock_guard<std::mutex> l(s->m);
+        double spent = 0, ref_bits = -1;
+        int ref_qp = s->qp_p;
+        for (int j = 0; j < t; j++) {
+            auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
+            double b;
+            if (fr.bits >= 0) b = (double)fr.bits;
+            else if (fr.est_known) b = (double)fr.est_q4 / 16.0 * (fr.type == 2 ? s->ratio_i : s->ratio_p);
+            else if (ref_bits >= 0) b = ref_bits * std::pow(2.0, (ref_qp - fr.qp) / 6.0);
+            else b = budget[g] / gop_len[g];
+            spent += b;
+            if (fr.bits >= 0 || fr.est_known) {
+                if (fr.type == 2) { if (ref_bits < 0) { ref_bits = b / w_i; ref_qp = fr.qp + 3; } }
+                else { ref_bits = b; ref_qp = fr.qp; }
+            }
+        }
+        const int left = gop_len[g] - t;
+        double target = (budget[g] - spent) / std::max(1, left);
+        target = std::max(target, 0.25 * budget[g] / gop_len[g]);
+        int qp = s->qp_p;
+        if (ref_bits > 0) qp = (int)std::lround(ref_qp + 6.0 * std::log2(ref_bits / target));
+        qp = std::max(qp, s->qp_p);                                  // the CRF is the quality ceiling, the VBV only raises QP
+        if (t > 1) qp = std::min(std::max(qp, qp_prev[g] - 2), qp_prev[g] + 2);
+        return std::min(qp, 51);
+    };
+    auto patch_qp = [&](int t, int g, int qp) {
+        StepView<T> hv(ha, lay, t);
+        hv.intra[g].prm = hv.inter[g].prm = hv.sao[g].prm = prm_for(qp);
+        std::lock_guard<std::mutex> l(s->m);
+        auto &fr = s->frames[(size_t)(first_index + g * s->keyint + t)];
+        fr.qp = qp; fr.type = t == 0 ? 2 : 1;
+    };
     // ---- lock-step over the GOPs ----
     hipEvent_t t_begin, t_end;
     HIPCK(s, hipEventCreate(&t_begin)); HIPCK(s, hipEventCreate(&t_end));
@@ -354,8 +422,16 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         // the copy of step t - kRing has completed (its jobs waited for it); compute may now reuse the device slot
         StepView<T> dv(da, lay, t);
-        for (int g = 0; g < B; g++)      // zero the slot's SSE accumulators
-            HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot] + sl.sse, 0, 3 * sizeof(unsigned long long), s->st_compute));
+        std::vector<int> qp_step(B);
+        for (int g = 0; g < B; g++) {
+            qp_step[g] = t == 0 ? s->qp_i : (s->rc_on ? decide_p(g, t) : s->qp_p);
+            patch_qp(t, g, qp_step[g]);
+            qp_prev[g] = qp_step[g];
+        }
+        for (int attempt = 0; attempt < 2; attempt++) {
+        HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
+        for (int g = 0; g < B; g++)      // zero the slot's SSE + estimate accumulators
+            HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
         auto mark = [&](int stage, bool begin) -> int {       // bracket a stage with events when profiling
             if (!s->cfg.profile_stages) return 0;
             size_t need_ev = s->marks.size() * 2 + 2;
@@ -374,6 +450,22 @@ template <typename T> int encode_chunk(mihevc_session *s)
         STAGE(4, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
         STAGE(5, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
         STAGE(6, launch_frame_sse<T>(s->st_compute, dv.sao, B));
+        // IDR pictures under rate control: read the device's rate estimate and re-run the step once when a picture
+        // would overshoot its share of the GOP budget (there is no earlier picture to learn from)
+        if (!(s->rc_on && t == 0 && attempt == 0)) break;
+        HIPCK(s, hipStreamSynchronize(s->st_compute));
+        bool again = false;
+        for (int g = 0; g < B; g++) {
+            unsigned long long e = 0;
+            HIPCK(s, hipMemcpy(&e, s->lane[g].sym_dev[slot] + sl.est, sizeof e, hipMemcpyDeviceToHost));
+            double pred = (double)e / 16.0 * s->ratio_i, alloc = budget[g] * w_i / (w_i + gop_len[g] - 1);
+            if (pred > 1.1 * alloc) {
+                int q = std::min(51, qp_step[g] + (int)std::ceil(6.0 * std::log2(pred / alloc)));
+                if (q != qp_step[g]) { qp_step[g] = q; patch_qp(t, g, q); qp_prev[g] = q + 3; again = true; }
+            }
+        }
+        if (!again) break;
+        }
 #undef STAGE
         HIPCK(s, hipEventRecord(s->ev_compute[slot], s->st_compute));
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot], 0));
@@ -405,7 +497,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             int fi = g * s->keyint + t;
             int64_t index = s->frames_in - n + fi, pts = s->pending[fi].pts;
             hipEvent_t ev = s->ev_copy[slot];
-            int st = t == 0 ? 2 : 1, qp = t == 0 ? s->qp_i : s->qp_p;
+            int st = t == 0 ? 2 : 1, qp = qp_step[g];
             bool first = index == 0;
             s->pool->submit([s, slot, g, index, pts, st, t, qp, first, ev] {
                 (void)hipEventSynchronize(ev);
@@ -476,6 +568,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->qp_p = cfg->qp >= 0 ? cfg->qp : std::min(51, std::max(0, cfg->crf + 2));
     s->qp_i = std::max(0, s->qp_p - 3);
     s->stats.last_qp = s->qp_p;
+    s->rc_on = cfg->qp < 0 && cfg->vbv_maxrate_kbps > 0;
     write_parameter_sets(s->cfg, s->headers);
     bool ok = hipStreamCreateWithFlags(&s->st_compute, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking) == hipSuccess;
@@ -593,6 +686,18 @@ int mihevc_get_recon(mihevc_session *s, int64_t index, uint16_t *y, uint16_t *u,
     memcpy(y, it->second.data(), ny * 2);
     memcpy(u, it->second.data() + ny, ny / 2);
     memcpy(v, it->second.data() + ny + ny / 4, ny / 2);
+    return MIHEVC_OK;
+}
+
+int mihevc_get_frame_info(mihevc_session *s, int64_t index, int *qp, int *slice_type, int64_t *bits)
+{
+    if (!s) return MIHEVC_EINVAL;
+    std::lock_guard<std::mutex> l(s->m);
+    if (index < 0 || (size_t)index >= s->frames.size()) return MIHEVC_ESTATE;
+    const auto &fr = s->frames[(size_t)index];
+    if (qp) *qp = fr.qp;
+    if (slice_type) *slice_type = fr.type;
+    if (bits) *bits = fr.bits;
     return MIHEVC_OK;
 }
 

@@ -140,6 +140,12 @@ class Encoder:
         self._check(self._lib.mihevc_get_recon(self._s, index, y.ctypes.data, u.ctypes.data, v.ctypes.data), "get_recon")
         return y, u, v
 
+    def frame_info(self, index: int):
+        """(qp, slice_type, bits) of output picture `index`"""
+        qp, st, bits = C.c_int(), C.c_int(), C.c_int64()
+        self._check(self._lib.mihevc_get_frame_info(self._s, index, C.byref(qp), C.byref(st), C.byref(bits)), "get_frame_info")
+        return qp.value, st.value, bits.value
+
     def psnr_y(self) -> float:
         st = self.stats()
         n = max(1, st.frames_out) * self.coded_size()[0] * self.coded_size()[1]

@@ -103,6 +103,8 @@ int  mihevc_get_headers(mihevc_session *s, const uint8_t **data, size_t *size);
 int  mihevc_set_keep_recon(mihevc_session *s, int keep);
 int  mihevc_get_recon(mihevc_session *s, int64_t index, uint16_t *y, uint16_t *u, uint16_t *v);
 int  mihevc_coded_size(const mihevc_session *s, int *w, int *h);
+/* QP, slice type (2 = IDR, 1 = P) and coded size in bits (-1 while CABAC is still running) of output picture `index` */
+int  mihevc_get_frame_info(mihevc_session *s, int64_t index, int *qp, int *slice_type, int64_t *bits);
 const char *mihevc_strerror(int err);
 const char *mihevc_last_error(const mihevc_session *s);
 
@@ -142,12 +144,14 @@ int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int
 /* K2+K3: intra picture analysis -> pre-deblock reconstruction, CU records, levels */
 int mihevc_k_intra_frame(int device, const void *src_y, const void *src_u, const void *src_v, int width, int height,
                          const mihevc_cost_params *prm, void *rec_y, void *rec_u, void *rec_v,
-                         mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v);
+                         mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
+                         uint64_t *est_bits_q4 /* optional: the picture's rate estimate in 1/16 bit (rate control input) */);
 /* K1+K3: inter picture analysis against one (unpadded) reference reconstruction */
 int mihevc_k_inter_frame(int device, const void *src_y, const void *src_u, const void *src_v,
                          const void *ref_y, const void *ref_u, const void *ref_v, int width, int height,
                          const mihevc_cost_params *prm, const int16_t *centers, void *rec_y, void *rec_u, void *rec_v,
-                         mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump);
+                         mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump,
+                         uint64_t *est_bits_q4);
 /* K4a: deblocking in place */
 int mihevc_k_deblock(int device, void *rec_y, void *rec_u, void *rec_v, int width, int height,
                      const mihevc_cu_rec *cu, int bit_depth);

@@ -460,6 +460,44 @@ static int code_tu(const pix *src, int sstride, const pix *pred, int pstride, pi
     return nnz != 0;
 }
 
+/* Picture-level rate estimate in 1/16 bit (drives the rate controller; mirrored by the kernels' `est` accumulators):
+ * every 4x4 sub-block with a non-zero level costs 24 + sum f(|level|) (f as in code_tu), every CU a header of
+ * 8 bits (intra) or 6 + mvd bits relative to the CTU's search centre (inter). */
+static uint64_t estimate_bits(const orc_cu_rec *cu, const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v, int w, int h,
+                              const int16_t *centers)
+{
+    uint64_t est = 0;
+    int w8 = w >> 3, wc = (w + ORC_CTU - 1) / ORC_CTU;
+    for (int by = 0; by < h >> 3; by++)
+        for (int bx = 0; bx < w8; bx++) {
+            const orc_cu_rec *r = &cu[by * w8 + bx];
+            int mask = (1 << r->log2_size) - 1;
+            if (((bx * 8) & mask) || ((by * 8) & mask)) continue;
+            if (r->flags & ORC_F_INTER) {
+                int ctu = (by * 8 / ORC_CTU) * wc + bx * 8 / ORC_CTU;
+                int sx = centers ? centers[2 * ctu] : 0, sy = centers ? centers[2 * ctu + 1] : 0;
+                est += 16u * (unsigned)(6 + orc_mvd_bits(r->mvx - 4 * sx) + orc_mvd_bits(r->mvy - 4 * sy));
+            } else est += 16u * 8u;
+        }
+    for (int pl = 0; pl < 3; pl++) {
+        const int16_t *c = pl == 0 ? coef_y : pl == 1 ? coef_u : coef_v;
+        int pw = pl ? w / 2 : w, ph = pl ? h / 2 : h;
+        for (int y = 0; y < ph; y += 4)
+            for (int x = 0; x < pw; x += 4) {
+                int bits = 0, any = 0;
+                for (int j = 0; j < 4; j++)
+                    for (int i = 0; i < 4; i++) {
+                        int a = iabs(c[(y + j) * pw + x + i]);
+                        if (!a) continue;
+                        any = 1;
+                        bits += a == 1 ? 40 : a == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(a - 1));
+                    }
+                if (any) est += (unsigned)(bits + 24);
+            }
+    }
+    return est;
+}
+
 /* ================================================================================================
  * K1 + K3 : inter frame
  * ================================================================================================ */
@@ -478,7 +516,7 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                              const pix *ref_y, const pix *ref_u, const pix *ref_v, int ref_stride, int ref_cstride,
                              int w, int h, const orc_params *prm, const int16_t *centers,
                              pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
-                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump)
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump, uint64_t *est)
 {
     /* search domain: dy in [-R, R]; dx in [-R, -R + spanx - 1] with spanx = 2R+1 rounded UP to a multiple of 4 (the
      * device evaluates four horizontal positions per v_qsad_pk_u16_u8, so the row is widened instead of masked) */
@@ -608,6 +646,7 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
             }
         }
     free(sad8);
+    if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers);
 }
 
 /* ================================================================================================
@@ -741,7 +780,7 @@ static uint64_t intra_tree(intra_ctx *c, int x, int y, int log2n)
 void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
                              int w, int h, const orc_params *prm,
                              pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
-                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v)
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint64_t *est)
 {
     intra_ctx c;
     c.src[0] = src_y; c.src[1] = src_u; c.src[2] = src_v;
@@ -752,6 +791,7 @@ void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_
     c.cu = cu; c.w = w; c.h = h; c.w8 = w >> 3; c.prm = prm;
     for (int y = 0; y < h; y += ORC_CTU)
         for (int x = 0; x < w; x += ORC_CTU) intra_tree(&c, x, y, ORC_CTU_LOG2);
+    if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, NULL);
 }
 
 /* ================================================================================================

@@ -99,12 +99,13 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                              int w, int h, const orc_params *prm, const int16_t *centers /*2 per CTU or NULL*/,
                              pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
                              orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
-                             int32_t *me_dump /* optional: per CTU 21*(mvx,mvy,cost) after integer search, or NULL */);
+                             int32_t *me_dump /* optional: per CTU 21*(mvx,mvy,cost) after integer search, or NULL */,
+                             uint64_t *est /* optional: picture rate estimate in 1/16 bit */);
 /* K2+K3: intra (I) frame */
 void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
                              int w, int h, const orc_params *prm,
                              pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
-                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v);
+                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, uint64_t *est);
 /* K4a: deblocking, in place on rec_* (clause 8.7.2) */
 void orc_deblock_frame(pix *rec_y, pix *rec_u, pix *rec_v, int stride, int cstride, int w, int h,
                        const orc_cu_rec *cu, int bit_depth, int deblock_chroma_qp_offset);

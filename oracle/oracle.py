@@ -189,13 +189,16 @@ class Analysis:
         self.coef_u = np.zeros((h // 2, w // 2), np.int16)
         self.coef_v = np.zeros((h // 2, w // 2), np.int16)
         self.me = None
+        self.est = 0
 
 
 def analyze_intra(src: Frame, prm: Params) -> Analysis:
     h, w = src.shape
     a = Analysis(h, w)
+    est = C.c_uint64(0)
     lib().orc_analyze_intra_frame(_p(src.y), _p(src.u), _p(src.v), w, w // 2, w, h, C.byref(prm),
-                                  _p(a.rec.y), _p(a.rec.u), _p(a.rec.v), w, w // 2, _p(a.cu), _p(a.coef_y), _p(a.coef_u), _p(a.coef_v))
+                                  _p(a.rec.y), _p(a.rec.u), _p(a.rec.v), w, w // 2, _p(a.cu), _p(a.coef_y), _p(a.coef_u), _p(a.coef_v), C.byref(est))
+    a.est = est.value
     return a
 
 
@@ -213,12 +216,14 @@ def analyze_inter(src: Frame, ref: Frame, prm: Params, centers=None, dump_me=Fal
     if centers is not None:
         cen = np.ascontiguousarray(centers, dtype=np.int16).reshape(n_ctu, 2)
     me = np.zeros((n_ctu, 21, 3), np.int32) if dump_me else None
+    est = C.c_uint64(0)
     lib().orc_analyze_inter_frame(_p(src.y), _p(src.u), _p(src.v), w, w // 2,
                                   C.c_void_p(by), C.c_void_p(bu), C.c_void_p(bv), sy, sc, w, h, C.byref(prm),
                                   _p(cen) if cen is not None else None,
                                   _p(a.rec.y), _p(a.rec.u), _p(a.rec.v), w, w // 2, _p(a.cu), _p(a.coef_y), _p(a.coef_u), _p(a.coef_v),
-                                  _p(me) if me is not None else None)
+                                  _p(me) if me is not None else None, C.byref(est))
     a.me = me
+    a.est = est.value
     return a
 
 

@@ -43,7 +43,7 @@ static CostParams to_prm(const mihevc_cost_params *p)
 template <typename T>
 static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const T *ru, const T *rv, int w, int h,
                        const mihevc_cost_params *prm, const int16_t *centers, T *oy, T *ou, T *ov, mihevc_cu_rec *cu,
-                       int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump)
+                       int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump, unsigned long long *est)
 {
     Padded<T> ref0(w, h, PAD_Y), ref1(w / 2, h / 2, PAD_C), ref2(w / 2, h / 2, PAD_C);
     ref0.load(ry, w, h); ref1.load(ru, w / 2, h / 2); ref2.load(rv, w / 2, h / 2);
@@ -52,7 +52,8 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     a.ref[0] = {ref0.plane.p, ref0.stride}; a.ref[1] = {ref1.plane.p, ref1.stride}; a.ref[2] = {ref2.plane.p, ref2.stride};
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU;
-    a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv;
+    a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est;
+    if (est) *est = 0;
     int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU), R = a.prm.me_range;
     std::vector<int32_t> me((size_t)n_ctu * 63);
     a.me = me.data();
@@ -75,13 +76,14 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
 
 template <typename T>
 static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, const mihevc_cost_params *prm, T *oy, T *ou, T *ov,
-                       mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+                       mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv, unsigned long long *est)
 {
     IntraArgs<T> a;
     a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU;
-    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv;
+    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est;
+    if (est) *est = 0;
     SeqExec ex;
     // same launch order as the device: one anti-diagonal (cx + 2 cy) at a time
     for (int d = 0; d <= (a.ctus_w - 1) + 2 * (a.ctus_h - 1); d++) {
@@ -130,20 +132,20 @@ static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, 
 extern "C" {
 int emu_inter_frame(const void *sy, const void *su, const void *sv, const void *ry, const void *ru, const void *rv, int w, int h,
                     const mihevc_cost_params *prm, const int16_t *centers, void *oy, void *ou, void *ov, mihevc_cu_rec *cu,
-                    int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump)
+                    int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump, unsigned long long *est)
 {
     if (prm->bit_depth == 8)
         return inter_frame<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (const uint8_t *)ry, (const uint8_t *)ru,
-                                    (const uint8_t *)rv, w, h, prm, centers, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv, me_dump);
+                                    (const uint8_t *)rv, w, h, prm, centers, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv, me_dump, est);
     return inter_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)ry, (const uint16_t *)ru,
-                                 (const uint16_t *)rv, w, h, prm, centers, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv, me_dump);
+                                 (const uint16_t *)rv, w, h, prm, centers, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv, me_dump, est);
 }
 int emu_intra_frame(const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *oy, void *ou, void *ov,
-                    mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv)
+                    mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv, unsigned long long *est)
 {
     if (prm->bit_depth == 8)
-        return intra_frame<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, w, h, prm, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv);
-    return intra_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, w, h, prm, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv);
+        return intra_frame<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, w, h, prm, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv, est);
+    return intra_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, w, h, prm, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv, est);
 }
 int emu_deblock(void *y, void *u, void *v, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
 {

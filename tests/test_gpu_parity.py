@@ -150,3 +150,40 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
         assert dec[i].same(enc_rec), f"frame {i}: decoded picture != encoder reconstruction"
     if bd == 10:
         assert info["sei.mdcv.gx"] == 13250 and info["sei.cll.max_cll"] == 1000 and info["sps.profile_idc"] == 2
+
+
+def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
+    """VBV-capped constant quality: per-GOP bits stay near vbv-maxrate, QP never drops below the CRF floor, and the
+    stream still decodes to the encoder reconstruction == oracle pipeline replayed with the per-picture QPs."""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder
+    w, h, n, keyint, bd = 192, 128, 24, 12, 8
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.me_range, cfg.gops_in_flight = w, h, keyint, 2, 8, 2
+    cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = 19, -1, 150, 180
+    frames = [util.synth_frame(h, w, seed=21, shift=(2 * i, i), bit_depth=bd) for i in range(n)]
+    stream = b""
+    with Encoder(cfg, device=0, keep_recon=True) as enc:
+        for f in frames:
+            enc.send(*util.planes(f, bd))
+        enc.flush()
+        sizes = []
+        for data, pts, key in enc.packets():
+            stream += data
+            sizes.append(len(data) * 8)
+        infos = [enc.frame_info(i) for i in range(n)]
+        recs = [O.Frame(*enc.recon(i)) for i in range(n)]
+    dec, _ = O.decode(stream)
+    assert len(dec) == n and all(d.same(r) for d, r in zip(dec, recs))
+    qps = [q for q, _, _ in infos]
+    assert all(t == (2 if i % keyint == 0 else 1) for i, (_, t, _) in enumerate(infos))
+    assert min(qps[1:keyint]) >= cfg.crf + 2 and max(qps) > cfg.crf + 2          # the cap had to raise QP on this clip
+    budget = cfg.vbv_maxrate_kbps * 1000 * keyint / 30.0
+    for g in range(n // keyint):
+        assert sum(sizes[g * keyint:(g + 1) * keyint]) <= 1.35 * budget, (g, sum(sizes[g * keyint:(g + 1) * keyint]), budget)
+    ref = None
+    for i, f in enumerate(frames):
+        prm, _ = lib_params(lib, qps[i], bd, 8)
+        a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
+        ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
+        assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"

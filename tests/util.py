@@ -78,9 +78,10 @@ class StageApi:
         s = planes(src, bd)
         o = [np.zeros_like(p) for p in s]
         a = O.Analysis(h, w)
+        est = C.c_uint64(0)
         self._call("intra_frame", ptr(s[0]), ptr(s[1]), ptr(s[2]), w, h, C.byref(prm), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(a.cu), ptr(a.coef_y),
-                   ptr(a.coef_u), ptr(a.coef_v))
-        a.rec = to_frame(o)
+                   ptr(a.coef_u), ptr(a.coef_v), C.byref(est))
+        a.rec, a.est = to_frame(o), est.value
         return a
 
     def inter(self, src: O.Frame, ref: O.Frame, prm, centers=None):
@@ -90,10 +91,11 @@ class StageApi:
         o = [np.zeros_like(p) for p in s]
         a = O.Analysis(h, w)
         me = np.zeros((n_ctus(w, h), 21, 3), np.int32)
+        est = C.c_uint64(0)
         cen = np.ascontiguousarray(centers, dtype=np.int16) if centers is not None else None
         self._call("inter_frame", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(r[0]), ptr(r[1]), ptr(r[2]), w, h, C.byref(prm),
-                   ptr(cen) if cen is not None else None, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(a.cu), ptr(a.coef_y), ptr(a.coef_u), ptr(a.coef_v), ptr(me))
-        a.rec, a.me = to_frame(o), me
+                   ptr(cen) if cen is not None else None, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(a.cu), ptr(a.coef_y), ptr(a.coef_u), ptr(a.coef_v), ptr(me), C.byref(est))
+        a.rec, a.me, a.est = to_frame(o), me, est.value
         return a
 
     def deblock(self, rec: O.Frame, cu, bd):
@@ -114,7 +116,7 @@ class StageApi:
 
 def same_analysis(a, b):
     return (a.rec.same(b.rec) and np.array_equal(a.cu, b.cu) and np.array_equal(a.coef_y, b.coef_y) and
-            np.array_equal(a.coef_u, b.coef_u) and np.array_equal(a.coef_v, b.coef_v))
+            np.array_equal(a.coef_u, b.coef_u) and np.array_equal(a.coef_v, b.coef_v) and a.est == b.est)
 
 
 def describe_diff(a, b):
@@ -130,6 +132,8 @@ def describe_diff(a, b):
     for n in ("coef_y", "coef_u", "coef_v"):
         if not np.array_equal(getattr(a, n), getattr(b, n)):
             out.append(f"{n} differs")
+    if a.est != b.est:
+        out.append(f"rate estimate {a.est} vs {b.est}")
     return "; ".join(out) or "identical"
 
 
