@@ -400,7 +400,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
         int qp = s->qp_p;
         if (ref_bits > 0) qp = (int)std::lround(ref_qp + 6.0 * std::log2(ref_bits / target));
         qp = std::max(qp, s->qp_p);                                  // the CRF is the quality ceiling, the VBV only raises QP
-        if (t > 1) qp = std::min(std::max(qp, qp_prev[g] - 2), qp_prev[g] + 2);
+        if (t == 1) qp = std::max(qp, qp_prev[g] + 2);                 // first P: never finer than its IDR + 2
+        else qp = std::min(std::max(qp, qp_prev[g] - 2), qp_prev[g] + 4);
         return std::min(qp, 51);
     };
     auto patch_qp = [&](int t, int g, int qp) {
@@ -423,6 +424,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
         // the copy of step t - kRing has completed (its jobs waited for it); compute may now reuse the device slot
         StepView<T> dv(da, lay, t);
         std::vector<int> qp_step(B);
+        if (s->rc_on)       // estimates of earlier steps whose D2H copy has landed (no wait): they lead CABAC by several steps
+            for (int j = std::max(1, t - kRing + 1); j < t; j++) {
+                if (hipEventQuery(s->ev_copy[j % kRing]) != hipSuccess) continue;
+                std::lock_guard<std::mutex> l(s->m);
+                for (int g = 0; g < batch[j]; g++) {
+                    auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
+                    if (!fr.est_known) { fr.est_q4 = *(const unsigned long long *)(s->lane[g].sym_host[j % kRing] + sl.est); fr.est_known = true; }
+                }
+            }
         for (int g = 0; g < B; g++) {
             qp_step[g] = t == 0 ? s->qp_i : (s->rc_on ? decide_p(g, t) : s->qp_p);
             patch_qp(t, g, qp_step[g]);
@@ -461,8 +471,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
             double pred = (double)e / 16.0 * s->ratio_i, alloc = budget[g] * w_i / (w_i + gop_len[g] - 1);
             if (pred > 1.1 * alloc) {
                 int q = std::min(51, qp_step[g] + (int)std::ceil(6.0 * std::log2(pred / alloc)));
-                if (q != qp_step[g]) { qp_step[g] = q; patch_qp(t, g, q); qp_prev[g] = q + 3; again = true; }
+                if (q != qp_step[g]) { qp_step[g] = q; patch_qp(t, g, q); qp_prev[g] = q; again = true; continue; }
             }
+            std::lock_guard<std::mutex> l(s->m);           // estimate of the version that will be coded
+            auto &fr = s->frames[(size_t)(first_index + g * s->keyint)];
+            fr.est_q4 = e; fr.est_known = true;
         }
         if (!again) break;
         }

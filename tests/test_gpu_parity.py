@@ -157,10 +157,10 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     stream still decodes to the encoder reconstruction == oracle pipeline replayed with the per-picture QPs."""
     from hevc_amd import _lib
     from hevc_amd.encoder import Encoder
-    w, h, n, keyint, bd = 192, 128, 24, 12, 8
+    w, h, n, keyint, bd = 192, 128, 40, 20, 8
     cfg = _lib.default_config()
     cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.me_range, cfg.gops_in_flight = w, h, keyint, 2, 8, 2
-    cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = 19, -1, 150, 180
+    cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = 19, -1, 200, 240
     frames = [util.synth_frame(h, w, seed=21, shift=(2 * i, i), bit_depth=bd) for i in range(n)]
     stream = b""
     with Encoder(cfg, device=0, keep_recon=True) as enc:
@@ -180,7 +180,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     assert min(qps[1:keyint]) >= cfg.crf + 2 and max(qps) > cfg.crf + 2          # the cap had to raise QP on this clip
     budget = cfg.vbv_maxrate_kbps * 1000 * keyint / 30.0
     for g in range(n // keyint):
-        assert sum(sizes[g * keyint:(g + 1) * keyint]) <= 1.35 * budget, (g, sum(sizes[g * keyint:(g + 1) * keyint]), budget)
+        assert sum(sizes[g * keyint:(g + 1) * keyint]) <= 1.5 * budget, (g, sum(sizes[g * keyint:(g + 1) * keyint]), budget)
     ref = None
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
