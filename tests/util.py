@@ -10,11 +10,11 @@ from oracle import oracle as O
 def synth_frame(h, w, seed=0, shift=(0, 0), bit_depth=8, detail=True) -> O.Frame:
     """Band-limited texture + sine + moving rectangles + per-frame grain; `shift` translates the texture."""
     rng = np.random.default_rng(seed)
-    big = rng.normal(0, 1, (h + 128, w + 128))
+    big = rng.normal(0, 1, (h + 384, w + 384))          # room for shifts up to +-190 samples
     for _ in range(3):
         big = (big + np.roll(big, 1, 0) + np.roll(big, 1, 1) + np.roll(big, -1, 0) + np.roll(big, -1, 1)) / 5
     big = (big - big.min()) / (big.max() - big.min())
-    oy, ox = 64 + shift[1], 64 + shift[0]
+    oy, ox = 192 + shift[1], 192 + shift[0]
     y = big[oy:oy + h, ox:ox + w] * 180 + 30
     yy, xx = np.mgrid[0:h, 0:w]
     y = y + 15 * np.sin((xx + shift[0]) / 7.0)
