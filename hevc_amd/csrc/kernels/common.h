@@ -199,6 +199,26 @@ DEV uint32_t align_bytes(uint32_t hi, uint32_t lo, int shift_bytes)     // ({hi,
     return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> (8 * shift_bytes));
 #endif
 }
+// Copy a w x h window (w a multiple of 4 samples... of 4 BYTES for 8-bit, 2 samples for 16-bit) of a padded plane into
+// an LDS image with row stride ls, one dword per lane-iteration and no integer division: lanes are laid out as 32
+// dword-columns x 8 rows.  Source coordinates are clamped into the plane's border so partial CTUs at the picture edge
+// never read outside the allocation (the clamped samples are never used).
+template <typename T>
+DEV void copy_window(T *lds, int ls, const T *plane, int pstride, int ox, int oy, int w, int h, int lo_x, int hi_x, int lo_y, int hi_y, int tid)
+{
+    constexpr int per = 4 / (int)sizeof(T);            // samples per dword
+    const int dpr = w / per, col = tid & 31, rg = tid >> 5;
+    for (int r = rg; r < h; r += NT / 32) {
+        const int y = clip3(lo_y, hi_y, oy + r);
+        const T *srow = plane + (ptrdiff_t)y * pstride;
+        for (int d = col; d < dpr; d += 32) {
+            const int x = clip3(lo_x, hi_x - (per - 1), ox + d * per);
+            uint32_t v = load_u32(srow + x);
+            __builtin_memcpy(__builtin_assume_aligned(lds + r * ls + d * per, 4), &v, 4);
+        }
+    }
+}
+
 // returns 0 in a way the optimiser cannot see through: stops loop-invariant hoisting of whole LDS tiles into VGPRs
 DEV int opaque_zero()
 {

@@ -83,11 +83,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
             int x = x0 + (i & 31), y = y0 + (i >> 5);
             s.src[i] = (x < a.w && y < a.h) ? a.src[0].p[(size_t)y * a.src[0].stride + x] : (T)0;
         }
-        for (int i = tid; i < ww * wh; i += NT) {
-            int wx = i % ww, wy = i / ww;
-            int x = clip3(-PAD_Y, a.w + PAD_Y - 1, x0 + sx - R + wx), y = clip3(-PAD_Y, a.h + PAD_Y - 1, y0 + sy - R + wy);
-            win[wy * ws + wx] = a.ref[0].p[(ptrdiff_t)y * a.ref[0].stride + x];
-        }
+        copy_window<T>(win, ws, a.ref[0].p, a.ref[0].stride, x0 + sx - R, y0 + sy - R, ww, wh, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, tid);
         if (tid < 21) {
             int nx, ny, nl;
             node_geom(tid, nx, ny, nl);
@@ -181,9 +177,9 @@ template <typename T> struct InterShared {
     // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
 };
 // motion-compensation windows cover every vector the search can return: |mv| <= R + 3 (widened horizontal span)
-HDI int mc_win_y(int R) { return 32 + 2 * (R + 3) + 8; }
+HDI int mc_win_y(int R) { return (32 + 2 * (R + 3) + 8 + 3) & ~3; }
 HDI int mc_win_y_stride(int R) { return mc_win_y(R) + 4; }
-HDI int mc_win_c(int R) { return 16 + (R + 3) + 8; }
+HDI int mc_win_c(int R) { return (16 + (R + 3) + 8 + 3) & ~3; }
 HDI int mc_win_c_stride(int R) { return mc_win_c(R) + 4; }
 
 // quarter-sample luma prediction of one 8x8 tile from the LDS window (8.5.3.3.3.1; the general 2-D form with the
@@ -232,6 +228,31 @@ DEV int luma_tile(const T *win, int i00, int ws, int fx, int fy, int bit_depth, 
     return diff_src ? hadamard8_satd(acc) : 0;
 }
 
+// four horizontally adjacent predicted luma samples (8.5.3.3.3.1) starting at window element i00: the final motion
+// compensation of a CTU spread over all 256 lanes (16 tiles x 8 rows x 2 halves)
+template <typename T>
+DEV void luma_quad(const T *win, int i00, int ws, int fx, int fy, int bit_depth, T *out)
+{
+    const int8_t *tx = g_tab.luma_tap[fx], *ty = g_tab.luma_tap[fy];
+    const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int px[15];
+        load_row15(win, i00 + (r - 3) * ws - 3, px);
+        const int t = ty[r];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v += tx[k] * px[i + k];
+            acc[i] += t * (v >> shift1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = (T)clip3(0, maxv, ((acc[i] >> 6) + (1 << (shift3 - 1))) >> shift3);
+}
+
 template <typename T>
 DEV int chroma_sample(const T *p00, int ws, int fx, int fy, int bit_depth)
 {
@@ -264,16 +285,9 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
             s.src[i] = (gx < pw && gy < ph) ? a.src[pl].p[(size_t)gy * a.src[pl].stride + gx] : (T)0;
         }
-        for (int i = tid; i < wy * wy; i += NT) {
-            int cx = i % wy, cy = i / wy;
-            int x = clip3(-PAD_Y, a.w + PAD_Y - 1, oy_x + cx), y = clip3(-PAD_Y, a.h + PAD_Y - 1, oy_y + cy);
-            win_y[cy * wys + cx] = a.ref[0].p[(ptrdiff_t)y * a.ref[0].stride + x];
-        }
-        for (int i = tid; i < 2 * wc * wc; i += NT) {
-            int pl = i >= wc * wc, k = pl ? i - wc * wc : i, cx = k % wc, cy = k / wc;
-            int x = clip3(-PAD_C, (a.w >> 1) + PAD_C - 1, oc_x + cx), y = clip3(-PAD_C, (a.h >> 1) + PAD_C - 1, oc_y + cy);
-            (pl ? win_v : win_u)[cy * wcs + cx] = a.ref[1 + pl].p[(ptrdiff_t)y * a.ref[1 + pl].stride + x];
-        }
+        copy_window<T>(win_y, wys, a.ref[0].p, a.ref[0].stride, oy_x, oy_y, wy, wy, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, tid);
+        copy_window<T>(win_u, wcs, a.ref[1].p, a.ref[1].stride, oc_x, oc_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
+        copy_window<T>(win_v, wcs, a.ref[2].p, a.ref[2].stride, oc_x, oc_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
         if (tid < 21) {
             const int32_t *m = a.me + ((size_t)ctu * 21 + tid) * 3;
             s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.valid[tid] = m[2] >= 0; s.cost[tid] = 0;
@@ -348,23 +362,22 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.rs.tu_intra[t] = 0;
         }
     });
-    // motion compensation of the chosen CUs: luma per 8x8 tile (threads 0..15), chroma per sample (threads 64..255)
+    // motion compensation of the chosen CUs: every lane predicts 4 luma samples and 2 chroma samples
     ex.phase([&](int tid) {
-        if (tid < 16) {
-            int t = tid, txp = t & 3, typ = t >> 2;
+        {
+            const int t = tid >> 4, j = (tid >> 1) & 7, hx = (tid & 1) * 4, txp = t & 3, typ = t >> 2;
             if (s.rs.tu_log2[t]) {
                 int mx = s.tile_mvx[t], my = s.tile_mvy[t];
-                int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                luma_tile<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, nullptr, 0, s.pred + typ * 8 * 32 + txp * 8, 32);
+                int px = x0 + txp * 8 + hx + (mx >> 2) - oy_x, py = y0 + typ * 8 + j + (my >> 2) - oy_y;
+                luma_quad<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, s.pred + (typ * 8 + j) * 32 + txp * 8 + hx);
             }
-        } else if (tid >= 64) {
-            for (int i = tid - 64; i < 512; i += NT - 64) {
-                int pl = i >> 8, k = i & 255, x = k & 15, y = k >> 4, t = (y >> 2) * 4 + (x >> 2);
-                if (!s.rs.tu_log2[t]) continue;
-                int mx = s.tile_mvx[t], my = s.tile_mvy[t];
-                int px = (x0 >> 1) + x + (mx >> 3) - oc_x, py = (y0 >> 1) + y + (my >> 3) - oc_y;
-                s.pred[1024 + i] = (T)chroma_sample<T>((pl ? win_v : win_u) + py * wcs + px, wcs, mx & 7, my & 7, bd);
-            }
+        }
+        for (int i = tid; i < 512; i += NT) {
+            int pl = i >> 8, k = i & 255, x = k & 15, y = k >> 4, t = (y >> 2) * 4 + (x >> 2);
+            if (!s.rs.tu_log2[t]) continue;
+            int mx = s.tile_mvx[t], my = s.tile_mvy[t];
+            int px = (x0 >> 1) + x + (mx >> 3) - oc_x, py = (y0 >> 1) + y + (my >> 3) - oc_y;
+            s.pred[1024 + i] = (T)chroma_sample<T>((pl ? win_v : win_u) + py * wcs + px, wcs, mx & 7, my & 7, bd);
         }
     });
     ex.phase([&](int tid) {
