@@ -28,7 +28,7 @@ template <typename T> __global__ __launch_bounds__(NT, 3) void k_me_search(const
     me_search_program<T>(ex, s, win, a, ctu);
 }
 
-template <typename T> __global__ __launch_bounds__(NT) void k_inter_ctu(const InterArgs<T> *args, int n_ctu)
+template <typename T> __global__ __launch_bounds__(NT, 3) void k_inter_ctu(const InterArgs<T> *args, int n_ctu)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ctu = xcd_remap(blockIdx.x, n_ctu);
@@ -139,7 +139,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const S
 // ------------------------------------------------------------------------------------------ launchers
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch)
 {
-    hipLaunchKernelGGL(k_frame_sse<T>, dim3(64, (unsigned)batch), dim3(256), 0, st, d_args);
+    hipLaunchKernelGGL(k_frame_sse<T>, dim3(1024, (unsigned)batch), dim3(256), 0, st, d_args);
     return hipGetLastError();
 }
 template <typename K> static hipError_t ensure_smem(K kernel, size_t bytes)

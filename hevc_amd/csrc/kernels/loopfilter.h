@@ -104,11 +104,14 @@ template <typename T> struct SaoArgs {
 };
 
 struct SaoShared {
-    int eo_n[3][4][5], eo_s[3][4][5], bo_n[3][32], bo_s[3][32];
+    int eo_n[3][4][5], eo_s[3][4][5], bo_n[3][32], bo_s[3][32];     // (these four first: zeroed as one int run)
     int8_t bo_off[3][32];
     long long bo_cost[3][32];
     int8_t eo_off[3][4][4];
     long long eo_cost[3][4];
+    // deblocked CTB + 1-sample halo, staged once with row-contiguous loads: every sample's 8 neighbours are then LDS reads
+    uint16_t tile_y[34 * 36];
+    uint16_t tile_c[2][18 * 20];
 };
 
 DEVCONST int8_t kEoDx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};
@@ -151,7 +154,14 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
     const int maxoff = (1 << (imin(bd, 10) - 5)) - 1;
     ex.phase([&](int tid) {
         int *z = &s.eo_n[0][0][0];
-        for (int i = tid; i < (int)(sizeof(SaoShared) / sizeof(int)); i += NT) z[i] = 0;   // whole struct is int-aligned
+        for (int i = tid; i < 3 * (20 + 20 + 32 + 32); i += NT) z[i] = 0;
+        for (int i = tid; i < 34 * 34 + 2 * 18 * 18; i += NT) {
+            int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), k = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
+            int tx = k % dim, ty = k / dim, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
+            int gx = clip3(0, pw - 1, (pl ? cx * 16 : cx * 32) + tx - 1), gy = clip3(0, ph - 1, (pl ? cy * 16 : cy * 32) + ty - 1);
+            uint16_t v = (uint16_t)a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+            if (pl) s.tile_c[pl - 1][ty * 20 + tx] = v; else s.tile_y[ty * 36 + tx] = v;
+        }
     });
     ex.phase([&](int tid) {
         for (int i = tid; i < 1536; i += NT) {
@@ -159,13 +169,19 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
             int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
             if (gx >= pw || gy >= ph) continue;
-            int r = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+            const uint16_t *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
+            const int ts = pl ? 20 : 36, ti = (y + 1) * ts + x + 1;
+            int r = tp[ti];
             int d = (int)a.src[pl].p[(ptrdiff_t)gy * a.src[pl].stride + gx] - r;
             int b = r >> (bd - 5);
             ex.atomic_add(&s.bo_n[pl][b], 1);
             ex.atomic_add(&s.bo_s[pl][b], d);
             for (int c = 0; c < 4; c++) {
-                int k = eo_category<T>(a.dbk[pl], gx, gy, pw, ph, c);
+                int xa = gx + kEoDx[c][0], ya = gy + kEoDy[c][0], xb = gx + kEoDx[c][1], yb = gy + kEoDy[c][1], k = 0;
+                if (!(xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph)) {
+                    int e = 2 + sgn3(r - tp[ti + kEoDy[c][0] * ts + kEoDx[c][0]]) + sgn3(r - tp[ti + kEoDy[c][1] * ts + kEoDx[c][1]]);
+                    k = e == 2 ? 0 : e < 2 ? e + 1 : e;
+                }
                 ex.atomic_add(&s.eo_n[pl][c][k], 1);
                 ex.atomic_add(&s.eo_s[pl][c][k], d);
             }

@@ -30,7 +30,9 @@ using namespace mihevc;
 
 namespace {
 
-constexpr int kRing = 8;      // symbol ring depth (steps in flight between device and CABAC workers)
+constexpr int kRing = 8;      // symbol slots per lane: 0..2 hold the IDR picture's QP variants, 3..7 rotate over the P steps
+constexpr int kVariants = 3;  // IDR pictures under rate control are analysed at QP, QP+5, QP+10 in ONE set of launches
+constexpr int kVariantStep = 5;
 
 class ThreadPool {
 public:
@@ -152,6 +154,7 @@ struct mihevc_session {
     struct Lane {
         void *rec_base[2][3], *rec_p[2][3]; int rec_stride[3];       // padded final reconstructions (ping-pong)
         void *work_base[3], *work_p[3]; int work_stride[3];           // pre-deblock / deblocked picture (unpadded)
+        void *var_base[kVariants - 1][3], *var_p[kVariants - 1][3];   // work pictures of IDR variants 1..
         int32_t *me = nullptr;
         uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
     };
@@ -222,6 +225,8 @@ int ensure_lanes(mihevc_session *s, int n)
         for (int k = 0; k < 2; k++)
             if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, true)) return e;
         if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, false)) return e;
+        for (int v = 0; v < kVariants - 1; v++)
+            if (int e = alloc_planes(s, L.var_base[v], L.var_p[v], L.work_stride, false)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         for (int k = 0; k < kRing; k++) {
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
@@ -239,7 +244,7 @@ template <typename T> struct StepLayout {
     {
         auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
         intra = 0;
-        inter = al(intra + gops * sizeof(IntraArgs<T>));
+        inter = al(intra + (size_t)kVariants * gops * sizeof(IntraArgs<T>));
         dbk_v = al(inter + gops * sizeof(InterArgs<T>));
         dbk_h = al(dbk_v + gops * sizeof(DeblockArgs<T>));
         sao = al(dbk_h + gops * sizeof(DeblockArgs<T>));
@@ -308,6 +313,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     if (int e = ensure_lanes(s, gops)) return e;
     SymLayout sl(s->w, s->h);
     const int steps = std::min(n, s->keyint);
+    auto slot_of = [](int t) { return t == 0 ? 0 : kVariants + (t - 1) % (kRing - kVariants); };      // IDR variant v lives in slot v
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
     const size_t need = (size_t)steps * lay.total;
@@ -340,7 +346,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             mihevc_session::Src &src = s->pending[fi];
             StepView<T> hv(ha, lay, t);
             struct { IntraArgs<T> &intra; InterArgs<T> &inter; DeblockArgs<T> &dbk_v, &dbk_h; SaoArgs<T> &sao; } A{hv.intra[g], hv.inter[g], hv.dbk_v[g], hv.dbk_h[g], hv.sao[g]};
-            uint8_t *sym = L.sym_dev[t % kRing];
+            uint8_t *sym = L.sym_dev[slot_of(t)];
             const int cur = t & 1, prev = cur ^ 1;
             const CostParams P = prm_for(t == 0 ? s->qp_i : s->qp_p);      // provisional; the controller patches it per step
             for (int i = 0; i < 3; i++) {
@@ -415,22 +421,31 @@ template <typename T> int encode_chunk(mihevc_session *s)
     hipEvent_t t_begin, t_end;
     HIPCK(s, hipEventCreate(&t_begin)); HIPCK(s, hipEventCreate(&t_end));
     HIPCK(s, hipEventRecord(t_begin, s->st_compute));
+    auto mark = [&](int stage, int pictures, bool begin) -> int {       // bracket a stage with events when profiling
+        if (!s->cfg.profile_stages) return 0;
+        size_t need_ev = s->marks.size() * 2 + 2;
+        while (s->ev_pool.size() < need_ev) { hipEvent_t e; HIPCK(s, hipEventCreate(&e)); s->ev_pool.push_back(e); }
+        if (begin) { s->marks.push_back({stage, pictures, s->marks.size() * 2}); HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev], s->st_compute)); }
+        else HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev + 1], s->st_compute));
+        return 0;
+    };
+#define STAGE(idx, pics, call) do { if (int e_ = mark(idx, pics, true)) return e_; HIPCK(s, call); if (int e_ = mark(idx, pics, false)) return e_; } while (0)
     for (int t = 0; t < steps; t++) {
-        const int slot = t % kRing, B = batch[t];
-        {   // ring wrap: the slot's previous CABAC jobs must be done before the device overwrites its symbols
+        const int B = batch[t], nv = (t == 0 && s->rc_on) ? kVariants : 1;
+        const int slot0 = slot_of(t);
+        {   // the slots this step writes must have been drained by their previous CABAC jobs
             std::unique_lock<std::mutex> l(s->m);
-            s->cv.wait(l, [&] { return s->jobs_open[slot] == 0; });
+            s->cv.wait(l, [&] { for (int v = 0; v < nv; v++) if (s->jobs_open[slot0 + v]) return false; return true; });
         }
-        // the copy of step t - kRing has completed (its jobs waited for it); compute may now reuse the device slot
-        StepView<T> dv(da, lay, t);
-        std::vector<int> qp_step(B);
+        StepView<T> dv(da, lay, t), hv(ha, lay, t);
+        std::vector<int> qp_step(B), lane_slot(B, slot0);
         if (s->rc_on)       // estimates of earlier steps whose D2H copy has landed (no wait): they lead CABAC by several steps
-            for (int j = std::max(1, t - kRing + 1); j < t; j++) {
-                if (hipEventQuery(s->ev_copy[j % kRing]) != hipSuccess) continue;
+            for (int j = std::max(1, t - (kRing - kVariants) + 1); j < t; j++) {
+                if (hipEventQuery(s->ev_copy[slot_of(j)]) != hipSuccess) continue;
                 std::lock_guard<std::mutex> l(s->m);
                 for (int g = 0; g < batch[j]; g++) {
                     auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
-                    if (!fr.est_known) { fr.est_q4 = *(const unsigned long long *)(s->lane[g].sym_host[j % kRing] + sl.est); fr.est_known = true; }
+                    if (!fr.est_known) { fr.est_q4 = *(const unsigned long long *)(s->lane[g].sym_host[slot_of(j)] + sl.est); fr.est_known = true; }
                 }
             }
         for (int g = 0; g < B; g++) {
@@ -438,52 +453,74 @@ template <typename T> int encode_chunk(mihevc_session *s)
             patch_qp(t, g, qp_step[g]);
             qp_prev[g] = qp_step[g];
         }
-        for (int attempt = 0; attempt < 2; attempt++) {
-        HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
-        for (int g = 0; g < B; g++)      // zero the slot's SSE + estimate accumulators
-            HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
-        auto mark = [&](int stage, bool begin) -> int {       // bracket a stage with events when profiling
-            if (!s->cfg.profile_stages) return 0;
-            size_t need_ev = s->marks.size() * 2 + 2;
-            while (s->ev_pool.size() < need_ev) { hipEvent_t e; HIPCK(s, hipEventCreate(&e)); s->ev_pool.push_back(e); }
-            if (begin) { s->marks.push_back({stage, B, s->marks.size() * 2}); HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev], s->st_compute)); }
-            else HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev + 1], s->st_compute));
-            return 0;
-        };
-#define STAGE(idx, call) do { if (int e_ = mark(idx, true)) return e_; HIPCK(s, call); if (int e_ = mark(idx, false)) return e_; } while (0)
-        if (t == 0) STAGE(0, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B));
-        else {
-            STAGE(1, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
-            STAGE(2, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
-        }
-        STAGE(3, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
-        STAGE(4, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
-        STAGE(5, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
-        STAGE(6, launch_frame_sse<T>(s->st_compute, dv.sao, B));
-        // IDR pictures under rate control: read the device's rate estimate and re-run the step once when a picture
-        // would overshoot its share of the GOP budget (there is no earlier picture to learn from)
-        if (!(s->rc_on && t == 0 && attempt == 0)) break;
-        HIPCK(s, hipStreamSynchronize(s->st_compute));
-        bool again = false;
-        for (int g = 0; g < B; g++) {
-            unsigned long long e = 0;
-            HIPCK(s, hipMemcpy(&e, s->lane[g].sym_dev[slot] + sl.est, sizeof e, hipMemcpyDeviceToHost));
-            double pred = (double)e / 16.0 * s->ratio_i, alloc = budget[g] * w_i / (w_i + gop_len[g] - 1);
-            if (pred > 1.1 * alloc) {
-                int q = std::min(51, qp_step[g] + (int)std::ceil(6.0 * std::log2(pred / alloc)));
-                if (q != qp_step[g]) { qp_step[g] = q; patch_qp(t, g, q); qp_prev[g] = q; again = true; continue; }
+        if (t == 0) {
+            // IDR pictures: under rate control every lane is analysed at kVariants QPs in the SAME anti-diagonal launches
+            // (the wavefront leaves most CUs idle, so the extra variants ride along almost for free); the device's rate
+            // estimates then pick, per lane, the finest variant that fits the picture's share of the GOP budget
+            for (int v = 1; v < nv; v++)
+                for (int g = 0; g < B; g++) {
+                    IntraArgs<T> &A = hv.intra[v * B + g];
+                    A = hv.intra[g];
+                    mihevc_session::Lane &L = s->lane[g];
+                    uint8_t *sym = L.sym_dev[v];
+                    for (int i = 0; i < 3; i++) A.rec[i] = mk<T>(L.var_p[v - 1][i], L.work_stride[i]);
+                    A.prm = prm_for(std::min(51, qp_step[g] + kVariantStep * v));
+                    A.cu = (mihevc_cu_rec *)(sym + sl.cu);
+                    A.coef[0] = (int16_t *)(sym + sl.cy); A.coef[1] = (int16_t *)(sym + sl.cu_); A.coef[2] = (int16_t *)(sym + sl.cv);
+                    A.est = (unsigned long long *)(sym + sl.est);
+                }
+            HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
+            for (int v = 0; v < nv; v++)
+                for (int g = 0; g < B; g++)
+                    HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[v] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
+            STAGE(0, nv * B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, nv * B));
+            if (nv > 1) {
+                HIPCK(s, hipStreamSynchronize(s->st_compute));
+                for (int g = 0; g < B; g++) {
+                    const double alloc = budget[g] * w_i / (w_i + gop_len[g] - 1);
+                    unsigned long long e[kVariants] = {0};
+                    int pick = nv - 1;
+                    for (int v = 0; v < nv; v++) HIPCK(s, hipMemcpy(&e[v], s->lane[g].sym_dev[v] + sl.est, sizeof e[v], hipMemcpyDeviceToHost));
+                    for (int v = 0; v < nv; v++)
+                        if ((double)e[v] / 16.0 * s->ratio_i <= 1.1 * alloc) { pick = v; break; }
+                    lane_slot[g] = pick;
+                    qp_step[g] = std::min(51, qp_step[g] + kVariantStep * pick);
+                    patch_qp(t, g, qp_step[g]);
+                    qp_prev[g] = qp_step[g];
+                    {
+                        std::lock_guard<std::mutex> l(s->m);
+                        auto &fr = s->frames[(size_t)(first_index + g * s->keyint)];
+                        fr.est_q4 = e[pick]; fr.est_known = true;
+                    }
+                    if (pick) {       // the loop filters and the symbol copy follow the chosen variant's buffers
+                        mihevc_session::Lane &L = s->lane[g];
+                        uint8_t *sym = L.sym_dev[pick];
+                        for (int i = 0; i < 3; i++) {
+                            hv.dbk_v[g].rec[i] = hv.dbk_h[g].rec[i] = mk<T>(L.var_p[pick - 1][i], L.work_stride[i]);
+                            hv.sao[g].dbk[i] = mkc<T>(L.var_p[pick - 1][i], L.work_stride[i]);
+                        }
+                        hv.dbk_v[g].cu = hv.dbk_h[g].cu = (const mihevc_cu_rec *)(sym + sl.cu);
+                        hv.sao[g].sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
+                        hv.sao[g].sse = (unsigned long long *)(sym + sl.sse);
+                    }
+                }
+                HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
             }
-            std::lock_guard<std::mutex> l(s->m);           // estimate of the version that will be coded
-            auto &fr = s->frames[(size_t)(first_index + g * s->keyint)];
-            fr.est_q4 = e; fr.est_known = true;
+        } else {
+            HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
+            for (int g = 0; g < B; g++)      // zero the slot's SSE + estimate accumulators
+                HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
+            STAGE(1, B, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
         }
-        if (!again) break;
-        }
-#undef STAGE
-        HIPCK(s, hipEventRecord(s->ev_compute[slot], s->st_compute));
-        HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot], 0));
+        STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
+        STAGE(4, B, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
+        STAGE(5, B, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
+        STAGE(6, B, launch_frame_sse<T>(s->st_compute, dv.sao, B));
+        HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));
+        HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot0], 0));
         for (int g = 0; g < B; g++)
-            HIPCK(s, hipMemcpyAsync(s->lane[g].sym_host[slot], s->lane[g].sym_dev[slot], sl.total, hipMemcpyDeviceToHost, s->st_copy));
+            HIPCK(s, hipMemcpyAsync(s->lane[g].sym_host[lane_slot[g]], s->lane[g].sym_dev[lane_slot[g]], sl.total, hipMemcpyDeviceToHost, s->st_copy));
         if (s->keep_recon) {
             for (int g = 0; g < B; g++) {
                 int fi = g * s->keyint + t;
@@ -501,14 +538,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 for (size_t k = 0; k < dst.size(); k++) dst[k] = s->is16 ? ((uint16_t *)tmp.data())[k] : tmp[k];
             }
         }
-        HIPCK(s, hipEventRecord(s->ev_copy[slot], s->st_copy));
+        for (int v = 0; v < nv; v++) HIPCK(s, hipEventRecord(s->ev_copy[slot0 + v], s->st_copy));
         {
             std::lock_guard<std::mutex> l(s->m);
-            s->jobs_open[slot] += B;
+            for (int g = 0; g < B; g++) s->jobs_open[lane_slot[g]]++;
         }
         for (int g = 0; g < B; g++) {
             int fi = g * s->keyint + t;
             int64_t index = s->frames_in - n + fi, pts = s->pending[fi].pts;
+            const int slot = lane_slot[g];
             hipEvent_t ev = s->ev_copy[slot];
             int st = t == 0 ? 2 : 1, qp = qp_step[g];
             bool first = index == 0;
@@ -518,6 +556,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             });
         }
     }
+#undef STAGE
     HIPCK(s, hipEventRecord(t_end, s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_copy));
@@ -737,6 +776,7 @@ void mihevc_close(mihevc_session *s)
     for (auto &x : s->free_src) free3(x.base, 0);
     for (auto &L : s->lane) {
         free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
+        for (int v = 0; v < kVariants - 1; v++) free3(L.var_base[v], 0);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
         for (int k = 0; k < kRing; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
