@@ -62,7 +62,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_deblock(const Deb
     deblock_segment<T>(args[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
 }
 
-template <typename T> __global__ __launch_bounds__(NT) void k_sao_decide(const SaoArgs<T> *args, int n_ctu)
+template <typename T> __global__ __launch_bounds__(NT, 4) void k_sao_decide(const SaoArgs<T> *args, int n_ctu)
 {
     __shared__ SaoShared s;
     const int ctu = xcd_remap(blockIdx.x, n_ctu);

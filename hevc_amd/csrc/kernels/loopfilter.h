@@ -115,6 +115,7 @@ struct SaoShared {
     // 16 private copies of the statistics (copy = lane & 15, odd stride -> distinct banks): neighbouring samples mostly
     // fall in the same category/band, and 64 lanes hitting one LDS word serialise (SQ_LDS_BANK_CONFLICT, r01 profiles)
     int priv[3][16][105];            // per copy: eo_n[4][5] | eo_s[4][5] | bo_n[32] | bo_s[32]
+    unsigned long long band_key[3];  // min over the 29 band positions of ((cost + bias) << 8 | position)
 };
 
 DEVCONST int8_t kEoDx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};
@@ -215,19 +216,24 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             s.eo_cost[pl][c] = cost;
         }
     });
+    ex.phase([&](int tid) {          // best band position per plane: 87 lanes, ties -> lowest position
+        if (tid < 3) s.band_key[tid] = ~0ull;
+    });
+    ex.phase([&](int tid) {
+        if (tid < 87) {
+            int pl = tid / 29, p = tid % 29;
+            long long c = s.bo_cost[pl][p] + s.bo_cost[pl][p + 1] + s.bo_cost[pl][p + 2] + s.bo_cost[pl][p + 3];
+            ex.atomic_min(&s.band_key[pl], ((unsigned long long)(c + (1ll << 50)) << 8) | (unsigned)p);
+        }
+    });
     ex.phase([&](int tid) {
         if (tid != 0) return;
         // candidates per plane in fixed order: 0 off, 1 band (best of 29 positions), 2..5 edge classes
         long long cost[3][6];
         int band[3];
         for (int pl = 0; pl < 3; pl++) {
-            long long bestb = 0;
-            int pos = -1;
-            for (int p = 0; p <= 28; p++) {
-                long long c = s.bo_cost[pl][p] + s.bo_cost[pl][p + 1] + s.bo_cost[pl][p + 2] + s.bo_cost[pl][p + 3];
-                if (pos < 0 || c < bestb) { bestb = c; pos = p; }
-            }
-            band[pl] = pos;
+            band[pl] = (int)(s.band_key[pl] & 255);
+            long long bestb = (long long)(s.band_key[pl] >> 8) - (1ll << 50);
             cost[pl][0] = 0;
             cost[pl][1] = bestb + (long long)lam * 7;
             for (int c = 0; c < 4; c++) cost[pl][2 + c] = s.eo_cost[pl][c];

@@ -187,3 +187,53 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"
+
+
+def test_convert_video_end_to_end_on_the_gpu(tmp_path):
+    """The boundary itself: convert_video on a .y4m clip -> method MI355X, an hvc1 MP4 whose samples decode (oracle
+    decoder) to pictures close to the source; progress and the six-key result dict as in the reference."""
+    import threading
+    from hevc_amd import mp4, transcoder as T, yuvio
+    w, h, n = 160, 96, 12
+    clip = yuvio.SyntheticClip("motion", 1, w, h, n)
+    src = list(clip.frames())
+    inp = tmp_path / "clip.y4m"
+    yuvio.write_y4m(inp, src, w, h, 30)
+    seen = []
+    res = T.convert_video(inp, tmp_path, progress_callback=lambda name, f, t: seen.append((name, f, t)), skip_validator=True)
+    assert res == {"file": "clip.y4m", "status": "SUCCESS", "quality": res["quality"], "retries": 0, "method": "MI355X", "hdr": False}
+    assert seen and seen[-1][1] == seen[-1][2]
+    data = (tmp_path / "clip.mp4").read_bytes()
+    top = mp4.parse_boxes(data)
+    assert [b[0] for b in top] == ["ftyp", "moov", "mdat"]
+
+    def find(path, start, end):
+        for name in path:
+            _, start, end = [b for b in mp4.parse_boxes(data, start, end) if b[0] == name][0]
+        return start, end
+    s0, e0 = find(["moov", "trak", "mdia", "minf", "stbl", "stsd"], 0, len(data))
+    entry = mp4.parse_boxes(data, s0 + 8, e0)[0]
+    hv = [b for b in mp4.parse_boxes(data, entry[1] + 78, entry[2]) if b[0] == "hvcC"][0]
+    rec = data[hv[1]:hv[2]]
+    annexb, p = b"", 23
+    for _ in range(rec[22]):                       # parameter-set arrays of the hvcC record
+        cnt = int.from_bytes(rec[p + 1:p + 3], "big")
+        p += 3
+        for _ in range(cnt):
+            ln = int.from_bytes(rec[p:p + 2], "big")
+            annexb += b"\0\0\0\1" + rec[p + 2:p + 2 + ln]
+            p += 2 + ln
+    q = top[2][1]
+    while q < top[2][2]:                           # length-prefixed NAL units of the mdat
+        ln = int.from_bytes(data[q:q + 4], "big")
+        annexb += b"\0\0\0\1" + data[q + 4:q + 4 + ln]
+        q += 4 + ln
+    frames, info = O.decode(annexb)
+    assert len(frames) == n and info["conf_width"] == w and info["conf_height"] == h
+    for f, (y, u, v) in zip(frames, src):
+        assert util.psnr(f.y[:h, :w], y) > 30.0
+    ev = threading.Event()
+    ev.set()                                       # cancelled before the first frame
+    (tmp_path / "x").mkdir()
+    res = T.convert_video(inp, tmp_path / "x", skip_validator=True, stop_event=ev)
+    assert res["status"] == "CANCELLED"
