@@ -1,0 +1,50 @@
+"""Measurements for DESIGN.md that are NOT the bench line: BASELINE configs[2] (2160p30 HDR10 10-bit) and the
+PCIe-inclusive 1080p rate (frames handed over as host buffers).  Run on a GPU box; prints one JSON object."""
+import json
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from hevc_amd import _lib                                   # noqa: E402
+from hevc_amd.encoder import Encoder, config_for             # noqa: E402
+from hevc_amd.probe import VideoInfo                         # noqa: E402
+from hevc_amd.transcoder import calculate_apple_hevc_level, calculate_dynamic_values   # noqa: E402
+from hevc_amd.yuvio import SyntheticClip                     # noqa: E402
+
+
+def run(w, h, n, hdr, repeats=2):
+    tags = ("bt2020", "smpte2084", "bt2020nc", "yuv420p10le") if hdr else ("bt709", "bt709", "bt709", "yuv420p")
+    info = VideoInfo(w, h, 30.0, *tags, "", "", 0, hdr, "eng", n, n / 30.0)
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
+    level, tier = calculate_apple_hevc_level(info)
+    cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
+    cfg.profile_stages = 1
+    frames = list(SyntheticClip("motion", 0, w, h, n, bit_depth=10 if hdr else 8).frames())
+    best = None
+    for _ in range(repeats):
+        t0 = time.perf_counter()
+        with Encoder(cfg) as enc:
+            nbytes = 0
+            for y, u, v in frames:
+                enc.send(y, u, v)
+                for d, _p, _k in enc.packets():
+                    nbytes += len(d)
+            enc.flush()
+            for d, _p, _k in enc.packets():
+                nbytes += len(d)
+            st = enc.stats()
+            psnr = enc.psnr_y()
+        dt = time.perf_counter() - t0
+        rec = {"size": f"{w}x{h}", "bit_depth": cfg.bit_depth, "frames": n, "keyint": gop, "fps_pcie_inclusive": round(n / dt, 1),
+               "device_ms_per_frame": round(st.device_ms / n, 3), "bitrate_kbps": round(nbytes * 8 / (n / 30.0) / 1e3, 1), "target_kbps": maxrate,
+               "psnr_y_db": round(psnr, 2), "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(st.stage_ms[i] / max(1, st.stage_pictures[i]), 4) for i in range(7)}}
+        if best is None or rec["fps_pcie_inclusive"] > best["fps_pcie_inclusive"]:
+            best = rec
+    return best
+
+
+out = {"1080p8_host_buffers": run(1920, 1080, 300, False), "2160p10_hdr10_host_buffers": run(3840, 2160, 120, True)}
+print(json.dumps(out))
