@@ -16,7 +16,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (b & 7) * chunk + (b >> 3);
 }
 
-template <typename T> __global__ __launch_bounds__(NT, 3) void k_me_search(const InterArgs<T> *args, int n_ctu)
+template <typename T> __global__ __launch_bounds__(NT, (sizeof(T) == 1 ? 3 : 2)) void k_me_search(const InterArgs<T> *args, int n_ctu)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ctu = xcd_remap(blockIdx.x, n_ctu);
@@ -272,6 +272,7 @@ __global__ __launch_bounds__(NT) void k_transform_blocks(const int16_t *res, int
             int x = i & 31, y = i >> 5, blk = first + (y >> log2n) * (32 >> log2n) + (x >> log2n);
             if (blk < n_blocks) s.res[i] = res[(size_t)blk * n * n + (y & (n - 1)) * n + (x & (n - 1))];
         }
+        for (int i = tid; i < 1536; i += NT) s.desc[i] = pack_loc(locate(s, i));
     });
     residual_pipeline(ex, s, qp, qp, bit_depth, whole_ctu());
     ex.phase([&](int tid) {

@@ -264,6 +264,20 @@ DEV void load_row15(const uint16_t *base, int idx, int (&px)[15])
     for (int i = 0; i < 15; i++) px[i] = (int)((r[i >> 1] >> (16 * (i & 1))) & 65535);
 }
 
+// a.lo*b.lo + a.hi*b.hi + acc on packed signed 16-bit pairs (v_dot2_i32_i16)
+DEV int dot2_i16(uint32_t a, uint32_t b, int acc)
+{
+#if MIHEVC_GPU
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    v2s va, vb;
+    __builtin_memcpy(&va, &a, 4);
+    __builtin_memcpy(&vb, &b, 4);
+    return __builtin_amdgcn_sdot2(va, vb, acc, false);
+#else
+    return acc + (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (int)(int16_t)(a >> 16) * (int)(int16_t)(b >> 16);
+#endif
+}
+
 // in-place 8x8 Hadamard SATD of a difference block held in registers: (sum |H d H| + 2) >> 2
 DEV int hadamard8_satd(int (&m)[8][8])
 {

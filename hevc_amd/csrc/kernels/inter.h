@@ -64,12 +64,27 @@ DEV void quad_block_row(const uint8_t *src, const uint8_t *ref, int ws, unsigned
 }
 DEV void quad_block_row(const uint16_t *src, const uint16_t *ref, int ws, unsigned (&out)[4][4])
 {
+    // 16-bit samples: no quad-SAD instruction; v_sad_u16 on sample pairs, odd positions realigned with v_alignbyte
+    unsigned acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int r = 0; r < 8; r++) {
+        uint32_t rr[18], cc[16];
+#pragma unroll
+        for (int d = 0; d < 18; d++) rr[d] = load_u32_aligned(ref + r * ws + 2 * d);
+#pragma unroll
+        for (int d = 0; d < 16; d++) cc[d] = load_u32_aligned(src + r * 32 + 2 * d);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                const int k = d + (j >> 1);
+                uint32_t v = (j & 1) ? align_bytes(rr[k + 1], rr[k], 2) : rr[k];
+                acc[d >> 2][j] = sad_packed_u16(v, cc[d], acc[d >> 2][j]);
+            }
+    }
+#pragma unroll
     for (int b = 0; b < 4; b++)
-        for (int j = 0; j < 4; j++) {
-            unsigned a = 0;
-            for (int r = 0; r < 8; r++) a = sad_row8(src + r * 32 + 8 * b, ref + r * ws + 8 * b + j, a);
-            out[b][j] = a;
-        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) out[b][j] = acc[b][j];
 }
 
 template <typename T, class Ex>
@@ -381,7 +396,10 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         }
     });
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1536; i += NT) s.rs.res[i] = (int16_t)((int)s.src[i] - (int)s.pred[i]);
+        for (int i = tid; i < 1536; i += NT) {
+            s.rs.res[i] = (int16_t)((int)s.src[i] - (int)s.pred[i]);
+            s.rs.desc[i] = pack_loc(locate(s.rs, i));
+        }
     });
     residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, whole_ctu());
     // reconstruction + outputs

@@ -309,6 +309,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         for (int k = tid; k < rcnt; k += NT) {
             const int i = rg.index(k);
             SampleLoc l = locate(s.rs, i);
+            s.rs.desc[i] = pack_loc(l);
             if (!l.log2n) continue;
             int v;
             if (l.plane == 0) v = intra_sample<T>(L, log2n, mode, l.x - cx, l.y - cy, 0, bd, s.dc_val[0]);

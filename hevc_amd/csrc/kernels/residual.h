@@ -13,11 +13,13 @@
 namespace mihevc {
 
 struct ResidualShared {
-    int8_t mat[32][32];        // LDS copy of the transform matrix
+    int16_t mat[32][32];       // LDS copy of the transform matrix, 16-bit so rows feed v_dot2_i32_i16 as dword pairs
+    int16_t mat_t[32][32];     // its transpose (inverse transform reads columns)
     int16_t res[1536];         // residual in, reconstructed residual out
-    int32_t tmp[1536];         // stage intermediates
-    int16_t coef[1536];        // transform coefficients / scaled coefficients
+    int16_t tmp[1536];         // stage intermediates (forward stage 1 output is stored TRANSPOSED inside its TU)
+    int16_t coef[1536];        // transform coefficients, then scaled coefficients (stored TRANSPOSED inside the TU)
     int16_t lvl[1536];         // quantised levels (TU-local raster at CTU coordinates)
+    uint32_t desc[1536];       // per sample: TU geometry, written once per TU map by residual_describe
     uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
     uint8_t tu_intra[16];      // per tile: 1 = intra rounding
     unsigned cbf[3];           // bit t set: tile t's TU has a non-zero level in that plane (all tiles of a TU set the TU's first tile bit)
@@ -64,40 +66,55 @@ DEV SampleLoc locate(const ResidualShared &s, int idx)
     l.tile0 = (l.ty0 >> sh) * 4 + (l.tx0 >> sh);
     return l;
 }
+// packed form kept in LDS so the five transform phases do one read instead of re-deriving the geometry
+DEV uint32_t pack_loc(const SampleLoc &l) { return (uint32_t)l.log2n | (uint32_t)l.tx0 << 3 | (uint32_t)l.ty0 << 8 | (uint32_t)l.tile0 << 13 | (uint32_t)l.intra << 17; }
+DEV SampleLoc unpack_loc(uint32_t d, int idx)
+{
+    SampleLoc l;
+    if (idx < 1024) { l.plane = 0; l.x = idx & 31; l.y = idx >> 5; l.stride = 32; l.base = 0; }
+    else { int i = idx - 1024; l.plane = 1 + (i >> 8); i &= 255; l.x = i & 15; l.y = i >> 4; l.stride = 16; l.base = 1024 + (l.plane - 1) * 256; }
+    l.log2n = (int)(d & 7); l.tx0 = (int)(d >> 3) & 31; l.ty0 = (int)(d >> 8) & 31; l.tile0 = (int)(d >> 13) & 15; l.intra = (int)(d >> 17) & 1;
+    return l;
+}
 
-// forward + quant + scaling + inverse for every TU described by s.tu_log2; qp / qp_c are syntax QPs
+// sum_{i<n} a[i] * b[i] over contiguous, 4-byte aligned int16 runs (n even)
+DEV int dot_i16(const int16_t *a, const int16_t *b, int n)
+{
+    int acc = 0;
+    for (int i = 0; i < n; i += 2) acc = dot2_i16(load_u32_aligned(a + i), load_u32_aligned(b + i), acc);
+    return acc;
+}
+
+// forward + quant + scaling + inverse for every TU of the region; s.desc must describe the region's samples
+// (callers fill it while they form the residual).  qp / qp_c are syntax QPs.
 template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth, Region rg)
 {
     const int cnt = rg.count();
-    ex.phase([&](int tid) {      // forward stage 1: rows
+    ex.phase([&](int tid) {      // forward stage 1: rows; result stored transposed inside the TU
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
-            SampleLoc l = locate(s, idx);
+            SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0, row = l.base + l.y * l.stride + l.tx0;
-            const int8_t *m = s.mat[u << (5 - l.log2n)];
-            int acc = 0;
-            for (int i = 0; i < n; i++) acc += m[i] * s.res[row + i];
-            s.tmp[idx] = sh1 > 0 ? (acc + (1 << (sh1 - 1))) >> sh1 : acc;
+            int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0, yl = l.y - l.ty0;
+            int acc = dot_i16(s.mat[u << (5 - l.log2n)], s.res + l.base + l.y * l.stride + l.tx0, n);
+            s.tmp[l.base + (l.ty0 + u) * l.stride + l.tx0 + yl] = (int16_t)(sh1 > 0 ? (acc + (1 << (sh1 - 1))) >> sh1 : acc);
         }
     });
-    ex.phase([&](int tid) {      // forward stage 2: columns
+    ex.phase([&](int tid) {      // forward stage 2: columns (contiguous thanks to the transposed intermediate)
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
-            SampleLoc l = locate(s, idx);
+            SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            int n = 1 << l.log2n, sh2 = l.log2n + 6, v = l.y - l.ty0, col = l.base + l.ty0 * l.stride + l.x;
-            const int8_t *m = s.mat[v << (5 - l.log2n)];
-            long long acc = 0;
-            for (int j = 0; j < n; j++) acc += (long long)m[j] * s.tmp[col + j * l.stride];
+            int n = 1 << l.log2n, sh2 = l.log2n + 6, u = l.x - l.tx0, v = l.y - l.ty0;
+            int acc = dot_i16(s.mat[v << (5 - l.log2n)], s.tmp + l.base + (l.ty0 + u) * l.stride + l.tx0, n);
             acc = (acc + (1 << (sh2 - 1))) >> sh2;
-            s.coef[idx] = (int16_t)(acc < -32768 ? -32768 : acc > 32767 ? 32767 : acc);
+            s.coef[idx] = (int16_t)clip3(-32768, 32767, acc);
         }
     });
-    ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16)
+    ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16); scaled value stored transposed
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
-            SampleLoc l = locate(s, idx);
+            SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) { s.lvl[idx] = 0; continue; }
             int q = (l.plane ? qp_c : qp) + 6 * (bit_depth - 8);
             int qbits = 14 + q / 6 + (15 - bit_depth - l.log2n);
@@ -111,29 +128,37 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
             int bd_shift = bit_depth + l.log2n - 5;
             long long scale = (long long)16 * g_tab.level_scale[q % 6] << (q / 6);
             long long d = (lev * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
-            s.coef[idx] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
+            s.tmp[l.base + (l.ty0 + (l.x - l.tx0)) * l.stride + l.tx0 + (l.y - l.ty0)] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
         }
     });
     ex.phase([&](int tid) {      // inverse stage 1: columns, shift 7, clip to 16 bit (8.6.4.2)
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
-            SampleLoc l = locate(s, idx);
+            SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            int n = 1 << l.log2n, yy = l.y - l.ty0, col = l.base + l.ty0 * l.stride + l.x, step = 1 << (5 - l.log2n);
-            long long acc = 0;
-            for (int j = 0; j < n; j++) acc += (long long)s.mat[j * step][yy] * s.coef[col + j * l.stride];
-            acc = (acc + 64) >> 7;
-            s.tmp[idx] = (int)(acc < -32768 ? -32768 : acc > 32767 ? 32767 : acc);
+            int n = 1 << l.log2n, xl = l.x - l.tx0, yy = l.y - l.ty0, step = 5 - l.log2n;
+            // e[x][y] = sum_j transMatrix[j][y] * d[x][j]: column x of the scaled block is row x of the transposed store
+            int acc = 0;
+            const int16_t *dq = s.tmp + l.base + (l.ty0 + xl) * l.stride + l.tx0;
+            for (int j = 0; j < n; j += 2) {
+                uint32_t m2 = (uint32_t)(uint16_t)s.mat_t[yy][j << step] | (uint32_t)(uint16_t)s.mat_t[yy][(j + 1) << step] << 16;
+                acc = dot2_i16(m2, load_u32_aligned(dq + j), acc);
+            }
+            s.coef[idx] = (int16_t)clip3(-32768, 32767, (acc + 64) >> 7);
         }
     });
     ex.phase([&](int tid) {      // inverse stage 2: rows, shift 20 - bitDepth
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
-            SampleLoc l = locate(s, idx);
+            SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) { s.res[idx] = 0; continue; }
-            int n = 1 << l.log2n, xx = l.x - l.tx0, row = l.base + l.y * l.stride + l.tx0, step = 1 << (5 - l.log2n), sh = 20 - bit_depth;
-            long long acc = 0;
-            for (int j = 0; j < n; j++) acc += (long long)s.mat[j * step][xx] * s.tmp[row + j];
+            int n = 1 << l.log2n, xx = l.x - l.tx0, step = 5 - l.log2n, sh = 20 - bit_depth;
+            int acc = 0;
+            const int16_t *g = s.coef + l.base + l.y * l.stride + l.tx0;
+            for (int j = 0; j < n; j += 2) {
+                uint32_t m2 = (uint32_t)(uint16_t)s.mat_t[xx][j << step] | (uint32_t)(uint16_t)s.mat_t[xx][(j + 1) << step] << 16;
+                acc = dot2_i16(m2, load_u32_aligned(g + j), acc);
+            }
             s.res[idx] = (int16_t)((acc + (1 << (sh - 1))) >> sh);
         }
     });
@@ -142,7 +167,7 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
 template <class Ex> DEV void residual_init(Ex &ex, ResidualShared &s)
 {
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1024; i += NT) s.mat[i >> 5][i & 31] = g_tab.mat[i >> 5][i & 31];
+        for (int i = tid; i < 1024; i += NT) { s.mat[i >> 5][i & 31] = g_tab.mat[i >> 5][i & 31]; s.mat_t[i & 31][i >> 5] = g_tab.mat[i >> 5][i & 31]; }
         if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
         if (tid < 3) s.cbf[tid] = 0;
     });
