@@ -7,10 +7,11 @@ header declares is absent, and every encode entry point returns MIHEVC_ENODEV on
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
-LIB_PATH = HERE / "libmihevc.so"
+LIB_PATH = Path(os.environ.get("MIHEVC_LIBRARY", HERE / "libmihevc.so"))      # override: A/B runs of two builds in one GPU call
 
 OK, EAGAIN, EOF, EINVAL, ENODEV, ENOMEM, EDEVICE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
 

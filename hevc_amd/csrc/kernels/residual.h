@@ -12,14 +12,18 @@
 
 namespace mihevc {
 
+// pair tables: offsets of the 4-, 8-, 16-, 32-point sections (n/2 x n dwords each)
+DEV int pair_off(int log2n) { return log2n == 2 ? 0 : log2n == 3 ? 8 : log2n == 4 ? 40 : 168; }
+
 struct ResidualShared {
-    int16_t mat[32][32];       // LDS copy of the transform matrix, 16-bit so rows feed v_dot2_i32_i16 as dword pairs
-    int16_t mat_t[32][32];     // its transpose (inverse transform reads columns)
+    // transform matrices as dword pairs for v_dot2_i32_i16, laid out so that the lanes of a wave (consecutive x)
+    // read consecutive dwords: mp[off + p*n + u] = (M[u][2p], M[u][2p+1]),  mq[off + p*n + y] = (M[2p][y], M[2p+1][y])
+    uint32_t mp[680], mq[680];
     int16_t res[1536];         // residual in, reconstructed residual out
-    int16_t tmp[1536];         // stage intermediates (forward stage 1 output is stored TRANSPOSED inside its TU)
-    int16_t coef[1536];        // transform coefficients, then scaled coefficients (stored TRANSPOSED inside the TU)
+    int16_t tmp[1536];         // stage intermediates, row-pair interleaved: element (r, c) at (r & ~1) * stride + 2c + (r & 1)
+    int16_t coef[1536];        // transform coefficients / inverse stage-1 output (natural layout)
     int16_t lvl[1536];         // quantised levels (TU-local raster at CTU coordinates)
-    uint32_t desc[1536];       // per sample: TU geometry, written once per TU map by residual_describe
+    uint32_t desc[1536];       // per sample: TU geometry, written by the caller while it forms the residual
     uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
     uint8_t tu_intra[16];      // per tile: 1 = intra rounding
     unsigned cbf[3];           // bit t set: tile t's TU has a non-zero level in that plane (all tiles of a TU set the TU's first tile bit)
@@ -77,41 +81,40 @@ DEV SampleLoc unpack_loc(uint32_t d, int idx)
     return l;
 }
 
-// sum_{i<n} a[i] * b[i] over contiguous, 4-byte aligned int16 runs (n even)
-DEV int dot_i16(const int16_t *a, const int16_t *b, int n)
-{
-    int acc = 0;
-    for (int i = 0; i < n; i += 2) acc = dot2_i16(load_u32_aligned(a + i), load_u32_aligned(b + i), acc);
-    return acc;
-}
-
 // forward + quant + scaling + inverse for every TU of the region; s.desc must describe the region's samples
-// (callers fill it while they form the residual).  qp / qp_c are syntax QPs.
+// (callers fill it while they form the residual).  qp / qp_c are syntax QPs.  Every inner loop is a v_dot2_i32_i16
+// over (matrix pair, sample pair) dwords whose addresses are consecutive across the lanes of a wave.
 template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth, Region rg)
 {
     const int cnt = rg.count();
-    ex.phase([&](int tid) {      // forward stage 1: rows; result stored transposed inside the TU
+    ex.phase([&](int tid) {      // forward stage 1: rows
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0, yl = l.y - l.ty0;
-            int acc = dot_i16(s.mat[u << (5 - l.log2n)], s.res + l.base + l.y * l.stride + l.tx0, n);
-            s.tmp[l.base + (l.ty0 + u) * l.stride + l.tx0 + yl] = (int16_t)(sh1 > 0 ? (acc + (1 << (sh1 - 1))) >> sh1 : acc);
+            const int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0;
+            const uint32_t *m = s.mp + pair_off(l.log2n) + u;
+            const int16_t *r = s.res + l.base + l.y * l.stride + l.tx0;
+            int acc = 0;
+            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(r + 2 * p), acc);
+            s.tmp[l.base + (l.y & ~1) * l.stride + 2 * l.x + (l.y & 1)] = (int16_t)(sh1 > 0 ? (acc + (1 << (sh1 - 1))) >> sh1 : acc);
         }
     });
-    ex.phase([&](int tid) {      // forward stage 2: columns (contiguous thanks to the transposed intermediate)
+    ex.phase([&](int tid) {      // forward stage 2: columns
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            int n = 1 << l.log2n, sh2 = l.log2n + 6, u = l.x - l.tx0, v = l.y - l.ty0;
-            int acc = dot_i16(s.mat[v << (5 - l.log2n)], s.tmp + l.base + (l.ty0 + u) * l.stride + l.tx0, n);
+            const int n = 1 << l.log2n, sh2 = l.log2n + 6, v = l.y - l.ty0;
+            const uint32_t *m = s.mp + pair_off(l.log2n) + v;
+            const int16_t *t = s.tmp + l.base + l.ty0 * l.stride + 2 * l.x;
+            int acc = 0;
+            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(t + 2 * p * l.stride), acc);
             acc = (acc + (1 << (sh2 - 1))) >> sh2;
             s.coef[idx] = (int16_t)clip3(-32768, 32767, acc);
         }
     });
-    ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16); scaled value stored transposed
+    ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16)
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
@@ -128,7 +131,7 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
             int bd_shift = bit_depth + l.log2n - 5;
             long long scale = (long long)16 * g_tab.level_scale[q % 6] << (q / 6);
             long long d = (lev * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
-            s.tmp[l.base + (l.ty0 + (l.x - l.tx0)) * l.stride + l.tx0 + (l.y - l.ty0)] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
+            s.tmp[l.base + (l.y & ~1) * l.stride + 2 * l.x + (l.y & 1)] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
         }
     });
     ex.phase([&](int tid) {      // inverse stage 1: columns, shift 7, clip to 16 bit (8.6.4.2)
@@ -136,14 +139,11 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            int n = 1 << l.log2n, xl = l.x - l.tx0, yy = l.y - l.ty0, step = 5 - l.log2n;
-            // e[x][y] = sum_j transMatrix[j][y] * d[x][j]: column x of the scaled block is row x of the transposed store
+            const int n = 1 << l.log2n, yy = l.y - l.ty0;
+            const uint32_t *m = s.mq + pair_off(l.log2n) + yy;
+            const int16_t *d = s.tmp + l.base + l.ty0 * l.stride + 2 * l.x;
             int acc = 0;
-            const int16_t *dq = s.tmp + l.base + (l.ty0 + xl) * l.stride + l.tx0;
-            for (int j = 0; j < n; j += 2) {
-                uint32_t m2 = (uint32_t)(uint16_t)s.mat_t[yy][j << step] | (uint32_t)(uint16_t)s.mat_t[yy][(j + 1) << step] << 16;
-                acc = dot2_i16(m2, load_u32_aligned(dq + j), acc);
-            }
+            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(d + 2 * p * l.stride), acc);
             s.coef[idx] = (int16_t)clip3(-32768, 32767, (acc + 64) >> 7);
         }
     });
@@ -152,13 +152,11 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) { s.res[idx] = 0; continue; }
-            int n = 1 << l.log2n, xx = l.x - l.tx0, step = 5 - l.log2n, sh = 20 - bit_depth;
-            int acc = 0;
+            const int n = 1 << l.log2n, xx = l.x - l.tx0, sh = 20 - bit_depth;
+            const uint32_t *m = s.mq + pair_off(l.log2n) + xx;
             const int16_t *g = s.coef + l.base + l.y * l.stride + l.tx0;
-            for (int j = 0; j < n; j += 2) {
-                uint32_t m2 = (uint32_t)(uint16_t)s.mat_t[xx][j << step] | (uint32_t)(uint16_t)s.mat_t[xx][(j + 1) << step] << 16;
-                acc = dot2_i16(m2, load_u32_aligned(g + j), acc);
-            }
+            int acc = 0;
+            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(g + 2 * p), acc);
             s.res[idx] = (int16_t)((acc + (1 << (sh - 1))) >> sh);
         }
     });
@@ -167,7 +165,11 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
 template <class Ex> DEV void residual_init(Ex &ex, ResidualShared &s)
 {
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1024; i += NT) { s.mat[i >> 5][i & 31] = g_tab.mat[i >> 5][i & 31]; s.mat_t[i & 31][i >> 5] = g_tab.mat[i >> 5][i & 31]; }
+        for (int i = tid; i < 680; i += NT) {
+            const int lg = i < 8 ? 2 : i < 40 ? 3 : i < 168 ? 4 : 5, n = 1 << lg, k = i - pair_off(lg), p = k / n, c = k % n, st = 5 - lg;
+            s.mp[i] = (uint32_t)(uint16_t)(int16_t)g_tab.mat[c << st][2 * p] | (uint32_t)(uint16_t)(int16_t)g_tab.mat[c << st][2 * p + 1] << 16;
+            s.mq[i] = (uint32_t)(uint16_t)(int16_t)g_tab.mat[(2 * p) << st][c] | (uint32_t)(uint16_t)(int16_t)g_tab.mat[(2 * p + 1) << st][c] << 16;
+        }
         if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
         if (tid < 3) s.cbf[tid] = 0;
     });
