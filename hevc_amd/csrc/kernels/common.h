@@ -264,6 +264,16 @@ DEV void load_row15(const uint16_t *base, int idx, int (&px)[15])
     for (int i = 0; i < 15; i++) px[i] = (int)((r[i >> 1] >> (16 * (i & 1))) & 65535);
 }
 
+// sum of four signed-byte products + acc (v_dot4_i32_i8)
+DEV int dot4_i8(uint32_t a, uint32_t b, int acc)
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_sdot4((int)a, (int)b, acc, false);
+#else
+    for (int i = 0; i < 4; i++) acc += (int)(int8_t)(a >> (8 * i)) * (int)(int8_t)(b >> (8 * i));
+    return acc;
+#endif
+}
 // a.lo*b.lo + a.hi*b.hi + acc on packed signed 16-bit pairs (v_dot2_i32_i16)
 DEV int dot2_i16(uint32_t a, uint32_t b, int acc)
 {

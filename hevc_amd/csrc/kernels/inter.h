@@ -243,6 +243,64 @@ DEV int luma_tile(const T *win, int i00, int ws, int fx, int fy, int bit_depth, 
     return diff_src ? hadamard8_satd(acc) : 0;
 }
 
+// 8-bit specialisation of luma_tile: the horizontal 8-tap filter of one row is 16 v_dot4_i32_i8 on byte-realigned
+// dwords.  Samples are biased to signed bytes (p - 128); the taps of every fraction sum to 64, so the bias comes back
+// as the constant 128 * 64.  Results are identical to the generic form (the fractional search was 72 % of
+// k_inter_ctu, VALU bound on 8 multiply-adds per output: profiles/r01 ablation).
+DEV int luma_tile(const uint8_t *win, int i00, int ws, int fx, int fy, int bit_depth, const uint8_t *diff_src, int src_stride, uint8_t *pred_out,
+                  int pred_stride)
+{
+    const uint32_t tlo = load_u32(&g_tab.luma_tap[fx][0]), thi = load_u32(&g_tab.luma_tap[fx][4]);
+    int ty[8];          // vertical taps in registers: the row loop is fully unrolled so every tap index is static
+#pragma unroll
+    for (int k = 0; k < 8; k++) ty[k] = g_tab.luma_tap[fy][k];
+    int acc[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+        const int idx = i00 + (r - 3) * ws - 3, off = idx & 3;
+        const uint8_t *p = win + (idx - off);
+        uint32_t d[5], a[12];
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = load_u32_aligned(p + 4 * k);
+        uint32_t q[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) q[k] = align_bytes(d[k + 1], d[k], off) ^ 0x80808080u;      // bytes 4k..4k+3 of the row, signed
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            a[4 * k] = q[k];
+            a[4 * k + 1] = align_bytes(q[k + 1], q[k], 1);
+            a[4 * k + 2] = align_bytes(q[k + 1], q[k], 2);
+            a[4 * k + 3] = align_bytes(q[k + 1], q[k], 3);
+        }
+        int hv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) hv[i] = dot4_i8(a[i], tlo, dot4_i8(a[i + 4], thi, 128 * 64));
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int k = r - j;
+            if (k >= 0 && k < 8) {
+                int t = ty[k];
+#pragma unroll
+                for (int i = 0; i < 8; i++) acc[j][i] += t * hv[i];
+            }
+        }
+    }
+    (void)bit_depth;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int v = clip3(0, 255, ((acc[j][i] >> 6) + 32) >> 6);
+            if (diff_src) acc[j][i] = (int)diff_src[j * src_stride + i] - v;
+            else pred_out[j * pred_stride + i] = (uint8_t)v;
+        }
+    return diff_src ? hadamard8_satd(acc) : 0;
+}
+
 // four horizontally adjacent predicted luma samples (8.5.3.3.3.1) starting at window element i00: the final motion
 // compensation of a CTU spread over all 256 lanes (16 tiles x 8 rows x 2 halves)
 template <typename T>
@@ -327,7 +385,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                 if (al != level) continue;
                 int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
                 int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                s.satd[level][k][t] = luma_tile<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, s.src + typ * 8 * 32 + txp * 8, 32, nullptr, 0);
+                s.satd[level][k][t] = luma_tile((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8), 32, (T *)nullptr, 0);
             }
         });
         ex.phase([&](int tid) {
