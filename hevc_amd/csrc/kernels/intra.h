@@ -37,6 +37,7 @@ template <typename T> struct IntraShared {
     T save_c[2][16 * 16];
     int16_t coef_acc[1536], coef_save[1536];
     mihevc_cu_rec cu_acc[16], cu_save[16];
+    mihevc_cu_rec left_cu[4];    // CU records of the left CTU's right column (MPM derivation), fetched once per CTU
     T ref_raw[3][132], ref[3][132], filt[132];   // [plane]: 4N+1 reference samples (raw, substituted); filtered luma
     uint8_t avail[3][132];
     int satd[35][16];
@@ -55,7 +56,9 @@ template <typename T> DEV int ref_left(const T *L, int n, int y) { return L[2 * 
 template <typename T> DEV int ref_top(const T *L, int n, int x) { return L[2 * n + 1 + x]; }
 
 // one predicted sample — 8.4.4.2.4 (planar), .5 (DC incl. edge smoothing), .6 (angular incl. modes 10/26 edge filter)
-template <typename T> DEV int intra_sample(const T *L, int log2n, int mode, int x, int y, int c_idx, int bit_depth, int dc)
+// `angle` / `inv` are the mode's Table 8-4 / 8-5 entries, fetched once per lane by the caller (a global-memory read per
+// sample sat on the critical path of the latency-bound intra wavefront)
+template <typename T> DEV int intra_sample(const T *L, int log2n, int mode, int angle, int inv, int x, int y, int c_idx, int bit_depth, int dc)
 {
     const int n = 1 << log2n;
     if (mode == 0)
@@ -68,7 +71,7 @@ template <typename T> DEV int intra_sample(const T *L, int log2n, int mode, int 
         }
         return dc;
     }
-    const int angle = g_tab.intra_angle[mode], vertical = mode >= 18;
+    const int vertical = mode >= 18;
     const int a = vertical ? y : x, b = vertical ? x : y;     // a: along the prediction direction
     if (angle == 0 && c_idx == 0 && n < 32 && b == 0) {
         int corner = L[2 * n];
@@ -78,12 +81,15 @@ template <typename T> DEV int intra_sample(const T *L, int log2n, int mode, int 
     const int idx = ((a + 1) * angle) >> 5, f = ((a + 1) * angle) & 31;
     auto r = [&](int i) -> int {
         if (i >= 0) return vertical ? L[2 * n + i] : L[2 * n - i];
-        int k = -1 + ((i * g_tab.inv_angle[mode - 11] + 128) >> 8);
+        int k = -1 + ((i * inv + 128) >> 8);
         return vertical ? L[2 * n - 1 - k] : L[2 * n + 1 + k];
     };
     int v0 = r(b + idx + 1);
     return f ? ((32 - f) * v0 + f * r(b + idx + 2) + 16) >> 5 : v0;
 }
+
+DEV int mode_angle(int mode) { return g_tab.intra_angle[mode]; }
+DEV int mode_inv_angle(int mode) { return (mode >= 11 && mode <= 25) ? g_tab.inv_angle[mode - 11] : 0; }
 
 // difference (source - prediction) of one 8x8 tile of an NxN luma block for `mode`: the same arithmetic as
 // intra_sample, with everything that depends only on the mode / row hoisted out of the sample loop (the SATD mode
@@ -184,7 +190,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         if (tid == 0) {   // 8.4.2 candModeList
             int ma = 1, mb = 1;
             if (gx > 0) {
-                const mihevc_cu_rec &r = cx > 0 ? s.cu_acc[(cy >> 3) * 4 + ((cx - 1) >> 3)] : a.cu[(size_t)(gy >> 3) * (a.w >> 3) + ((gx - 1) >> 3)];
+                const mihevc_cu_rec &r = cx > 0 ? s.cu_acc[(cy >> 3) * 4 + ((cx - 1) >> 3)] : s.left_cu[cy >> 3];
                 if (!(r.flags & CU_INTER)) ma = r.intra_mode[0];
             }
             if (cy > 0) {
@@ -244,9 +250,10 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             for (int u = tid; u < 35 * 8; u += NT) {
                 const int mode = u >> 3, y = u & 7;
                 const T *L = intra_filter_on(3, mode) ? s.filt : s.ref[0];
+                const int ang = mode_angle(mode), inv = mode_inv_angle(mode);
                 int d[8];
 #pragma unroll
-                for (int x = 0; x < 8; x++) d[x] = (int)s.src[(cy + y) * 32 + cx + x] - intra_sample<T>(L, 3, mode, x, y, 0, bd, s.dc_val[0]);
+                for (int x = 0; x < 8; x++) d[x] = (int)s.src[(cy + y) * 32 + cx + x] - intra_sample<T>(L, 3, mode, ang, inv, x, y, 0, bd, s.dc_val[0]);
 #pragma unroll
                 for (int st = 1; st < 8; st <<= 1)
 #pragma unroll
@@ -306,14 +313,15 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
     ex.phase([&](int tid) {
         const int mode = (int)(s.mode_key & 63);
         const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
+        const int ang = mode_angle(mode), inv = mode_inv_angle(mode);
         for (int k = tid; k < rcnt; k += NT) {
             const int i = rg.index(k);
             SampleLoc l = locate(s.rs, i);
             s.rs.desc[i] = pack_loc(l);
             if (!l.log2n) continue;
             int v;
-            if (l.plane == 0) v = intra_sample<T>(L, log2n, mode, l.x - cx, l.y - cy, 0, bd, s.dc_val[0]);
-            else v = intra_sample<T>(s.ref[l.plane], log2n - 1, mode, l.x - (cx >> 1), l.y - (cy >> 1), l.plane, bd, s.dc_val[l.plane]);
+            if (l.plane == 0) v = intra_sample<T>(L, log2n, mode, ang, inv, l.x - cx, l.y - cy, 0, bd, s.dc_val[0]);
+            else v = intra_sample<T>(s.ref[l.plane], log2n - 1, mode, ang, inv, l.x - (cx >> 1), l.y - (cy >> 1), l.plane, bd, s.dc_val[l.plane]);
             s.pred[i] = (T)v;
             s.rs.res[i] = (int16_t)((int)s.src[i] - v);
         }
@@ -403,6 +411,7 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             s.coef_acc[i] = 0;
         }
         if (tid == 0) s.est = 0;
+        if (tid < 4 && x0 > 0 && y0 + tid * 8 < a.h) s.left_cu[tid] = a.cu[(size_t)((y0 >> 3) + tid) * (a.w >> 3) + ((x0 - 1) >> 3)];
         // neighbourhood: row -1 (cols -1..63 luma / -1..31 chroma) and column -1 (rows 0..31 / 0..15) from the picture
         for (int u = tid; u < 65 + 32 + 2 * (33 + 16); u += NT) {
             int pl, k, row_len, col_len;

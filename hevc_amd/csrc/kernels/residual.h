@@ -27,6 +27,7 @@ struct ResidualShared {
     uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
     uint8_t tu_intra[16];      // per tile: 1 = intra rounding
     unsigned cbf[3];           // bit t set: tile t's TU has a non-zero level in that plane (all tiles of a TU set the TU's first tile bit)
+    int quant_scale[6], level_scale[6];   // LDS copies: no global-memory read on the per-sample path
 };
 
 struct SampleLoc {
@@ -123,13 +124,13 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
             int qbits = 14 + q / 6 + (15 - bit_depth - l.log2n);
             long long add = (long long)(l.intra ? 171 : 85) << (qbits - 9);
             int c = s.coef[idx];
-            long long a = ((long long)iabs(c) * g_tab.quant_scale[q % 6] + add) >> qbits;
+            long long a = ((long long)iabs(c) * s.quant_scale[q % 6] + add) >> qbits;
             if (a > 32767) a = 32767;
             int lev = (int)(c < 0 ? -a : a);
             s.lvl[idx] = (int16_t)lev;
             if (lev) ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
             int bd_shift = bit_depth + l.log2n - 5;
-            long long scale = (long long)16 * g_tab.level_scale[q % 6] << (q / 6);
+            long long scale = (long long)16 * s.level_scale[q % 6] << (q / 6);
             long long d = (lev * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
             s.tmp[l.base + (l.y & ~1) * l.stride + 2 * l.x + (l.y & 1)] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
         }
@@ -171,6 +172,7 @@ template <class Ex> DEV void residual_init(Ex &ex, ResidualShared &s)
             s.mq[i] = (uint32_t)(uint16_t)(int16_t)g_tab.mat[(2 * p) << st][c] | (uint32_t)(uint16_t)(int16_t)g_tab.mat[(2 * p + 1) << st][c] << 16;
         }
         if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
+        if (tid < 6) { s.quant_scale[tid] = g_tab.quant_scale[tid]; s.level_scale[tid] = g_tab.level_scale[tid]; }
         if (tid < 3) s.cbf[tid] = 0;
     });
 }
