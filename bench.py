@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--me-range", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-threads", type=int, default=0, help="CABAC worker threads (0 = library default)")
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
     args = ap.parse_args()
 
@@ -81,6 +82,7 @@ def main():
     cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
     cfg.me_range, cfg.profile_stages = args.me_range, 1
     cfg.qp = args.qp
+    cfg.host_threads = args.host_threads
 
     # synthetic clip -> HBM (untimed).  torch is plumbing for device memory only.
     clip = SyntheticClip("motion", rank, W, H, N)
