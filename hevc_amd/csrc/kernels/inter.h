@@ -26,6 +26,8 @@ template <typename T> struct InterArgs {
     mihevc_cu_rec *cu;           // (h/8) x (w/8)
     int16_t *coef[3];            // strides w, w/2, w/2
     unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit), see DESIGN.md rate control
+    int sparse_coef;             // 1: store levels only for TUs that have a non-zero one (the host coder never reads the others);
+                                 //    lets `coef` point at pinned host memory so no 6 MB/picture D2H blit is needed
 };
 
 // candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
@@ -469,7 +471,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             int gx = (l.plane ? x0 >> 1 : x0) + l.x, gy = (l.plane ? y0 >> 1 : y0) + l.y;
             int v = clip3(0, maxv, (int)s.pred[i] + s.rs.res[i]);
             a.rec[l.plane].p[(ptrdiff_t)gy * a.rec[l.plane].stride + gx] = (T)v;
-            a.coef[l.plane][(size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx] = s.rs.lvl[i];
+            if (!a.sparse_coef || ((s.rs.cbf[l.plane] >> l.tile0) & 1)) a.coef[l.plane][(size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx] = s.rs.lvl[i];
         }
         if (a.est) {       // rate estimate: coefficient sub-block costs + a header per CU (oracle: inter estimate)
             unsigned e = 0;

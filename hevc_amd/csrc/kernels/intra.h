@@ -22,6 +22,7 @@ template <typename T> struct IntraArgs {
     int16_t *coef[3];
     int diagonal;                // CTUs with cx + 2*cy == diagonal are processed by this launch
     unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit)
+    int sparse_coef;             // 1: store levels only for TUs with a non-zero level (see InterArgs)
 };
 
 constexpr int RY_STRIDE = 68;    // LDS luma neighbourhood: rows -1..31, cols -1..63 (+ pad)
@@ -461,7 +462,10 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
             if (gx >= pw || gy >= ph) continue;
             a.rec[pl].p[(ptrdiff_t)gy * a.rec[pl].stride + gx] = pl ? s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : s.rec_y[(y + 1) * RY_STRIDE + x + 1];
-            a.coef[pl][(size_t)gy * pw + gx] = s.coef_acc[i];
+            {
+                const int sh = pl ? 2 : 3, fl = s.cu_acc[(y >> sh) * 4 + (x >> sh)].flags;
+                if (!a.sparse_coef || (fl & (pl == 0 ? CU_CBF_Y : pl == 1 ? CU_CBF_CB : CU_CBF_CR))) a.coef[pl][(size_t)gy * pw + gx] = s.coef_acc[i];
+            }
         }
         if (tid < 16) {
             int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;

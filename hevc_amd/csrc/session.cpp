@@ -363,8 +363,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.prm = A.inter.prm = A.sao.prm = P;
             A.intra.cu = A.inter.cu = (mihevc_cu_rec *)(sym + sl.cu);
             A.dbk_v.cu = A.dbk_h.cu = (const mihevc_cu_rec *)(sym + sl.cu);
-            int16_t *c3[3] = {(int16_t *)(sym + sl.cy), (int16_t *)(sym + sl.cu_), (int16_t *)(sym + sl.cv)};
+            // levels go straight to the pinned host block (device-mapped): only TUs with a non-zero level are stored, so the
+            // 6 MB/picture coefficient planes never cross PCIe as a blit (profiles/r01: copyBuffer was 17 % of GPU time)
+            uint8_t *symh = L.sym_host[slot_of(t)];
+            int16_t *c3[3] = {(int16_t *)(symh + sl.cy), (int16_t *)(symh + sl.cu_), (int16_t *)(symh + sl.cv)};
             for (int i = 0; i < 3; i++) A.intra.coef[i] = A.inter.coef[i] = c3[i];
+            A.intra.sparse_coef = A.inter.sparse_coef = 1;
             A.intra.diagonal = 0;
             A.inter.centers = nullptr; A.inter.me = L.me;
             A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
@@ -466,7 +470,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     for (int i = 0; i < 3; i++) A.rec[i] = mk<T>(L.var_p[v - 1][i], L.work_stride[i]);
                     A.prm = prm_for(std::min(51, qp_step[g] + kVariantStep * v));
                     A.cu = (mihevc_cu_rec *)(sym + sl.cu);
-                    A.coef[0] = (int16_t *)(sym + sl.cy); A.coef[1] = (int16_t *)(sym + sl.cu_); A.coef[2] = (int16_t *)(sym + sl.cv);
+                    uint8_t *symh = L.sym_host[v];
+                    A.coef[0] = (int16_t *)(symh + sl.cy); A.coef[1] = (int16_t *)(symh + sl.cu_); A.coef[2] = (int16_t *)(symh + sl.cv);
                     A.est = (unsigned long long *)(sym + sl.est);
                 }
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
@@ -520,7 +525,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
         HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot0], 0));
         for (int g = 0; g < B; g++)
-            HIPCK(s, hipMemcpyAsync(s->lane[g].sym_host[lane_slot[g]], s->lane[g].sym_dev[lane_slot[g]], sl.total, hipMemcpyDeviceToHost, s->st_copy));
+        {   // CU records, then SAO parameters + SSE + rate estimate (the level planes were written to the host block directly)
+            uint8_t *hd = s->lane[g].sym_host[lane_slot[g]], *dd = s->lane[g].sym_dev[lane_slot[g]];
+            HIPCK(s, hipMemcpyAsync(hd, dd, sl.cy, hipMemcpyDeviceToHost, s->st_copy));
+            HIPCK(s, hipMemcpyAsync(hd + sl.sao, dd + sl.sao, sl.total - sl.sao, hipMemcpyDeviceToHost, s->st_copy));
+        }
         if (s->keep_recon) {
             for (int g = 0; g < B; g++) {
                 int fi = g * s->keyint + t;

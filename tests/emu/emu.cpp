@@ -52,7 +52,7 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     a.ref[0] = {ref0.plane.p, ref0.stride}; a.ref[1] = {ref1.plane.p, ref1.stride}; a.ref[2] = {ref2.plane.p, ref2.stride};
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU;
-    a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est;
+    a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0;
     if (est) *est = 0;
     int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU), R = a.prm.me_range;
     std::vector<int32_t> me((size_t)n_ctu * 63);
@@ -82,7 +82,7 @@ static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, cons
     a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU;
-    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est;
+    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0;
     if (est) *est = 0;
     SeqExec ex;
     // same launch order as the device: one anti-diagonal (cx + 2 cy) at a time
