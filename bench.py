@@ -8,6 +8,7 @@ N > 1 shards one clip per GPU with no data-path collective (BASELINE configs[3])
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -41,6 +42,23 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     return {"value": round(budget_frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"oracle/hevc_oracle.c, first {budget_frames} pictures (1 I + {budget_frames - 1} P) of the same {width}x{height} clip, "
                       f"analysis+deblock+SAO, no CABAC, {dt:.1f} s; libx265 itself is unavailable (no ffmpeg on this host)"}
+
+
+def measured_traffic(kernel, workload):
+    """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/r*/traffic.json, written by
+    tools/profile_bench.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  PMC passes cannot
+    run inside the timed bench, so the figure is only reported for the default workload it was collected on."""
+    if workload != (1920, 1080, 300, 15):
+        return None, None
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, "profiles", "r*", "traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], here)) if k else (None, None)
 
 
 def main():
@@ -158,12 +176,14 @@ def main():
         avg_ms = stage_ms[dom] / launches
         bytes_per_launch = per_pic[dom] * stage_pics[dom] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic("k_" + _lib.STAGE_NAMES[dom] if dom else "k_intra_diag", (W, H, N, args.me_range))
         out = {
             "metric": "encoded 1080p30 frames/sec/GPU; PSNR-Y parity vs libx265 at matched bitrate",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"{W}x{H}@30 SDR 8-bit Main, CQ (crf {crf} -> QP {st.last_qp}), {N}-frame synthetic 'motion' clip per GPU, "
+            "config": {"workload": f"{W}x{H}@30 SDR 8-bit Main, crf {crf} capped by VBV maxrate {maxrate} kbps / bufsize {bufsize} kbit "
+                                   f"(the reference's libx265 operating point), {N}-frame synthetic 'motion' clip per GPU, "
                                    f"keyint {gop}, IPPP, full-search +-{args.me_range}, one clip per GPU"},
             "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1),
                         "libx265_parity": "unavailable: no ffmpeg/libx265 on this host"},
@@ -172,7 +192,8 @@ def main():
                      "step_phases_ms": dict(zip(("open", "send", "flush_drain", "close"), [round(x / args.steps * 1e3, 2) for x in phase_s])),
                      "device_ms_per_step": round(st.device_ms, 2)},
             "roofline": {"bound": "hbm", "kernel": _lib.STAGE_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "pictures_per_launch": round(stage_pics[dom] / launches, 2),
                          "note": "integer-VALU/LDS bound path: the HBM fraction is small by construction (SURVEY.md §0.5)"},
         }
