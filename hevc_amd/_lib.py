@@ -23,7 +23,7 @@ class Config(C.Structure):
         "aud", "repeat_headers", "hdr10")] +
         [("md_primaries", (C.c_uint16 * 2) * 3), ("md_white", C.c_uint16 * 2), ("md_max_lum", C.c_uint32), ("md_min_lum", C.c_uint32),
          ("max_cll", C.c_uint16), ("max_fall", C.c_uint16)] +
-        [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages")] + [("reserved", C.c_int32 * 7)])
+        [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages", "intra_tiles")] + [("reserved", C.c_int32 * 6)])
 
 
 class Stats(C.Structure):
@@ -36,14 +36,14 @@ STAGE_NAMES = ("intra", "me_search", "inter_ctu", "deblock", "sao", "pad", "sse"
 
 
 class CostParams(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("qp", "qp_c", "bit_depth", "lambda_sad_q4", "lambda_q4", "me_range")]
+    _fields_ = [(n, C.c_int32) for n in ("qp", "qp_c", "bit_depth", "lambda_sad_q4", "lambda_q4", "me_range", "tile_cols", "tile_rows")]
 
 
 # every symbol include/mihevc.h declares; tests/test_abi.py checks the header against this list and the .so
 EXPORTS = (
     "mihevc_abi_version", "mihevc_device_count", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_device",
     "mihevc_receive_packet", "mihevc_flush", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
-    "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_k_transform",
+    "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_tile_grid", "mihevc_k_transform",
     "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_write_parameter_sets",
     "mihevc_encode_picture_host",
 )
@@ -117,3 +117,12 @@ def cost_params(qp: int, bit_depth: int = 8, me_range: int = 16) -> CostParams:
     p = CostParams()
     load().mihevc_cost_params_for_qp(qp, bit_depth, me_range, C.byref(p))
     return p
+
+
+def tile_grid(cfg: Config):
+    """(columns, rows) of the tile grid IDR pictures of this configuration are coded with (mihevc_tile_grid)."""
+    c, r = C.c_int(), C.c_int()
+    rc = load().mihevc_tile_grid(C.byref(cfg), C.byref(c), C.byref(r))
+    if rc != 0:
+        raise MihevcError(rc, "mihevc_tile_grid")
+    return c.value, r.value

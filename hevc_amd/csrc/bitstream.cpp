@@ -184,10 +184,30 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
     append_nal(out, 33, w.bytes());
 }
 
-void write_pps(const mihevc_config &, std::vector<uint8_t> &out)
+TileGrid tile_grid(const mihevc_config &cfg)
+{
+    TileGrid g;
+    CodedSize cs = coded_size(cfg.width, cfg.height);
+    g.wc = (cs.w + kCtu - 1) >> kCtuLog2; g.hc = (cs.h + kCtu - 1) >> kCtuLog2;
+    if (!cfg.intra_tiles || cs.w < 256 || cs.h < 64) return g;     // A.4.1 bounds every tile, so small pictures stay untiled
+    // Table A.8 (MaxTileCols / MaxTileRows) by general_level_idc
+    int max_cols = 1, max_rows = 1;
+    if (cfg.level_idc >= 180) { max_cols = 20; max_rows = 22; }
+    else if (cfg.level_idc >= 150) { max_cols = 10; max_rows = 11; }
+    else if (cfg.level_idc >= 120) { max_cols = 5; max_rows = 5; }
+    else if (cfg.level_idc >= 93) { max_cols = 3; max_rows = 3; }
+    else if (cfg.level_idc >= 90) { max_cols = 2; max_rows = 2; }
+    // A.4.1: columns >= 256 and rows >= 64 luma samples; with uniform spacing the narrowest column is floor(wc / cols) CTBs
+    g.cols = std::max(1, std::min(max_cols, g.wc / (256 / kCtu)));
+    g.rows = std::max(1, std::min(max_rows, g.hc / (64 / kCtu)));
+    return g;
+}
+
+void write_pps(const mihevc_config &cfg, int pps_id, std::vector<uint8_t> &out)
 {
     BitWriter w;
-    w.ue(0);              // pps_pic_parameter_set_id
+    const TileGrid g = pps_id == 1 ? tile_grid(cfg) : TileGrid();
+    w.ue((uint32_t)pps_id); // pps_pic_parameter_set_id
     w.ue(0);              // pps_seq_parameter_set_id
     w.put1(0);            // dependent_slice_segments_enabled_flag
     w.put1(0);            // output_flag_present_flag
@@ -206,8 +226,14 @@ void write_pps(const mihevc_config &, std::vector<uint8_t> &out)
     w.put1(0);            // weighted_pred_flag
     w.put1(0);            // weighted_bipred_flag
     w.put1(0);            // transquant_bypass_enabled_flag
-    w.put1(0);            // tiles_enabled_flag
+    w.put1(g.on());       // tiles_enabled_flag
     w.put1(0);            // entropy_coding_sync_enabled_flag
+    if (g.on()) {
+        w.ue((uint32_t)g.cols - 1);   // num_tile_columns_minus1
+        w.ue((uint32_t)g.rows - 1);   // num_tile_rows_minus1
+        w.put1(1);                    // uniform_spacing_flag
+        w.put1(1);                    // loop_filter_across_tiles_enabled_flag
+    }
     w.put1(1);            // pps_loop_filter_across_slices_enabled_flag
     w.put1(0);            // deblocking_filter_control_present_flag
     w.put1(0);            // pps_scaling_list_data_present_flag
@@ -259,7 +285,8 @@ void write_parameter_sets(const mihevc_config &c, std::vector<uint8_t> &out)
 {
     write_vps(c, out);
     write_sps(c, out);
-    write_pps(c, out);
+    write_pps(c, 0, out);
+    if (tile_grid(c).on()) write_pps(c, 1, out);
     if (c.hdr10) write_sei_hdr10(c, out);
 }
 
@@ -310,7 +337,8 @@ const uint8_t kInitP[kCtxCount] = {
 
 class Cabac {
 public:
-    explicit Cabac(std::vector<uint8_t> &out) : out_(out) {}
+    explicit Cabac(std::vector<uint8_t> &out) : out_p_(&out) {}
+    void redirect(std::vector<uint8_t> &out) { out_p_ = &out; }
     void init(bool intra_slice, int qp)
     {
         const uint8_t *iv = intra_slice ? kInitI : kInitP;
@@ -379,12 +407,12 @@ public:
     void finish()
     {
         if (low_ >> (32 - bits_left_)) {
-            out_.push_back((uint8_t)(buffered_ + 1));
-            while (n_buffered_ > 1) { out_.push_back(0x00); n_buffered_--; }
+            out_p_->push_back((uint8_t)(buffered_ + 1));
+            while (n_buffered_ > 1) { out_p_->push_back(0x00); n_buffered_--; }
             low_ -= 1u << (32 - bits_left_);
         } else {
-            if (n_buffered_ > 0) out_.push_back((uint8_t)buffered_);
-            while (n_buffered_ > 1) { out_.push_back(0xff); n_buffered_--; }
+            if (n_buffered_ > 0) out_p_->push_back((uint8_t)buffered_);
+            while (n_buffered_ > 1) { out_p_->push_back(0xff); n_buffered_--; }
         }
         // remaining 24 - bits_left_ bits of low_, then the stop bit + alignment
         int n = 24 - bits_left_;
@@ -392,11 +420,11 @@ public:
         uint32_t acc = 0; int na = 0;
         for (int i = n - 1; i >= 0; i--) {
             acc = (acc << 1) | ((v >> i) & 1);
-            if (++na == 8) { out_.push_back((uint8_t)acc); acc = 0; na = 0; }
+            if (++na == 8) { out_p_->push_back((uint8_t)acc); acc = 0; na = 0; }
         }
         acc = (acc << 1) | 1; na++;            // rbsp_stop_one_bit
         acc <<= (8 - na);
-        out_.push_back((uint8_t)acc);
+        out_p_->push_back((uint8_t)acc);
     }
     size_t bins() const { return bins_; }
 
@@ -409,16 +437,16 @@ private:
         if (lead == 0xff) { n_buffered_++; return; }
         if (n_buffered_ > 0) {
             uint32_t carry = lead >> 8;
-            out_.push_back((uint8_t)(buffered_ + carry));
+            out_p_->push_back((uint8_t)(buffered_ + carry));
             buffered_ = lead & 0xff;
             uint8_t fill = (uint8_t)(0xff + carry);
-            while (n_buffered_ > 1) { out_.push_back(fill); n_buffered_--; }
+            while (n_buffered_ > 1) { out_p_->push_back(fill); n_buffered_--; }
         } else {
             n_buffered_ = 1;
             buffered_ = lead;
         }
     }
-    std::vector<uint8_t> &out_;
+    std::vector<uint8_t> *out_p_;
     uint8_t state_[kCtxCount];
     uint32_t low_ = 0, range_ = 510, buffered_ = 0xff;
     int bits_left_ = 23, n_buffered_ = 0;
@@ -453,24 +481,33 @@ struct Mv { int ok, x, y; };
 
 class SliceCoder {
 public:
-    SliceCoder(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out)
-        : cfg_(cfg), pic_(pic), cabac_(out)
+    SliceCoder(const mihevc_config &cfg, const PictureSyms &pic) : cfg_(cfg), pic_(pic), cabac_(scratch_)
     {
         CodedSize cs = coded_size(cfg.width, cfg.height);
         w_ = cs.w; h_ = cs.h; w8_ = w_ >> 3;
         wc_ = (w_ + kCtu - 1) >> kCtuLog2; hc_ = (h_ + kCtu - 1) >> kCtuLog2;
         skip_.assign((size_t)w8_ * (h_ >> 3), 0);
         depth_.assign((size_t)w8_ * (h_ >> 3), 0);
+        if (pic.slice_type == 2) grid_ = tile_grid(cfg);
+        grid_.wc = wc_; grid_.hc = hc_;
     }
-    size_t run()
+    const TileGrid &grid() const { return grid_; }
+    // 7.3.8.1 slice_segment_data for tile (tx, ty) into `out`: one CABAC substream.  Every tile but the last ends with
+    // end_of_subset_one_bit + byte_alignment(), the last with end_of_slice_segment_flag = 1 + trailing bits; both are the
+    // same flush (the final written '1' is the alignment / stop bit).
+    size_t run_tile(int tx, int ty, std::vector<uint8_t> &out)
     {
+        cabac_.redirect(out);
         cabac_.init(pic_.slice_type == 2, pic_.qp);
-        for (int ry = 0; ry < hc_; ry++)
-            for (int rx = 0; rx < wc_; rx++) {
+        const bool last_tile = tx == grid_.cols - 1 && ty == grid_.rows - 1;
+        const int x1 = grid_.col_bd(tx + 1), y1 = grid_.row_bd(ty + 1);
+        for (int ry = grid_.row_bd(ty); ry < y1; ry++)
+            for (int rx = grid_.col_bd(tx); rx < x1; rx++) {
                 if (pic_.sao) sao(rx, ry);
                 quadtree(rx << kCtuLog2, ry << kCtuLog2, kCtuLog2, 0);
-                cabac_.terminate(ry == hc_ - 1 && rx == wc_ - 1);
+                cabac_.terminate(last_tile && ry == y1 - 1 && rx == x1 - 1);     // end_of_slice_segment_flag
             }
+        if (!last_tile) cabac_.terminate(1);                                      // end_of_subset_one_bit
         cabac_.finish();
         return cabac_.bins();
     }
@@ -484,9 +521,10 @@ private:
         return z;
     }
     int zaddr(int x, int y) const { return (((y >> kCtuLog2) * wc_ + (x >> kCtuLog2)) << 6) | zorder6((x & 31) >> 2, (y & 31) >> 2); }
-    bool avail(int xc, int yc, int xn, int yn) const   // 6.4.1
+    bool avail(int xc, int yc, int xn, int yn) const   // 6.4.1: earlier in decoding order and in the same tile
     {
-        return xn >= 0 && yn >= 0 && xn < w_ && yn < h_ && zaddr(xn, yn) <= zaddr(xc, yc);
+        if (!(xn >= 0 && yn >= 0 && xn < w_ && yn < h_ && zaddr(xn, yn) <= zaddr(xc, yc))) return false;
+        return !grid_.on() || (grid_.col_of(xn >> kCtuLog2) == grid_.col_of(xc >> kCtuLog2) && grid_.row_of(yn >> kCtuLog2) == grid_.row_of(yc >> kCtuLog2));
     }
 
     // 7.3.8.3
@@ -504,12 +542,12 @@ private:
             }
             return true;
         };
-        if (rx > 0) {
+        if (rx > grid_.col_bd(grid_.col_of(rx))) {       // merge candidates: same slice and tile
             bool m = same(s, pic_.sao[ry * wc_ + rx - 1]);
             cabac_.bin(kSaoMerge, m);
             if (m) return;
         }
-        if (ry > 0) {
+        if (ry > grid_.row_bd(grid_.row_of(ry))) {
             bool m = same(s, pic_.sao[(ry - 1) * wc_ + rx]);
             cabac_.bin(kSaoMerge, m);
             if (m) return;
@@ -879,8 +917,10 @@ private:
 
     const mihevc_config &cfg_;
     const PictureSyms &pic_;
+    std::vector<uint8_t> scratch_;
     Cabac cabac_;
     int w_, h_, w8_, wc_, hc_;
+    TileGrid grid_;
     std::vector<uint8_t> skip_, depth_;
 };
 
@@ -894,7 +934,8 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
     bool idr = pic.slice_type == 2;
     w.put1(1);                       // first_slice_segment_in_pic_flag
     if (idr) w.put1(0);              // no_output_of_prior_pics_flag
-    w.ue(0);                         // slice_pic_parameter_set_id
+    const TileGrid grid = idr ? tile_grid(cfg) : TileGrid();
+    w.ue(grid.on() ? 1 : 0);         // slice_pic_parameter_set_id: PPS 1 carries the IDR tile grid
     w.ue((uint32_t)pic.slice_type);  // 2 = I, 1 = P
     if (!idr) {
         w.put((uint32_t)pic.poc & 0xff, 8);   // slice_pic_order_cnt_lsb
@@ -910,11 +951,43 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
     }
     w.se(pic.qp - 26);               // slice_qp_delta
     w.put1(1);                       // slice_loop_filter_across_slices_enabled_flag
+    SliceCoder coder(cfg, pic);
+    const int n_tiles = grid.cols * grid.rows;
+    std::vector<std::vector<uint8_t>> sub((size_t)n_tiles);
+    size_t bins = 0;
+    for (int t = 0; t < n_tiles; t++) {
+        sub[(size_t)t].reserve(1 << 14);
+        bins += coder.run_tile(t % grid.cols, t / grid.cols, sub[(size_t)t]);
+    }
+    if (grid.on()) {
+        // entry points (7.4.7.1): substream sizes in bytes of the NAL payload, emulation prevention bytes included.  Every
+        // substream (and the header) ends in a byte that holds its final '1' bit, so the zero run that triggers an 0x03
+        // never crosses a boundary and each size can be counted on its own.
+        std::vector<uint32_t> esc((size_t)n_tiles - 1);
+        uint32_t max_off = 0;
+        for (int t = 0; t + 1 < n_tiles; t++) {
+            const std::vector<uint8_t> &v = sub[(size_t)t];
+            uint32_t n = (uint32_t)v.size();
+            int zeros = 0;
+            for (uint8_t b : v) {
+                if (zeros >= 2 && b <= 3) { n++; zeros = 0; }
+                zeros = b == 0 ? zeros + 1 : 0;
+            }
+            esc[(size_t)t] = n;
+            max_off = std::max(max_off, n - 1);
+        }
+        int len = 1;
+        while (len < 32 && (max_off >> len)) len++;
+        w.ue((uint32_t)n_tiles - 1);     // num_entry_point_offsets
+        w.ue((uint32_t)len - 1);         // offset_len_minus1
+        for (uint32_t e : esc) w.put(e - 1, len);   // entry_point_offset_minus1
+    }
     w.trailing();                    // byte_alignment(): same bit pattern as rbsp_trailing_bits
     std::vector<uint8_t> rbsp = std::move(w.bytes());
-    rbsp.reserve(rbsp.size() + (1 << 16));
-    SliceCoder coder(cfg, pic, rbsp);
-    size_t bins = coder.run();
+    size_t total = rbsp.size();
+    for (const auto &v : sub) total += v.size();
+    rbsp.reserve(total);
+    for (const auto &v : sub) rbsp.insert(rbsp.end(), v.begin(), v.end());
     append_nal(out, idr ? 19 : 1, rbsp);
     return bins;
 }

@@ -56,7 +56,18 @@ void append_nal(std::vector<uint8_t> &out, int nal_type, const std::vector<uint8
 
 void write_vps(const mihevc_config &cfg, std::vector<uint8_t> &out);
 void write_sps(const mihevc_config &cfg, std::vector<uint8_t> &out);
-void write_pps(const mihevc_config &cfg, std::vector<uint8_t> &out);
+void write_pps(const mihevc_config &cfg, int pps_id, std::vector<uint8_t> &out);   // id 0: one tile (P pictures); id 1: the IDR tile grid
+
+// uniform tile grid of IDR pictures (6.5.1); cols == rows == 1 when tiles are off
+struct TileGrid {
+    int cols = 1, rows = 1, wc = 0, hc = 0;
+    int col_bd(int i) const { return i * wc / cols; }
+    int row_bd(int j) const { return j * hc / rows; }
+    int col_of(int ctb_x) const { int i = 0; while (i + 1 < cols && col_bd(i + 1) <= ctb_x) i++; return i; }
+    int row_of(int ctb_y) const { int j = 0; while (j + 1 < rows && row_bd(j + 1) <= ctb_y) j++; return j; }
+    bool on() const { return cols > 1 || rows > 1; }
+};
+TileGrid tile_grid(const mihevc_config &cfg);
 void write_sei_hdr10(const mihevc_config &cfg, std::vector<uint8_t> &out);
 void write_aud(int slice_type, std::vector<uint8_t> &out);
 void write_parameter_sets(const mihevc_config &cfg, std::vector<uint8_t> &out);

@@ -46,12 +46,18 @@ template <typename T> __global__ __launch_bounds__(NT, 3) void k_inter_ctu(const
     inter_ctu_program<T>(ex, s, wy, wu, wv, a, ctu);
 }
 
-template <typename T> __global__ __launch_bounds__(NT) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int cy_first)
+// blockIdx.x = tile * rows_per_tile + row inside the tile: every tile row holds at most one CTU of a diagonal
+template <typename T> __global__ __launch_bounds__(NT) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int rows_per_tile)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const IntraArgs<T> &a = args[blockIdx.y];
-    const int cy = cy_first + blockIdx.x, cx = diagonal - 2 * cy;
-    if (cy >= a.ctus_h || cx < 0 || cx >= a.ctus_w) return;
+    const int tcn = a.prm.tile_cols > 1 ? a.prm.tile_cols : 1, trn = a.prm.tile_rows > 1 ? a.prm.tile_rows : 1;
+    const int tile = (int)blockIdx.x / rows_per_tile, r = (int)blockIdx.x % rows_per_tile;
+    if (tile >= tcn * trn) return;
+    const int tx = tile % tcn, ty = tile / tcn;
+    const int cx0 = tile_bd(tx, tcn, a.ctus_w), cx1 = tile_bd(tx + 1, tcn, a.ctus_w), cy0 = tile_bd(ty, trn, a.ctus_h), cy1 = tile_bd(ty + 1, trn, a.ctus_h);
+    const int cy = cy0 + r, cx = cx0 + diagonal - 2 * r;
+    if (cy >= cy1 || cx < cx0 || cx >= cx1) return;
     IntraShared<T> &s = *reinterpret_cast<IntraShared<T> *>(smem);
     GpuExec ex;
     intra_ctu_program<T>(ex, s, a, cx, cy);
@@ -169,16 +175,17 @@ template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArg
     return hipGetLastError();
 }
 
-template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch)
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows)
 {
     size_t smem = round16(sizeof(IntraShared<T>));
     hipError_t e = ensure_smem(k_intra_diag<T>, smem);
     if (e != hipSuccess) return e;
-    for (int d = 0; d <= (ctus_w - 1) + 2 * (ctus_h - 1); d++) {
-        int cy_lo = d - (ctus_w - 1) > 0 ? (d - (ctus_w - 1) + 1) / 2 : 0, cy_hi = d / 2 < ctus_h - 1 ? d / 2 : ctus_h - 1;
-        if (cy_hi < cy_lo) continue;
-        hipLaunchKernelGGL(k_intra_diag<T>, dim3((unsigned)(cy_hi - cy_lo + 1), (unsigned)batch), dim3(NT), smem, st, d_args, d, cy_lo);
-    }
+    if (tile_cols < 1) tile_cols = 1;
+    if (tile_rows < 1) tile_rows = 1;
+    // uniform spacing: the widest column / tallest row is ceil(n_ctb / n_tiles)
+    const int colw = (ctus_w + tile_cols - 1) / tile_cols, rowh = (ctus_h + tile_rows - 1) / tile_rows;
+    for (int d = 0; d <= (colw - 1) + 2 * (rowh - 1); d++)
+        hipLaunchKernelGGL(k_intra_diag<T>, dim3((unsigned)(tile_cols * tile_rows * rowh), (unsigned)batch), dim3(NT), smem, st, d_args, d, rowh);
     return hipGetLastError();
 }
 
@@ -237,7 +244,7 @@ int gfx950_device_count()
 #define INSTANTIATE(T)                                                                                                   \
     template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
-    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int);                      \
+    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                      \
     template hipError_t launch_deblock<T>(hipStream_t, const DeblockArgs<T> *, const DeblockArgs<T> *, int, int, int);  \
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
@@ -330,7 +337,7 @@ template <typename T> struct Planes3 {
     ~Planes3() { for (auto &x : p) free_plane<T>(x); }
 };
 
-CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range}; }
+CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows}; }
 
 bool geometry_ok(int w, int h) { return w >= 16 && h >= 16 && !(w & 7) && !(h & 7) && w <= 8192 && h <= 4352; }
 
@@ -351,7 +358,7 @@ int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, co
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
     a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0;
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
-    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1));
+    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows));
     CK(hipDeviceSynchronize());
     if (int e = rec.download(ry, ru, rv)) return e;
     CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));

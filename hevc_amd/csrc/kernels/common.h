@@ -49,7 +49,11 @@ template <typename T> struct Plane {
 
 struct CostParams {
     int qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
+    int tile_cols, tile_rows;     // intra pictures: uniform tile grid (6.5.1), 1x1 = no tiles
 };
+// uniform tile spacing (6.5.1): first CTB of tile i of n over n_ctb CTBs, and the tile holding a CTB
+HDI int tile_bd(int i, int n, int n_ctb) { return i * n_ctb / n; }
+HDI int tile_of(int ctb, int n, int n_ctb) { int i = 0; while (i + 1 < n && tile_bd(i + 1, n, n_ctb) <= ctb) i++; return i; }
 
 // ------------------------------------------------------------------------------------------ tables
 struct Tables {

@@ -1,6 +1,8 @@
 // hevc_amd/csrc/kernels/intra.h — K2: intra prediction + mode decision (35 modes, SATD) + K3 residual for the CTUs
 // of an I picture.  One 256-thread workgroup per 32x32 CTU; CTUs are launched one anti-diagonal (x + 2y = d) at a
-// time because a CTU predicts from its left, top-left, top and top-right neighbours' reconstructions.
+// time because a CTU predicts from its left, top-left, top and top-right neighbours' reconstructions.  With a tile
+// grid (prm.tile_cols x tile_rows, PPS 1) prediction stops at tile boundaries, so every tile runs its own wavefront and
+// the launch count drops from W + 2(H-1) to w + 2(h-1) CTUs of one tile.
 //
 // Inside the CTU the quadtree is walked depth first exactly like oracle/hevc_oracle.c intra_tree: the four 8x8
 // children of a 16x16 block first, then the 16x16 block itself, keep the cheaper (whole wins ties); then the same
@@ -20,7 +22,7 @@ template <typename T> struct IntraArgs {
     CostParams prm;
     mihevc_cu_rec *cu;
     int16_t *coef[3];
-    int diagonal;                // CTUs with cx + 2*cy == diagonal are processed by this launch
+    int diagonal;                // informational: the launch passes the diagonal as a kernel argument
     unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit)
     int sparse_coef;             // 1: store levels only for TUs with a non-zero level (see InterArgs)
 };
@@ -174,6 +176,12 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
     const Region rg{cx, cy, log2n};
     const int rcnt = rg.count();
     const int gx = x0 + cx, gy = y0 + cy;        // picture coordinates of the CU
+    // tile of this CTU as CTB bounds (neighbours outside it are unavailable, 6.4.1); one tile = the whole picture
+    const int ctu_x = x0 >> CTU_LOG2, ctu_y = y0 >> CTU_LOG2;
+    const int tcn = a.prm.tile_cols > 1 ? a.prm.tile_cols : 1, trn = a.prm.tile_rows > 1 ? a.prm.tile_rows : 1;
+    const int tci = tile_of(ctu_x, tcn, a.ctus_w), tri = tile_of(ctu_y, trn, a.ctus_h);
+    const int tx_lo = tile_bd(tci, tcn, a.ctus_w) << CTU_LOG2, tx_hi = tile_bd(tci + 1, tcn, a.ctus_w) << CTU_LOG2;
+    const int ty_lo = tile_bd(tri, trn, a.ctus_h) << CTU_LOG2;
     // reference samples: availability + raw values for the three planes
     ex.phase([&](int tid) {
         for (int u = tid; u < 3 * 129; u += NT) {
@@ -184,13 +192,13 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             else if (i == 2 * np) { xn = px - 1; yn = py - 1; }
             else { xn = px + (i - 2 * np - 1); yn = py - 1; }
             int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;      // luma picture position of the neighbour
-            bool ok = lx >= 0 && ly >= 0 && lx < a.w && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(gx, gy, a.ctus_w);
+            bool ok = lx >= tx_lo && ly >= ty_lo && lx < a.w && lx < tx_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(gx, gy, a.ctus_w);
             s.avail[pl][i] = ok;
             s.ref_raw[pl][i] = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
         }
         if (tid == 0) {   // 8.4.2 candModeList
             int ma = 1, mb = 1;
-            if (gx > 0) {
+            if (gx > tx_lo) {
                 const mihevc_cu_rec &r = cx > 0 ? s.cu_acc[(cy >> 3) * 4 + ((cx - 1) >> 3)] : s.left_cu[cy >> 3];
                 if (!(r.flags & CU_INTER)) ma = r.intra_mode[0];
             }

@@ -141,6 +141,7 @@ struct mihevc_session {
     mihevc_config cfg;
     int device = 0;
     int w = 0, h = 0, ctus_w = 0, ctus_h = 0, n_ctu = 0;      // coded size
+    TileGrid tiles;                                            // IDR pictures (PPS 1); 1x1 when cfg.intra_tiles == 0
     int keyint = 90, lanes = 4, me_range = 16, qp_p = 22, qp_i = 19;
     bool is16 = false, keep_recon = false, flushed = false, failed = false;
     std::string err;
@@ -328,7 +329,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto prm_for = [&](int qp) {
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
-        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range};
+        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows};
     };
     const int64_t first_index = s->frames_in - n;
     {
@@ -478,7 +479,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             for (int v = 0; v < nv; v++)
                 for (int g = 0; g < B; g++)
                     HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[v] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
-            STAGE(0, nv * B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, nv * B));
+            STAGE(0, nv * B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, nv * B, s->tiles.cols, s->tiles.rows));
             if (nv > 1) {
                 HIPCK(s, hipStreamSynchronize(s->st_compute));
                 for (int g = 0; g < B; g++) {
@@ -621,6 +622,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     CodedSize cs = coded_size(cfg->width, cfg->height);
     s->w = cs.w; s->h = cs.h;
     s->ctus_w = (s->w + CTU - 1) / CTU; s->ctus_h = (s->h + CTU - 1) / CTU; s->n_ctu = s->ctus_w * s->ctus_h;
+    s->tiles = tile_grid(s->cfg);
     s->is16 = cfg->bit_depth > 8;
     s->keyint = cfg->keyint;
     s->lanes = cfg->gops_in_flight > 0 ? std::min(cfg->gops_in_flight, 16) : 4;

@@ -61,7 +61,9 @@ typedef struct mihevc_config {
     int32_t host_threads;             /* CABAC worker threads; 0 = default */
     int32_t sao;                      /* 1 (default -1 -> 1) enable SAO */
     int32_t profile_stages;           /* 1: bracket every stage launch with HIP events on the compute stream (mihevc_stats.stage_ms) */
-    int32_t reserved[7];
+    int32_t intra_tiles;              /* 1 (default): IDR pictures use the largest uniform tile grid the level allows (PPS 1), which
+                                       * cuts the intra CTU wavefront from W+2H to w+2h CTUs of one tile; 0: one tile */
+    int32_t reserved[6];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -112,8 +114,12 @@ const char *mihevc_last_error(const mihevc_session *s);
  *      numbers to the oracle) ---- */
 typedef struct mihevc_cost_params {
     int32_t qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
+    int32_t tile_cols, tile_rows;     /* intra pictures: uniform tile grid (0/1 = one tile); see mihevc_tile_grid */
 } mihevc_cost_params;
-void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);
+void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1 */
+/* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every
+ * column >= 256 and every row >= 64 luma samples (A.4.1), uniform spacing; 1x1 when cfg->intra_tiles == 0. */
+int  mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows);
 
 /* per-8x8-block record produced by the analysis kernels and consumed by deblocking and the host entropy coder */
 typedef struct mihevc_cu_rec {

@@ -172,15 +172,18 @@ struct orc_decoder {
     int have_sps, have_pps, have_vps;
     int w, h, bit_depth, conf[4], log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, th_inter, th_intra;
     int sao_on, strong_intra, poc_bits, num_strps, strps_neg[64], strps_delta[64][4], strps_used[64][4], amp, tmvp;
-    /* PPS */
+    /* PPS (the active one; parse_pps files a copy under its id, decode_slice activates it) */
     int init_qp, sign_hiding, cu_qp_delta, cb_off, cr_off, lf_across, dbk_control, dbk_override_en, pps_dbk_disabled,
         cabac_init_present, par_mrg_level, transform_skip;
+    int tiles, tile_cols, tile_rows, lf_across_tiles, col_bd[22], row_bd[24];
+    struct pps_copy { int valid, v[12], tiles, tile_cols, tile_rows, lf_across_tiles, col_bd[22], row_bd[24]; } pps[4];
     /* pictures */
     picture *pics; int n_pics, cap_pics;
     picture cur; int cur_valid;
     orc_cu_rec *cu; uint8_t *depth8; uint8_t *skip8; orc_sao_ctu *sao;
     /* slice */
     int slice_type, slice_qp, sao_luma, sao_chroma, max_merge, ref_idx;
+    size_t *epb; int n_epb, cap_epb;   /* positions (escaped payload offsets after the NAL header) of the removed 0x03 bytes */
     int poc;
     cabac cb;
     char err[256];
@@ -210,7 +213,7 @@ void orc_dec_close(orc_decoder *d)
 {
     if (!d) return;
     for (int i = 0; i < d->n_pics; i++) free_pic(&d->pics[i]);
-    free(d->pics); free(d->cu); free(d->depth8); free(d->skip8); free(d->sao);
+    free(d->pics); free(d->cu); free(d->depth8); free(d->skip8); free(d->sao); free(d->epb);
     if (d->cur_valid) free_pic(&d->cur);
     free(d);
 }
@@ -403,9 +406,32 @@ static int parse_sps(orc_decoder *d, bitrd *b)
     return 0;
 }
 
+static void save_pps(orc_decoder *d, int id)
+{
+    struct pps_copy *p = &d->pps[id];
+    int v[12] = {d->init_qp, d->sign_hiding, d->cu_qp_delta, d->cb_off, d->cr_off, d->lf_across, d->dbk_control, d->dbk_override_en,
+                 d->pps_dbk_disabled, d->cabac_init_present, d->par_mrg_level, d->transform_skip};
+    memcpy(p->v, v, sizeof v);
+    p->valid = 1; p->tiles = d->tiles; p->tile_cols = d->tile_cols; p->tile_rows = d->tile_rows; p->lf_across_tiles = d->lf_across_tiles;
+    memcpy(p->col_bd, d->col_bd, sizeof p->col_bd); memcpy(p->row_bd, d->row_bd, sizeof p->row_bd);
+}
+static int activate_pps(orc_decoder *d, int id)
+{
+    if (id < 0 || id > 3 || !d->pps[id].valid) return -1;
+    const struct pps_copy *p = &d->pps[id];
+    d->init_qp = p->v[0]; d->sign_hiding = p->v[1]; d->cu_qp_delta = p->v[2]; d->cb_off = p->v[3]; d->cr_off = p->v[4]; d->lf_across = p->v[5];
+    d->dbk_control = p->v[6]; d->dbk_override_en = p->v[7]; d->pps_dbk_disabled = p->v[8]; d->cabac_init_present = p->v[9];
+    d->par_mrg_level = p->v[10]; d->transform_skip = p->v[11];
+    d->tiles = p->tiles; d->tile_cols = p->tile_cols; d->tile_rows = p->tile_rows; d->lf_across_tiles = p->lf_across_tiles;
+    memcpy(d->col_bd, p->col_bd, sizeof p->col_bd); memcpy(d->row_bd, p->row_bd, sizeof p->row_bd);
+    return 0;
+}
+
 static int parse_pps(orc_decoder *d, bitrd *b)
 {
-    if (br_ue(b) || br_ue(b)) { set_err(d, "pps: ids"); return -1; }
+    int pps_id = (int)br_ue(b);
+    if (pps_id > 3 || br_ue(b)) { set_err(d, "pps: ids"); return -1; }
+    if (!d->have_sps) { set_err(d, "pps before sps"); return -1; }
     if (br_bit(b)) { set_err(d, "pps: dependent slices"); return -1; }
     if (br_bit(b)) { set_err(d, "pps: output_flag_present"); return -1; }
     if (br_u(b, 3)) { set_err(d, "pps: extra slice header bits"); return -1; }
@@ -423,8 +449,32 @@ static int parse_pps(orc_decoder *d, bitrd *b)
     if (br_bit(b)) { set_err(d, "pps: slice chroma offsets"); return -1; }
     if (br_bit(b) || br_bit(b)) { set_err(d, "pps: weighted prediction"); return -1; }
     if (br_bit(b)) { set_err(d, "pps: transquant bypass"); return -1; }
-    if (br_bit(b)) { set_err(d, "pps: tiles"); return -1; }
+    d->tiles = br_bit(b);
     if (br_bit(b)) { set_err(d, "pps: wpp"); return -1; }
+    {   /* 7.3.2.3 tiles + 6.5.1 column / row boundaries */
+        int wc = (d->w + (1 << d->log2_ctb) - 1) >> d->log2_ctb, hc = (d->h + (1 << d->log2_ctb) - 1) >> d->log2_ctb;
+        d->tile_cols = d->tile_rows = 1; d->lf_across_tiles = 1;
+        d->col_bd[0] = d->row_bd[0] = 0;
+        if (d->tiles) {
+            d->tile_cols = 1 + (int)br_ue(b); d->tile_rows = 1 + (int)br_ue(b);
+            if (d->tile_cols > 20 || d->tile_rows > 22 || d->tile_cols > wc || d->tile_rows > hc || (d->tile_cols == 1 && d->tile_rows == 1)) {
+                set_err(d, "pps: tile grid %dx%d", d->tile_cols, d->tile_rows); return -1;
+            }
+            if (br_bit(b)) {      /* uniform_spacing_flag */
+                for (int i = 0; i <= d->tile_cols; i++) d->col_bd[i] = i * wc / d->tile_cols;
+                for (int i = 0; i <= d->tile_rows; i++) d->row_bd[i] = i * hc / d->tile_rows;
+            } else {
+                for (int i = 0; i < d->tile_cols - 1; i++) d->col_bd[i + 1] = d->col_bd[i] + 1 + (int)br_ue(b);
+                for (int i = 0; i < d->tile_rows - 1; i++) d->row_bd[i + 1] = d->row_bd[i] + 1 + (int)br_ue(b);
+                d->col_bd[d->tile_cols] = wc; d->row_bd[d->tile_rows] = hc;
+            }
+            for (int i = 0; i < d->tile_cols; i++) if ((d->col_bd[i + 1] - d->col_bd[i]) << d->log2_ctb < 256) { set_err(d, "pps: tile column narrower than 256 luma samples (A.4.1)"); return -1; }
+            for (int i = 0; i < d->tile_rows; i++) if ((d->row_bd[i + 1] - d->row_bd[i]) << d->log2_ctb < 64) { set_err(d, "pps: tile row lower than 64 luma samples (A.4.1)"); return -1; }
+            d->lf_across_tiles = br_bit(b);
+            if (!d->lf_across_tiles) { set_err(d, "pps: loop filter across tiles disabled"); return -1; }
+        }
+        d->col_bd[d->tile_cols] = wc; d->row_bd[d->tile_rows] = hc;
+    }
     d->lf_across = br_bit(b);
     d->dbk_control = br_bit(b);
     if (d->dbk_control) { set_err(d, "pps: deblocking control"); return -1; }
@@ -435,6 +485,8 @@ static int parse_pps(orc_decoder *d, bitrd *b)
     if (br_bit(b)) { set_err(d, "pps: extension"); return -1; }
     if (!br_trailing_ok(b) || b->err) { set_err(d, "pps: trailing bits"); return -1; }
     put_kv(d, "pps.init_qp", d->init_qp); put_kv(d, "pps.sign_hiding", d->sign_hiding);
+    if (d->tiles) { put_kv(d, "pps.tile_cols", d->tile_cols); put_kv(d, "pps.tile_rows", d->tile_rows); }
+    save_pps(d, pps_id);
     d->have_pps = 1;
     return 0;
 }
@@ -480,9 +532,17 @@ static inline int zaddr(const orc_decoder *d, int x, int y)
     return (((y >> ORC_CTU_LOG2) * wc + (x >> ORC_CTU_LOG2)) << 6) | zorder6((x & 31) >> 2, (y & 31) >> 2);
 }
 /* 6.4.1 z-scan availability of (xn,yn) seen from (xc,yc) */
+static inline int tile_col_of(const orc_decoder *d, int ctb_x) { int i = 0; while (i + 1 < d->tile_cols && d->col_bd[i + 1] <= ctb_x) i++; return i; }
+static inline int tile_row_of(const orc_decoder *d, int ctb_y) { int i = 0; while (i + 1 < d->tile_rows && d->row_bd[i + 1] <= ctb_y) i++; return i; }
+static inline int same_tile_d(const orc_decoder *d, int xa, int ya, int xb, int yb)
+{
+    return tile_col_of(d, xa >> d->log2_ctb) == tile_col_of(d, xb >> d->log2_ctb) && tile_row_of(d, ya >> d->log2_ctb) == tile_row_of(d, yb >> d->log2_ctb);
+}
+/* inside one tile the tile scan is the raster scan of its CTBs, so "earlier in decoding order" is the picture-raster
+ * z-order comparison restricted to the same tile (6.4.1 with 6.5.1) */
 static inline int avail_z(const orc_decoder *d, int xc, int yc, int xn, int yn)
 {
-    return xn >= 0 && yn >= 0 && xn < d->w && yn < d->h && zaddr(d, xn, yn) <= zaddr(d, xc, yc);
+    return xn >= 0 && yn >= 0 && xn < d->w && yn < d->h && zaddr(d, xn, yn) <= zaddr(d, xc, yc) && same_tile_d(d, xn, yn, xc, yc);
 }
 static inline orc_cu_rec *cu_at(orc_decoder *d, int x, int y) { return &d->cu[(y >> 3) * (d->w >> 3) + (x >> 3)]; }
 
@@ -645,7 +705,8 @@ static void intra_predict_block(orc_decoder *d, int c_idx, int x, int y, int log
 {
     pix ref[129], filt[129];
     int s = c_idx ? 1 : 0;
-    orc_intra_build_ref(d->cur.pl[c_idx], d->cur.stride[c_idx], x, y, log2n, d->w >> s, d->h >> s, NULL, 0, c_idx, d->bit_depth, ref);
+    if (d->tiles && (d->col_bd[1] != 1 * ((d->w + 31) >> 5) / d->tile_cols || d->row_bd[1] != 1 * ((d->h + 31) >> 5) / d->tile_rows)) set_err(d, "non-uniform tile grids are parsed but not predicted");
+    orc_intra_build_ref_tiles(d->cur.pl[c_idx], d->cur.stride[c_idx], x, y, log2n, d->w >> s, d->h >> s, c_idx, d->bit_depth, d->tile_cols, d->tile_rows, ref);
     orc_intra_filter_ref(ref, filt, log2n, mode, c_idx, d->bit_depth, d->strong_intra);
     orc_intra_pred(filt, d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x, d->cur.stride[c_idx], log2n, mode, c_idx, d->bit_depth);
 }
@@ -942,8 +1003,9 @@ static void parse_sao(orc_decoder *d, int rx, int ry)
     int wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2;
     orc_sao_ctu *o = &d->sao[ry * wc + rx];
     memset(o, 0, sizeof *o);
-    if (rx > 0 && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[ry * wc + rx - 1]; goto mask; }
-    if (ry > 0 && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[(ry - 1) * wc + rx]; goto mask; }
+    /* merge candidates must lie in the same slice and tile (7.3.8.3) */
+    if (rx > d->col_bd[tile_col_of(d, rx)] && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[ry * wc + rx - 1]; goto mask; }
+    if (ry > d->row_bd[tile_row_of(d, ry)] && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[(ry - 1) * wc + rx]; goto mask; }
     for (int ci = 0; ci < 3; ci++) {
         if ((ci == 0 && !d->sao_luma) || (ci > 0 && !d->sao_chroma)) continue;
         int t = ci ? 1 : 0;
@@ -966,6 +1028,14 @@ mask:
     if (!d->sao_chroma) o->type[1] = 0;
 }
 
+/* number of emulation prevention bytes removed before rbsp offset r of the current NAL */
+static size_t epb_before(const orc_decoder *d, size_t r)
+{
+    size_t k = 0;
+    while ((int)k < d->n_epb && d->epb[k] <= r + k) k++;
+    return k;
+}
+
 static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_type)
 {
     if (!d->have_sps || !d->have_pps) { set_err(d, "slice before parameter sets"); return -1; }
@@ -973,7 +1043,7 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
     if (!br_bit(&b)) { set_err(d, "multiple slice segments unsupported"); return -1; }
     int irap = nal_type >= 16 && nal_type <= 23, idr = nal_type == 19 || nal_type == 20;
     if (irap) br_bit(&b);
-    if (br_ue(&b)) { set_err(d, "slice: pps id"); return -1; }
+    if (activate_pps(d, (int)br_ue(&b))) { set_err(d, "slice: pps id"); return -1; }
     d->slice_type = (int)br_ue(&b);
     if (d->slice_type == 0) { set_err(d, "B slices unsupported"); return -1; }
     d->poc = 0;
@@ -998,6 +1068,15 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
     }
     d->slice_qp = d->init_qp + br_se(&b);
     if (d->lf_across) br_bit(&b);      /* slice_loop_filter_across_slices_enabled_flag: deblocking is on, so present */
+    int n_entry = 0;
+    uint32_t entry[20 * 22];
+    if (d->tiles) {
+        n_entry = (int)br_ue(&b);
+        if (n_entry != d->tile_cols * d->tile_rows - 1) { set_err(d, "slice: %d entry points for %d tiles", n_entry, d->tile_cols * d->tile_rows); return -1; }
+        int len = 1 + (int)br_ue(&b);
+        if (len > 32) { set_err(d, "slice: offset_len"); return -1; }
+        for (int i = 0; i < n_entry; i++) entry[i] = 1 + br_u(&b, len);
+    }
     if (!br_bit(&b)) { set_err(d, "slice: byte_alignment bit"); return -1; }
     while (b.pos & 7) if (br_bit(&b)) { set_err(d, "slice: alignment zero bits"); return -1; }
     if (b.err) { set_err(d, "slice header truncated"); return -1; }
@@ -1014,17 +1093,50 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
     memset(d->sao, 0, sizeof(orc_sao_ctu) * wc * hc);
     alloc_pic(d, &d->cur); d->cur_valid = 1; d->cur.poc = d->poc;
     build_scans();
-    cb_init(&d->cb, rbsp + (b.pos >> 3), n - (b.pos >> 3), d->slice_type == 2 ? 0 : 1, d->slice_qp);
     int ok = -1;
-    for (int ry = 0; ry < hc; ry++)
-        for (int rx = 0; rx < wc; rx++) {
-            if (d->sao_luma || d->sao_chroma) parse_sao(d, rx, ry);
-            if (coding_quadtree(d, rx << ORC_CTU_LOG2, ry << ORC_CTU_LOG2, ORC_CTU_LOG2, 0)) goto done;
-            int end = cb_terminate(&d->cb);
-            int last = ry == hc - 1 && rx == wc - 1;
-            if (end != last) { set_err(d, "end_of_slice_segment_flag=%d at ctu (%d,%d)", end, rx, ry); goto done;}
+    /* slice_segment_data (7.3.8.1) in tile scan; every tile is one CABAC substream that starts at its entry point.
+     * Entry points count bytes of the NAL payload WITH emulation prevention bytes (7.4.7.1): map through epb[]. */
+    size_t data0 = b.pos >> 3;            /* rbsp offset of the slice segment data */
+    size_t sub_start = data0;             /* rbsp offset of the current substream */
+    int n_tiles = d->tile_cols * d->tile_rows;
+    for (int t = 0; t < n_tiles; t++) {
+        int tx = t % d->tile_cols, ty = t / d->tile_cols;
+        size_t sub_end = n;
+        if (t < n_entry) {
+            /* escaped start of this substream = its rbsp start + EPBs before it; add the signalled size; map back */
+            size_t esc_start = sub_start + epb_before(d, sub_start), esc_end = esc_start + entry[t];
+            size_t e = esc_end;           /* rbsp position r with r + epb_before(r) == esc_end */
+            for (int k = 0; k < d->n_epb && d->epb[k] < esc_end; k++) e--;
+            sub_end = e;
+            if (sub_end > n || sub_end <= sub_start) { set_err(d, "slice: entry point %d out of range", t); goto done; }
         }
-    if (d->cb.err) { set_err(d, "slice data truncated"); goto done; }
+        cb_init(&d->cb, rbsp + sub_start, sub_end - sub_start, d->slice_type == 2 ? 0 : 1, d->slice_qp);
+        for (int ry = d->row_bd[ty]; ry < d->row_bd[ty + 1]; ry++)
+            for (int rx = d->col_bd[tx]; rx < d->col_bd[tx + 1]; rx++) {
+                if (d->sao_luma || d->sao_chroma) parse_sao(d, rx, ry);
+                if (coding_quadtree(d, rx << ORC_CTU_LOG2, ry << ORC_CTU_LOG2, ORC_CTU_LOG2, 0)) goto done;
+                int end = cb_terminate(&d->cb);
+                int last = t == n_tiles - 1 && ry == d->row_bd[ty + 1] - 1 && rx == d->col_bd[tx + 1] - 1;
+                if (end != last) { set_err(d, "end_of_slice_segment_flag=%d at ctu (%d,%d)", end, rx, ry); goto done;}
+            }
+        if (d->cb.err) { set_err(d, "slice data truncated (tile %d)", t); goto done; }
+        if (t < n_tiles - 1) {
+            /* end_of_subset_one_bit, then byte_alignment().  The encoder's flush (9.3.4.5: 7-bit renormalisation, put_bits(1),
+             * write_bits(((low >> 7) & 3) | 1, 2)) puts its final '1' -- which IS alignment_bit_equal_to_one -- on the last bit of
+             * the 9-bit window the arithmetic decoder holds when it decodes the terminating bin (no renormalisation follows a
+             * terminating 1).  So: the last bit read is 1, only zero bits follow in that byte, and the next byte is the entry point. */
+            if (!cb_terminate(&d->cb)) { set_err(d, "end_of_subset_one_bit != 1 after tile %d", t); goto done; }
+            {
+                const uint8_t *sp = rbsp + sub_start;
+                size_t next_bit = d->cb.pos * 8 + (d->cb.bits_left ? 8 - (size_t)d->cb.bits_left : 0), last = next_bit - 1;
+                if (d->cb.err || last / 8 >= sub_end - sub_start) { set_err(d, "tile %d: substream overrun", t); goto done; }
+                if (!((sp[last >> 3] >> (7 - (last & 7))) & 1)) { set_err(d, "tile %d: alignment_bit_equal_to_one missing", t); goto done; }
+                if (sp[last >> 3] & ((1u << (7 - (last & 7))) - 1)) { set_err(d, "tile %d: non-zero alignment bits", t); goto done; }
+                if ((last >> 3) + 1 != sub_end - sub_start) { set_err(d, "tile %d: substream is %zu bytes, entry point says %zu", t, (last >> 3) + 1, sub_end - sub_start); goto done; }
+            }
+        }
+        sub_start = sub_end;
+    }
     /* in-loop filters, then the picture becomes a reference */
     orc_deblock_frame(d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1], d->w, d->h, d->cu, d->bit_depth, d->cb_off);
     if (d->sao_luma || d->sao_chroma) {
@@ -1058,8 +1170,13 @@ int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
         int type = (data[s] >> 1) & 63, tid = data[s + 1] & 7;
         if (tid != 1 || ((data[s] & 1) << 5 | data[s + 1] >> 3) != 0) { set_err(d, "nuh layer/temporal id"); break; }
         size_t m = 0; int zeros = 0;
+        d->n_epb = 0;
         for (size_t k = s + 2; k < e; k++) {
-            if (zeros >= 2 && data[k] == 3) { zeros = 0; continue; }
+            if (zeros >= 2 && data[k] == 3) {
+                if (d->n_epb == d->cap_epb) { d->cap_epb = d->cap_epb ? d->cap_epb * 2 : 64; d->epb = (size_t *)realloc(d->epb, sizeof(size_t) * d->cap_epb); }
+                d->epb[d->n_epb++] = k - (s + 2);
+                zeros = 0; continue;
+            }
             if (zeros >= 2 && data[k] < 3) { set_err(d, "start-code emulation inside NAL type %d", type); goto out; }
             rbsp[m++] = data[k];
             zeros = data[k] == 0 ? zeros + 1 : 0;

@@ -154,8 +154,24 @@ void orc_intra_build_ref(const pix *rec, int stride, int x0, int y0, int log2n, 
                          const uint8_t *avail_map, int map_stride, int c_idx, int bit_depth, pix *ref)
 {
     (void)avail_map; (void)map_stride;
+    orc_intra_build_ref_tiles(rec, stride, x0, y0, log2n, pic_w, pic_h, c_idx, bit_depth, 1, 1, ref);
+}
+
+static int same_tile(int xa, int ya, int xb, int yb, int lw, int lh, int tc, int tr)   /* luma positions */
+{
+    if (tc <= 1 && tr <= 1) return 1;
+    int wc = (lw + ORC_CTU - 1) >> ORC_CTU_LOG2, hc = (lh + ORC_CTU - 1) >> ORC_CTU_LOG2;
+    if (tc < 1) tc = 1;
+    if (tr < 1) tr = 1;
+    return orc_tile_of(xa >> ORC_CTU_LOG2, tc, wc) == orc_tile_of(xb >> ORC_CTU_LOG2, tc, wc) &&
+           orc_tile_of(ya >> ORC_CTU_LOG2, tr, hc) == orc_tile_of(yb >> ORC_CTU_LOG2, tr, hc);
+}
+
+void orc_intra_build_ref_tiles(const pix *rec, int stride, int x0, int y0, int log2n, int pic_w, int pic_h,
+                               int c_idx, int bit_depth, int tile_cols, int tile_rows, pix *ref)
+{
     int n = 1 << log2n, s = c_idx ? 1 : 0, total = 4 * n + 1;
-    int lw = pic_w << s;
+    int lw = pic_w << s, lh = pic_h << s;
     int zc = zaddr(x0 << s, y0 << s, lw);
     uint8_t av[4 * 32 + 1];
     for (int i = 0; i < total; i++) {
@@ -163,7 +179,8 @@ void orc_intra_build_ref(const pix *rec, int stride, int x0, int y0, int log2n, 
         if (i < 2 * n) { xn = x0 - 1; yn = y0 + 2 * n - 1 - i; }
         else if (i == 2 * n) { xn = x0 - 1; yn = y0 - 1; }
         else { xn = x0 + (i - 2 * n - 1); yn = y0 - 1; }
-        int ok = xn >= 0 && yn >= 0 && xn < pic_w && yn < pic_h && zaddr(xn << s, yn << s, lw) < zc;
+        int ok = xn >= 0 && yn >= 0 && xn < pic_w && yn < pic_h && zaddr(xn << s, yn << s, lw) < zc &&
+                 same_tile(xn << s, yn << s, x0 << s, y0 << s, lw, lh, tile_cols, tile_rows);
         av[i] = (uint8_t)ok;
         ref[i] = ok ? rec[yn * stride + xn] : 0;
     }
@@ -665,7 +682,7 @@ typedef struct {
 static void mpm_list(const intra_ctx *c, int x, int y, int cand[3])
 {
     int a = 1, b = 1;
-    if (x > 0) {
+    if (x > 0 && same_tile(x - 1, y, x, y, c->w, c->h, c->prm->tile_cols, c->prm->tile_rows)) {
         const orc_cu_rec *r = &c->cu[(y >> 3) * c->w8 + ((x - 1) >> 3)];
         if (!(r->flags & ORC_F_INTER)) a = r->intra_mode[0];
     }
@@ -696,7 +713,7 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
     pix ref[129], filt[129], pred[32 * 32];
     int cand[3];
     mpm_list(c, x, y, cand);
-    orc_intra_build_ref(c->rec[0], c->rstride[0], x, y, log2n, c->w, c->h, NULL, 0, 0, bd, ref);
+    orc_intra_build_ref_tiles(c->rec[0], c->rstride[0], x, y, log2n, c->w, c->h, 0, bd, prm->tile_cols, prm->tile_rows, ref);
     uint64_t best = ~0ull;
     const pix *s = c->src[0] + y * c->sstride[0] + x;
     for (int mode = 0; mode < 35; mode++) {
@@ -718,7 +735,7 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
     sse_total += sse; bits_total += bits;
     for (int ci = 1; ci < 3; ci++) {
         int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
-        orc_intra_build_ref(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, NULL, 0, ci, bd, ref);
+        orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
         orc_intra_pred(ref, pred, nc, l2, mode, ci, bd);
         if (code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc,
                     c->rec[ci] + yc * c->rstride[ci] + xc, c->rstride[ci], c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1,

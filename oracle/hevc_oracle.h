@@ -66,6 +66,8 @@ typedef struct {
     int lambda_sad_q4; /* sqrt(lambda_mode) * 16 */
     int lambda_q4;     /* lambda_mode * 16  (SSE domain) */
     int me_range;      /* integer search +-range, <= 64 */
+    int tile_cols, tile_rows; /* intra pictures: uniform tile grid (6.5.1); 0 or 1 = one tile.  Neighbours in another tile
+                                * are unavailable for prediction (6.4.1), which is what shortens the CTU wavefront */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */
@@ -78,6 +80,12 @@ void orc_transform_matrix(int16_t *out32x32);
 
 void orc_intra_build_ref(const pix *rec, int stride, int x0, int y0, int log2n, int pic_w, int pic_h,
                          const uint8_t *avail_map, int map_stride, int c_idx, int bit_depth, pix *ref /*4N+1*/);
+/* same with a uniform tile grid: samples of another tile are unavailable */
+void orc_intra_build_ref_tiles(const pix *rec, int stride, int x0, int y0, int log2n, int pic_w, int pic_h,
+                               int c_idx, int bit_depth, int tile_cols, int tile_rows, pix *ref);
+/* first CTB column (row) of tile column (row) i of n over n_ctb CTBs, uniform spacing (6.5.1) */
+static inline int orc_tile_bd(int i, int n, int n_ctb) { return i * n_ctb / n; }
+static inline int orc_tile_of(int ctb, int n, int n_ctb) { int i = 0; while (i + 1 < n && orc_tile_bd(i + 1, n, n_ctb) <= ctb) i++; return i; }
 void orc_intra_filter_ref(const pix *ref, pix *filt, int log2n, int mode, int c_idx, int bit_depth, int strong);
 void orc_intra_pred(const pix *ref, pix *dst, int dstride, int log2n, int mode, int c_idx, int bit_depth);
 

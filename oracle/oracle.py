@@ -28,7 +28,7 @@ def build(force: bool = False) -> Path:
 
 class Params(C.Structure):
     _fields_ = [("qp", C.c_int), ("qp_c", C.c_int), ("bit_depth", C.c_int), ("lambda_sad_q4", C.c_int),
-                ("lambda_q4", C.c_int), ("me_range", C.c_int)]
+                ("lambda_q4", C.c_int), ("me_range", C.c_int), ("tile_cols", C.c_int), ("tile_rows", C.c_int)]
 
 
 CU_DTYPE = np.dtype([("log2_size", "u1"), ("flags", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("intra_mode", "u1", (4,)),
@@ -59,7 +59,7 @@ def _p(a):
 def default_params(qp: int, bit_depth: int = 8, me_range: int = 16) -> Params:
     """Same integer cost parameters the product derives (mihevc_cost_params): lambda = 0.57 * 2^((qp-12)/3)."""
     lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
-    return Params(qp, int(lib().orc_chroma_qp(qp)), bit_depth, int(round(16 * lam ** 0.5)), int(round(16 * lam)), me_range)
+    return Params(qp, int(lib().orc_chroma_qp(qp)), bit_depth, int(round(16 * lam ** 0.5)), int(round(16 * lam)), me_range, 1, 1)
 
 
 # ---------------------------------------------------------------- primitives
@@ -286,7 +286,7 @@ def decode(stream: bytes):
                   "vui.full_range", "vui.chroma_loc_present", "vui.chroma_loc_top", "vui.num_units_in_tick", "vui.time_scale",
                   "vui.hrd_present", "vps.num_units_in_tick", "vps.time_scale", "count.aud", "count.slices", "sei.137.size", "sei.144.size",
                   "sei.mdcv.gx", "sei.mdcv.gy", "sei.mdcv.bx", "sei.mdcv.by", "sei.mdcv.rx", "sei.mdcv.ry", "sei.mdcv.wpx", "sei.mdcv.wpy",
-                  "sei.mdcv.max_lum", "sei.mdcv.min_lum", "sei.cll.max_cll", "sei.cll.max_fall", "pps.init_qp", "slice.last_qp",
+                  "sei.mdcv.max_lum", "sei.mdcv.min_lum", "sei.cll.max_cll", "sei.cll.max_fall", "pps.init_qp", "pps.tile_cols", "pps.tile_rows", "slice.last_qp",
                   "slice.max_merge", "sps.conf_right", "sps.conf_bottom", "sps.sao", "sps.amp", "sps.strong_intra", "sps.poc_bits",
                   "vps.level_idc", "hrd.bit_rate_value_minus1", "hrd.cpb_size_value_minus1", "hrd.bit_rate_scale", "hrd.cpb_size_scale"):
             info[k] = q(k)

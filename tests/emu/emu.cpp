@@ -37,7 +37,7 @@ template <typename T> struct Padded {
 
 static CostParams to_prm(const mihevc_cost_params *p)
 {
-    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range};
+    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows};
 }
 
 template <typename T>
@@ -85,12 +85,16 @@ static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, cons
     a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0;
     if (est) *est = 0;
     SeqExec ex;
-    // same launch order as the device: one anti-diagonal (cx + 2 cy) at a time
-    for (int d = 0; d <= (a.ctus_w - 1) + 2 * (a.ctus_h - 1); d++) {
+    // same launch order as the device: per tile, one anti-diagonal (cx + 2 cy inside the tile) at a time
+    const int tcn = a.prm.tile_cols > 1 ? a.prm.tile_cols : 1, trn = a.prm.tile_rows > 1 ? a.prm.tile_rows : 1;
+    const int colw = (a.ctus_w + tcn - 1) / tcn, rowh = (a.ctus_h + trn - 1) / trn;
+    for (int d = 0; d <= (colw - 1) + 2 * (rowh - 1); d++) {
         a.diagonal = d;
-        for (int cyi = 0; cyi < a.ctus_h; cyi++) {
-            int cxi = d - 2 * cyi;
-            if (cxi < 0 || cxi >= a.ctus_w) continue;
+        for (int b = 0; b < tcn * trn * rowh; b++) {
+            const int tile = b / rowh, r = b % rowh, tx = tile % tcn, ty = tile / tcn;
+            const int cx0 = tile_bd(tx, tcn, a.ctus_w), cx1 = tile_bd(tx + 1, tcn, a.ctus_w), cy0 = tile_bd(ty, trn, a.ctus_h), cy1 = tile_bd(ty + 1, trn, a.ctus_h);
+            const int cyi = cy0 + r, cxi = cx0 + d - 2 * r;
+            if (cyi >= cy1 || cxi < cx0 || cxi >= cx1) continue;
             IntraShared<T> *is = new IntraShared<T>();
             intra_ctu_program<T>(ex, *is, a, cxi, cyi);
             delete is;

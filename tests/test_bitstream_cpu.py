@@ -19,6 +19,7 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000):
     headers = bytes(buf[:n])
     stream, recs, packets, ref = headers, [], [], None
     prm_i, prm_p = O.default_params(max(0, qp - 3), bd, me_range), O.default_params(qp, bd, me_range)
+    prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # IDR pictures are analysed for the grid PPS 1 signals
     for i, src in enumerate(srcs):
         intra = i % keyint == 0
         prm = prm_i if intra else prm_p
@@ -52,6 +53,44 @@ def test_stream_decodes_to_the_oracle_reconstruction(w, h, qp, bd, n, keyint):
     assert len(frames) == n and info["count.aud"] == n and info["bit_depth"] == bd
     for i, (f, r) in enumerate(zip(frames, recs)):
         assert f.same(r), f"picture {i} differs after decode"
+
+
+@pytest.mark.parametrize("w,h,level,grid,qp,bd", [(512, 128, 120, (2, 2), 30, 8), (544, 160, 120, (2, 2), 24, 8), (800, 224, 93, (3, 3), 34, 8),
+                                                  (512, 192, 150, (2, 3), 28, 10), (512, 128, 63, (1, 1), 30, 8)])
+def test_idr_tiles_decode_to_the_oracle_reconstruction(w, h, level, grid, qp, bd):
+    # IDR pictures use PPS 1 (uniform tile grid, as many tiles as Table A.8 / A.4.1 allow): prediction, MPM, CABAC contexts and
+    # SAO merge stop at tile borders, every tile is its own CABAC substream behind an entry point.  P pictures keep PPS 0.
+    cfg = make_cfg(w, h, bd, level_idc=level)
+    assert _lib.tile_grid(cfg) == grid
+    srcs = [util.synth_frame(h, w, seed=21, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
+    _, stream, recs, packets = encode_pictures(cfg, srcs, qp, bd, keyint=2)
+    frames, info = O.decode(stream)
+    assert len(frames) == 3
+    for i, (f, r) in enumerate(zip(frames, recs)):
+        assert f.same(r), f"picture {i} differs after decode"
+    if grid != (1, 1):
+        assert (info["pps.tile_cols"], info["pps.tile_rows"]) == grid
+    # the same pictures without tiles: different bits (prediction crosses the borders), same machinery
+    cfg0 = make_cfg(w, h, bd, level_idc=level, intra_tiles=0)
+    assert _lib.tile_grid(cfg0) == (1, 1)
+    _, stream0, recs0, _ = encode_pictures(cfg0, srcs, qp, bd, keyint=2)
+    frames0, _ = O.decode(stream0)
+    assert all(f.same(r) for f, r in zip(frames0, recs0))
+    if grid != (1, 1):
+        assert stream0 != stream
+
+
+def test_tile_entry_points_are_checked():
+    # flipping a bit inside the entry-point table must be caught by the decoder's substream-size check
+    cfg = make_cfg(512, 128, level_idc=120)
+    _, stream, _, packets = encode_pictures(cfg, [util.synth_frame(128, 512, seed=3)], 30, 8)
+    frames, _ = O.decode(stream)
+    assert len(frames) == 1
+    headers_len = len(stream) - len(packets[0][0])
+    bad = bytearray(stream)
+    bad[headers_len + 4 + 2 + 2] ^= 0x04         # start code (4) + NAL header (2) + 2 bytes into the slice header: offset bits
+    with pytest.raises(Exception):
+        O.decode(bytes(bad))
 
 
 def test_sao_off_and_skip_heavy_static_content():

@@ -84,6 +84,17 @@ def test_stage_parity_i_p_p(lib, api, w, h, qp, bd, rng):
         ref = f
 
 
+@pytest.mark.parametrize("w,h,grid,qp,bd", [(544, 160, (2, 2), 26, 8), (800, 224, (3, 3), 33, 8), (512, 192, (2, 3), 22, 10), (1920, 1080, (5, 5), 24, 8)])
+def test_intra_tile_grid_parity(lib, api, w, h, grid, qp, bd):
+    """K2 with the IDR tile grid (every tile its own CTU wavefront) against the oracle, up to the full 1080p 5x5 grid."""
+    prm, cp = lib_params(lib, qp, bd, 8)
+    prm.tile_cols, prm.tile_rows = grid
+    cp.tile_cols, cp.tile_rows = grid
+    src = util.synth_frame(h, w, seed=9, bit_depth=bd)
+    want, got = O.analyze_intra(src, prm), api.intra(src, cp)
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+
+
 def test_search_centres(lib, api):
     w, h = 96, 64
     prm, cp = lib_params(lib, 26, 8, 8)
@@ -115,7 +126,7 @@ def _encode(cfg, frames, keep=True):
         return out, recs, st, enc.coded_size()
 
 
-@pytest.mark.parametrize("w,h,bd,keyint,n", [(96, 80, 8, 4, 10), (132, 76, 8, 5, 7), (64, 64, 10, 3, 7)])
+@pytest.mark.parametrize("w,h,bd,keyint,n", [(96, 80, 8, 4, 10), (132, 76, 8, 5, 7), (64, 64, 10, 3, 7), (544, 160, 8, 3, 7)])
 def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint, n):
     """End to end: session -> Annex-B -> oracle decoder must equal the encoder's own reconstruction AND the oracle
     pipeline run with the same QPs; includes non-multiple-of-8 sizes (conformance window) and a short last GOP."""
@@ -135,6 +146,8 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     qp_p, qp_i = st.last_qp, max(0, st.last_qp - 3)
     prm_i, _ = lib_params(lib, qp_i, bd, 8)
     prm_p, _ = lib_params(lib, qp_p, bd, 8)
+    prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
+    assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     ref = None
     for i, f in enumerate(frames):
         pad = O.Frame(np.pad(f.y, ((0, ch - h), (0, cw - w)), mode="edge"), np.pad(f.u, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"),

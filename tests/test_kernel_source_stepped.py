@@ -56,6 +56,18 @@ def test_stepped_kernels_equal_oracle(emu, w, h, qp, bd, rng):
     assert len(sizes) >= 2 or qp >= 30
 
 
+@pytest.mark.parametrize("w,h,grid,qp,bd", [(544, 160, (2, 2), 26, 8), (800, 224, (3, 3), 33, 8), (512, 192, (2, 3), 22, 10)])
+def test_stepped_intra_with_tile_grid(emu, w, h, grid, qp, bd):
+    """IDR pictures are analysed per tile: neighbours across a tile border are unavailable (prediction and MPM)."""
+    prm = O.default_params(qp, bit_depth=bd)
+    prm.tile_cols, prm.tile_rows = grid
+    src = util.synth_frame(h, w, seed=9, bit_depth=bd)
+    want, got = O.analyze_intra(src, prm), emu.intra(src, prm)
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+    flat = O.default_params(qp, bit_depth=bd)
+    assert not util.same_analysis(O.analyze_intra(src, flat), want)       # the grid changes the prediction at the borders
+
+
 def test_search_centres_are_honoured(emu):
     w, h, bd = 96, 64, 8
     prm = O.default_params(26, me_range=8)
