@@ -47,7 +47,12 @@ template <typename T> __global__ __launch_bounds__(NT, 3) void k_inter_ctu(const
 }
 
 // blockIdx.x = tile * rows_per_tile + row inside the tile: every tile row holds at most one CTU of a diagonal
-template <typename T> __global__ __launch_bounds__(NT) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int rows_per_tile)
+// 3 workgroups per CU: with the tile grid a diagonal launch holds ~1800 CTUs (12 pictures x 25 tiles x <= 7 rows), so the kernel
+// is throughput-bound and needs the occupancy; measured per picture 4.02 ms (1, 298 VGPRs) / 2.33 (2) / 2.02 (3) / 2.21 (4, spills)
+#ifndef INTRA_OCC
+#define INTRA_OCC 3
+#endif
+template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int rows_per_tile)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const IntraArgs<T> &a = args[blockIdx.y];
