@@ -292,6 +292,16 @@ DEV int dot2_i16(uint32_t a, uint32_t b, int acc)
 #endif
 }
 
+// (lo & 0xffff) | (hi << 16): two 16-bit values into one dword (v_perm_b32)
+DEV uint32_t pack_lo16(int lo, int hi)
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+#else
+    return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+#endif
+}
+
 // in-place 8x8 Hadamard SATD of a difference block held in registers: (sum |H d H| + 2) >> 2
 DEV int hadamard8_satd(int (&m)[8][8])
 {

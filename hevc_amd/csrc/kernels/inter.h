@@ -253,10 +253,12 @@ DEV int luma_tile(const uint8_t *win, int i00, int ws, int fx, int fy, int bit_d
                   int pred_stride)
 {
     const uint32_t tlo = load_u32(&g_tab.luma_tap[fx][0]), thi = load_u32(&g_tab.luma_tap[fx][4]);
-    int ty[8];          // vertical taps in registers: the row loop is fully unrolled so every tap index is static
+    // vertical taps as four (even, odd) int16 pairs: the 8-tap column filter is 4 v_dot2_i32_i16 on row PAIRS of the
+    // horizontally filtered samples (|hv| < 2^15 for every fraction) instead of 8 quarter-rate 32-bit multiplies
+    uint32_t typ[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) ty[k] = g_tab.luma_tap[fy][k];
-    int acc[8][8];
+    for (int m = 0; m < 4; m++) typ[m] = pack_lo16(g_tab.luma_tap[fy][2 * m], g_tab.luma_tap[fy][2 * m + 1]);
+    int acc[8][8], prev[8];
 #pragma unroll
     for (int j = 0; j < 8; j++)
 #pragma unroll
@@ -281,15 +283,20 @@ DEV int luma_tile(const uint8_t *win, int i00, int ws, int fx, int fy, int bit_d
         int hv[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) hv[i] = dot4_i8(a[i], tlo, dot4_i8(a[i + 4], thi, 128 * 64));
+        if (r > 0) {
+            // rows (r-1, r) feed output row j with taps (2m, 2m+1) where r - 1 - j = 2m
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            int k = r - j;
-            if (k >= 0 && k < 8) {
-                int t = ty[k];
+            for (int i = 0; i < 8; i++) {
+                const uint32_t pr = pack_lo16(prev[i], hv[i]);
 #pragma unroll
-                for (int i = 0; i < 8; i++) acc[j][i] += t * hv[i];
+                for (int m = 0; m < 4; m++) {
+                    const int j = r - 1 - 2 * m;
+                    if (j >= 0 && j < 8) acc[j][i] = dot2_i16(pr, typ[m], acc[j][i]);
+                }
             }
         }
+#pragma unroll
+        for (int i = 0; i < 8; i++) prev[i] = hv[i];
     }
     (void)bit_depth;
 #pragma unroll
