@@ -179,7 +179,8 @@ struct mihevc_session {
     mihevc_stats stats{};
     // rate control (VBV-capped constant quality, one controller per GOP lane): see DESIGN.md §Rate control
     bool rc_on = false;
-    double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate)
+    double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
+    double rho_pi = 1.0 / 12.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
     std::atomic<long long> entropy_ns{0};
@@ -293,11 +294,6 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
             fr.bits = (long long)pk.data.size() * 8;
             fr.est_q4 = *(const unsigned long long *)(b + sl.est);
             fr.est_known = true;
-            if (fr.est_q4 > 0) {
-                double r = (double)fr.bits / ((double)fr.est_q4 / 16.0);
-                double &ratio = slice_type == 2 ? s->ratio_i : s->ratio_p;
-                ratio = 0.75 * ratio + 0.25 * r;
-            }
         }
         s->packets[index] = std::move(pk);
         s->frames_done++;
@@ -387,33 +383,52 @@ template <typename T> int encode_chunk(mihevc_session *s)
         budget[g] = s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
     }
     const double w_i = 8.0;                   // an IDR picture is budgeted like 8 P pictures
+    const int p_slots = kRing - kVariants;    // a P step's CABAC job is complete once its slot has been handed out again
+    // P-picture QP of lane g at step t.  Every input is deterministic: CABAC sizes only of pictures whose ring slot has been
+    // reused (steps <= t - p_slots), device estimates of steps <= t - 2 (the step loop waits for that copy), a model for the
+    // picture in flight.  The controller solves for the constant QP that spends the rest of the GOP budget and walks towards
+    // it (+3 / -1 per picture, dead band 0.75): a constant QP is what the budget buys the most PSNR with.
     auto decide_p = [&](int g, int t) -> int {
-        // bits spent so far in this GOP: CABAC sizes where known, else the device estimate, else a model from the last known picture
         std::lock_guard<std::mutex> l(s->m);
-        double spent = 0, ref_bits = -1;
-        int ref_qp = s->qp_p;
-        for (int j = 0; j < t; j++) {
-            auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
-            double b;
-            if (fr.bits >= 0) b = (double)fr.bits;
-            else if (fr.est_known) b = (double)fr.est_q4 / 16.0 * (fr.type == 2 ? s->ratio_i : s->ratio_p);
-            else if (ref_bits >= 0) b = ref_bits * std::pow(2.0, (ref_qp - fr.qp) / 6.0);
-            else b = budget[g] / gop_len[g];
-            spent += b;
-            if (fr.bits >= 0 || fr.est_known) {
-                if (fr.type == 2) { if (ref_bits < 0) { ref_bits = b / w_i; ref_qp = fr.qp + 3; } }
-                else { ref_bits = b; ref_qp = fr.qp; }
-            }
+        auto frame = [&](int j) -> mihevc_session::FrameRec & { return s->frames[(size_t)(first_index + g * s->keyint + j)]; };
+        // CABAC / estimate ratio of this GOP's finished P pictures, seeded with two pictures' worth of the session ratio
+        double sum_b = 0, sum_e = 0, seed = 0;
+        for (int j = 1; j <= t - p_slots; j++)
+            if (frame(j).bits >= 0 && frame(j).est_q4 > 0) { sum_b += (double)frame(j).bits; sum_e += (double)frame(j).est_q4 / 16.0; }
+        for (int j = t - 2; j >= 1 && seed == 0; j--) if (frame(j).est_known) seed = 2.0 * (double)frame(j).est_q4 / 16.0;
+        const double rp = (sum_e + seed) > 0 ? (sum_b + s->ratio_p * seed) / (sum_e + seed) : s->ratio_p;
+        // reference point (q_ref, b_ref) of the rate model b(q) = b_ref * 2^((q_ref - q) / 6): the last two P estimates, or the
+        // IDR picture scaled by the learned P/I ratio before any P estimate exists
+        const auto &idr = frame(0);
+        const double idr_bits = (double)idr.est_q4 / 16.0 * s->ratio_i;
+        double b_ref = idr_bits * s->rho_pi, lg = 0;
+        int q_ref = idr.qp, have = 0;
+        for (int j = t - 2; j >= 1 && have < 2; j--) {
+            if (!frame(j).est_known) continue;
+            const double b = std::max(1.0, (double)frame(j).est_q4 / 16.0 * rp);
+            if (!have) q_ref = frame(j).qp;
+            lg += std::log2(b) + (frame(j).qp - q_ref) / 6.0;
+            have++;
+        }
+        if (have) b_ref = std::exp2(lg / have);
+        double spent = idr_bits;
+        for (int j = 1; j < t; j++) {
+            const auto &fr = frame(j);
+            if (j <= t - p_slots && fr.bits >= 0) spent += (double)fr.bits;
+            else if (j <= t - 2 && fr.est_known) spent += (double)fr.est_q4 / 16.0 * rp;
+            else spent += b_ref * std::exp2((q_ref - fr.qp) / 6.0);
         }
         const int left = gop_len[g] - t;
         double target = (budget[g] - spent) / std::max(1, left);
         target = std::max(target, 0.25 * budget[g] / gop_len[g]);
-        int qp = s->qp_p;
-        if (ref_bits > 0) qp = (int)std::lround(ref_qp + 6.0 * std::log2(ref_bits / target));
-        qp = std::max(qp, s->qp_p);                                  // the CRF is the quality ceiling, the VBV only raises QP
-        if (t == 1) qp = std::max(qp, qp_prev[g] + 2);                 // first P: never finer than its IDR + 2
-        else qp = std::min(std::max(qp, qp_prev[g] - 2), qp_prev[g] + 4);
-        return std::min(qp, 51);
+        const double q_ss = q_ref + 6.0 * std::log2(b_ref / target);
+        int qp;
+        if (t == 1) qp = std::max((int)std::lround(q_ss), idr.qp);    // first P: straight to the model, never finer than its IDR
+        else {
+            const double d = q_ss - qp_prev[g];
+            qp = qp_prev[g] + (d >= 0.75 ? std::min(3, (int)std::lround(d)) : d <= -0.75 ? -1 : 0);
+        }
+        return std::min(std::max(qp, s->qp_p), 51);                   // the CRF is the quality ceiling, the VBV only raises QP
     };
     auto patch_qp = [&](int t, int g, int qp) {
         StepView<T> hv(ha, lay, t);
@@ -444,15 +459,19 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         StepView<T> dv(da, lay, t), hv(ha, lay, t);
         std::vector<int> qp_step(B), lane_slot(B, slot0);
-        if (s->rc_on)       // estimates of earlier steps whose D2H copy has landed (no wait): they lead CABAC by several steps
-            for (int j = std::max(1, t - (kRing - kVariants) + 1); j < t; j++) {
-                if (hipEventQuery(s->ev_copy[slot_of(j)]) != hipSuccess) continue;
+        if (s->rc_on && t >= 3) {
+            // rate feedback with a fixed lag of two steps: wait for the symbol copy of step t-2 (step t-1 is already queued behind
+            // it, so the device never idles) and take its estimates.  A fixed lag makes the QP sequence reproducible.
+            const int j = t - 2;
+            HIPCK(s, hipEventSynchronize(s->ev_copy[slot_of(j)]));
+            {
                 std::lock_guard<std::mutex> l(s->m);
                 for (int g = 0; g < batch[j]; g++) {
                     auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
                     if (!fr.est_known) { fr.est_q4 = *(const unsigned long long *)(s->lane[g].sym_host[slot_of(j)] + sl.est); fr.est_known = true; }
                 }
             }
+        }
         for (int g = 0; g < B; g++) {
             qp_step[g] = t == 0 ? s->qp_i : (s->rc_on ? decide_p(g, t) : s->qp_p);
             patch_qp(t, g, qp_step[g]);
@@ -487,8 +506,22 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     unsigned long long e[kVariants] = {0};
                     int pick = nv - 1;
                     for (int v = 0; v < nv; v++) HIPCK(s, hipMemcpy(&e[v], s->lane[g].sym_dev[v] + sl.est, sizeof e[v], hipMemcpyDeviceToHost));
-                    for (int v = 0; v < nv; v++)
-                        if ((double)e[v] / 16.0 * s->ratio_i <= 1.1 * alloc) { pick = v; break; }
+                    // pick the variant whose predicted steady P QP sits closest to IDR QP + 3 (the usual I/P offset): P size at the
+                    // IDR's QP is modelled as rho_pi x IDR size, the rest of the budget is shared by the GOP's P pictures
+                    (void)alloc;
+                    double best_d = 1e30;
+                    for (int v = 0; v < nv; v++) {
+                        const double ib = std::max(1.0, (double)e[v] / 16.0 * s->ratio_i), rest = budget[g] - ib;
+                        const int qi = std::min(51, qp_step[g] + kVariantStep * v);
+                        double d;
+                        if (gop_len[g] < 2) d = ib <= budget[g] ? -1e9 + v : 1e9 + ib;     // IDR-only GOP: finest that fits
+                        else if (rest <= 0) d = 1e9 + ib;
+                        else {
+                            const double q_ss = std::max((double)s->qp_p, qi + 6.0 * std::log2(ib * s->rho_pi / (rest / (gop_len[g] - 1))));
+                            d = std::fabs(q_ss - (qi + 3));
+                        }
+                        if (d < best_d) { best_d = d; pick = v; }
+                    }
                     lane_slot[g] = pick;
                     qp_step[g] = std::min(51, qp_step[g] + kVariantStep * pick);
                     patch_qp(t, g, qp_step[g]);
@@ -584,6 +617,28 @@ template <typename T> int encode_chunk(mihevc_session *s)
     {   // all CABAC jobs of the chunk
         std::unique_lock<std::mutex> l(s->m);
         s->cv.wait(l, [&] { int n = 0; for (int k = 0; k < kRing; k++) n += s->jobs_open[k]; return n == 0; });
+    }
+    if (s->rc_on) {
+        // learn from the finished chunk (all CABAC sizes are known now, so this is deterministic): CABAC bits per estimated
+        // bit for I and P pictures, and the P/I size ratio at equal QP
+        std::lock_guard<std::mutex> l(s->m);
+        double bi = 0, ei = 0, bp = 0, ep = 0, lg = 0;
+        int np = 0;
+        for (int g = 0; g < gops; g++) {
+            const auto &idr = s->frames[(size_t)(first_index + g * s->keyint)];
+            if (idr.bits < 0 || !idr.est_q4) continue;
+            bi += (double)idr.bits; ei += (double)idr.est_q4 / 16.0;
+            for (int j = 1; j < gop_len[g]; j++) {
+                const auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
+                if (fr.bits <= 0 || !fr.est_q4) continue;
+                bp += (double)fr.bits; ep += (double)fr.est_q4 / 16.0;
+                lg += std::log2((double)fr.bits / (double)idr.bits) + (fr.qp - idr.qp) / 6.0;
+                np++;
+            }
+        }
+        if (ei > 0) s->ratio_i = 0.5 * s->ratio_i + 0.5 * bi / ei;
+        if (ep > 0) s->ratio_p = 0.5 * s->ratio_p + 0.5 * bp / ep;
+        if (np) s->rho_pi = std::min(1.0, std::max(1.0 / 256, 0.5 * s->rho_pi + 0.5 * std::exp2(lg / np)));
     }
     for (auto &src : s->pending) s->free_src.push_back(src);
     s->pending.clear();

@@ -1,0 +1,21 @@
+#!/bin/bash
+# PMC passes for the per-CTU kernels on a short 1080p encode (tests/prof_clip.py): bash tools/pmc_kernels.sh <tag>
+# Each --pmc group is its own rocprofv3 run (never combined with traces); summary -> gpurun_out/<tag>/pmc_summary.txt
+set -e
+tag=${1:-pmc}
+root=$(pwd)
+out=$root/gpurun_out/$tag
+mkdir -p $out
+export TMPDIR=/tmp
+cd /tmp
+i=0
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" \
+           "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_WAIT_INST_ANY"; do
+  i=$((i+1))
+  rocprofv3 --pmc $grp -d $out/p$i -o p --output-format csv -- python3 $root/tests/prof_clip.py 24 12 > $out/run$i.log 2>&1 || { tail -5 $out/run$i.log; exit 1; }
+done
+cd $root
+python3 tools/prof_summary.py pmc $out/p1 $out/p2 $out/p3 > $out/pmc_summary.txt
+rm -rf $out/p1 $out/p2 $out/p3
+cat $out/pmc_summary.txt
