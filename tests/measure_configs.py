@@ -46,5 +46,8 @@ def run(w, h, n, hdr, repeats=2):
     return best
 
 
-out = {"1080p8_host_buffers": run(1920, 1080, 300, False), "2160p10_hdr10_host_buffers": run(3840, 2160, 120, True)}
+out = {"720p8_host_buffers": run(1280, 720, 300, False), "1080p8_host_buffers": run(1920, 1080, 300, False),
+       "2160p10_hdr10_host_buffers": run(3840, 2160, 120, True)}
+if len(sys.argv) > 1 and sys.argv[1] == "8k":
+    out["4320p10_hdr10_host_buffers_one_gpu"] = run(7680, 4320, 60, True, repeats=1)
 print(json.dumps(out))
