@@ -31,6 +31,11 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     clip = SyntheticClip("motion", 0, width, height, budget_frames)
     ch = (height + 7) & ~7
     prm_i, prm_p = O.default_params(max(0, qp - 3), me_range=me_range), O.default_params(qp, me_range=me_range)
+    from hevc_amd import _lib
+    cfg = _lib.default_config()
+    cfg.width, cfg.height = width, height
+    prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and NxN trial the device path runs
+    prm_i.intra_nxn = cfg.intra_nxn
     t0 = time.perf_counter()
     ref = None
     for i, (y, u, v) in enumerate(clip.frames()):

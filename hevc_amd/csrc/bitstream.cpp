@@ -676,11 +676,11 @@ private:
         int a = 1, b = 1;
         if (avail(x, y, x - 1, y)) {
             const mihevc_cu_rec &r = cu(x - 1, y);
-            if (!(r.flags & F_INTER)) a = r.intra_mode[(r.flags & F_NXN) ? (((y >> 2) & 1) * 2 + 1) : 0];
+            if (!(r.flags & F_INTER)) a = r.intra_mode[(r.flags & F_NXN) ? ((y >> 2) & 1) * 2 + (((x - 1) >> 2) & 1) : 0];   // the PU holding (x-1, y)
         }
         if (avail(x, y, x, y - 1) && ((y - 1) >> kCtuLog2) == (y >> kCtuLog2)) {
             const mihevc_cu_rec &r = cu(x, y - 1);
-            if (!(r.flags & F_INTER)) b = r.intra_mode[(r.flags & F_NXN) ? (2 + ((x >> 2) & 1)) : 0];
+            if (!(r.flags & F_INTER)) b = r.intra_mode[(r.flags & F_NXN) ? (((y - 1) >> 2) & 1) * 2 + ((x >> 2) & 1) : 0];   // the PU holding (x, y-1)
         }
         if (a == b) {
             if (a < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }

@@ -50,6 +50,7 @@ template <typename T> struct Plane {
 struct CostParams {
     int qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
     int tile_cols, tile_rows;     // intra pictures: uniform tile grid (6.5.1), 1x1 = no tiles
+    int intra_nxn;                // 1: 8x8 intra CUs are also tried as four 4x4 PUs (NxN, DST-VII luma TUs)
 };
 // uniform tile spacing (6.5.1): first CTB of tile i of n over n_ctb CTBs, and the tile holding a CTB
 HDI int tile_bd(int i, int n, int n_ctb) { return i * n_ctb / n; }
@@ -335,6 +336,15 @@ struct GpuExec {
         f((int)threadIdx.x);
         __syncthreads();
     }
+    // A step whose producers and consumers all sit in ONE wave (lanes tid < 64): no workgroup barrier, only wave-scope
+    // ordering — LDS operations of a wave execute in issue order, the fence keeps the compiler from moving them across.
+    // The caller closes the sequence of wave steps with a full phase() before other waves look at the results.
+    template <class F> DEV void wave_step(F &&f)
+    {
+        f((int)threadIdx.x);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
     DEV void atomic_add(int *p, int v) { atomicAdd(p, v); }
     DEV void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
     DEV void atomic_or(unsigned *p, unsigned v) { atomicOr(p, v); }
@@ -344,6 +354,10 @@ struct GpuExec {
 #endif
 struct SeqExec {      // sequential stepping of a phase program (tests/emu)
     template <class F> void phase(F &&f)
+    {
+        for (int t = 0; t < NT; t++) f(t);
+    }
+    template <class F> void wave_step(F &&f)
     {
         for (int t = 0; t < NT; t++) f(t);
     }

@@ -30,6 +30,13 @@ template <typename T> struct IntraArgs {
 constexpr int RY_STRIDE = 68;    // LDS luma neighbourhood: rows -1..31, cols -1..63 (+ pad)
 constexpr int RC_STRIDE = 36;    // chroma: rows -1..15, cols -1..31
 
+template <typename T> struct Nx4 {       // per block group g: 0 = luma PU or Cb, 1 = Cr
+    T ref_raw[2][17], ref[2][17];
+    unsigned av[2], nz[2];
+    int16_t pred[2][16], res[2][16], lvl[2][16];
+    int tmp[2][16];
+};
+
 template <typename T> struct IntraShared {
     ResidualShared rs;
     T src[1536];
@@ -52,6 +59,18 @@ template <typename T> struct IntraShared {
     int bits[3];
     unsigned long long j_cu;
     unsigned est;
+    // NxN trial of an 8x8 CU: the 2Nx2N result parked here while four 4x4 PUs are coded in place
+    T nx_rec[96];                // Y 8x8, Cb 4x4, Cr 4x4
+    int16_t nx_coef[96];
+    mihevc_cu_rec nx_cu;
+    unsigned long long nx_j2n;
+    unsigned nx_sse;
+    int nx_bits, nx_keep;
+    unsigned nx_cbf_c;           // CU_CBF_CB / CU_CBF_CR of the NxN trial
+    int16_t nx_mat[2][16];       // 4x4 DST-VII and DCT matrices [k * 4 + n]
+    int16_t tab_angle[35], tab_inv[35];   // Tables 8-4 / 8-5 by mode, LDS copies: a global read per use sat on the serial chain
+    int16_t tab_qs[6], tab_ls[6];
+    Nx4<T> nx;
 };
 
 // p[x][y] accessors on the linear 4N+1 layout: L[0] = p[-1][2N-1] ... L[2N] = p[-1][-1] ... L[4N] = p[2N-1][-1]
@@ -98,7 +117,7 @@ DEV int mode_inv_angle(int mode) { return (mode >= 11 && mode <= 25) ? g_tab.inv
 // intra_sample, with everything that depends only on the mode / row hoisted out of the sample loop (the SATD mode
 // search runs 35 x (N/8)^2 of these per CU and dominated k_intra_diag: profiles/r01_a_first)
 template <typename T>
-DEV void intra_tile_diff(const T *L, int log2n, int mode, int tx, int ty, int bit_depth, int dc, const T *src, int src_stride, int (&m)[8][8])
+DEV void intra_tile_diff(const T *L, int log2n, int mode, int angle, int inv, int tx, int ty, int bit_depth, int dc, const T *src, int src_stride, int (&m)[8][8])
 {
     const int n = 1 << log2n;
     if (mode == 0) {
@@ -134,7 +153,7 @@ DEV void intra_tile_diff(const T *L, int log2n, int mode, int tx, int ty, int bi
             }
         return;
     }
-    const int angle = g_tab.intra_angle[mode], vertical = mode >= 18, inv = angle < 0 ? g_tab.inv_angle[mode - 11] : 0;
+    const int vertical = mode >= 18;
     const int a0 = vertical ? ty : tx, b0 = vertical ? tx : ty;
     const int maxv = (1 << bit_depth) - 1;
 #pragma unroll
@@ -159,6 +178,29 @@ DEV void intra_tile_diff(const T *L, int log2n, int mode, int tx, int ty, int bi
             if (vertical) m[ai][bi] = (int)src[ai * src_stride + bi] - v;
             else m[bi][ai] = (int)src[bi * src_stride + ai] - v;
         }
+    }
+}
+
+// 8.4.2 candModeList of the PU whose top-left luma sample is (px, py) in CTU coordinates (a CU, or a 4x4 PU of an NxN
+// CU).  A neighbouring NxN CU answers with the mode of the 4x4 PU that holds the neighbouring sample; the left CTU's
+// right column comes from s.left_cu; the CTU above is never consulted (8.4.2: DC).
+template <typename T> DEV void mpm_cand(const IntraShared<T> &s, int px, int py, bool left_ok, int (&cand)[3])
+{
+    int ma = 1, mb = 1;
+    if (px > 0 || left_ok) {
+        const mihevc_cu_rec &r = px > 0 ? s.cu_acc[(py >> 3) * 4 + ((px - 1) >> 3)] : s.left_cu[py >> 3];
+        if (!(r.flags & CU_INTER)) ma = r.intra_mode[(r.flags & CU_NXN) ? ((py >> 2) & 1) * 2 + (((px - 1) >> 2) & 1) : 0];
+    }
+    if (py > 0) {
+        const mihevc_cu_rec &r = s.cu_acc[((py - 1) >> 3) * 4 + (px >> 3)];
+        if (!(r.flags & CU_INTER)) mb = r.intra_mode[(r.flags & CU_NXN) ? (((py - 1) >> 2) & 1) * 2 + ((px >> 2) & 1) : 0];
+    }
+    if (ma == mb) {
+        if (ma < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+        else { cand[0] = ma; cand[1] = 2 + ((ma + 29) & 31); cand[2] = 2 + ((ma - 2 + 1) & 31); }
+    } else {
+        cand[0] = ma; cand[1] = mb;
+        cand[2] = (ma != 0 && mb != 0) ? 0 : (ma != 1 && mb != 1) ? 1 : 26;
     }
 }
 
@@ -197,22 +239,9 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             s.ref_raw[pl][i] = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
         }
         if (tid == 0) {   // 8.4.2 candModeList
-            int ma = 1, mb = 1;
-            if (gx > tx_lo) {
-                const mihevc_cu_rec &r = cx > 0 ? s.cu_acc[(cy >> 3) * 4 + ((cx - 1) >> 3)] : s.left_cu[cy >> 3];
-                if (!(r.flags & CU_INTER)) ma = r.intra_mode[0];
-            }
-            if (cy > 0) {
-                const mihevc_cu_rec &r = s.cu_acc[((cy - 1) >> 3) * 4 + (cx >> 3)];
-                if (!(r.flags & CU_INTER)) mb = r.intra_mode[0];
-            }
-            if (ma == mb) {
-                if (ma < 2) { s.cand[0] = 0; s.cand[1] = 1; s.cand[2] = 26; }
-                else { s.cand[0] = ma; s.cand[1] = 2 + ((ma + 29) & 31); s.cand[2] = 2 + ((ma - 2 + 1) & 31); }
-            } else {
-                s.cand[0] = ma; s.cand[1] = mb;
-                s.cand[2] = (ma != 0 && mb != 0) ? 0 : (ma != 1 && mb != 1) ? 1 : 26;
-            }
+            int cand[3];
+            mpm_cand(s, cx, cy, x0 > tx_lo, cand);
+            s.cand[0] = cand[0]; s.cand[1] = cand[1]; s.cand[2] = cand[2];
             s.sse = 0; s.bits[0] = s.bits[1] = s.bits[2] = 0;
             s.mode_key = ~0ull;
         }
@@ -259,7 +288,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             for (int u = tid; u < 35 * 8; u += NT) {
                 const int mode = u >> 3, y = u & 7;
                 const T *L = intra_filter_on(3, mode) ? s.filt : s.ref[0];
-                const int ang = mode_angle(mode), inv = mode_inv_angle(mode);
+                const int ang = s.tab_angle[mode], inv = s.tab_inv[mode];
                 int d[8];
 #pragma unroll
                 for (int x = 0; x < 8; x++) d[x] = (int)s.src[(cy + y) * 32 + cx + x] - intra_sample<T>(L, 3, mode, ang, inv, x, y, 0, bd, s.dc_val[0]);
@@ -296,7 +325,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             int mode = u / ntile, t = u % ntile, tx = (t % tiles) * 8, ty = (t / tiles) * 8;
             const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
             int m[8][8];
-            intra_tile_diff<T>(L, log2n, mode, tx, ty, bd, s.dc_val[0], s.src + (cy + ty) * 32 + cx + tx, 32, m);
+            intra_tile_diff<T>(L, log2n, mode, s.tab_angle[mode], s.tab_inv[mode], tx, ty, bd, s.dc_val[0], s.src + (cy + ty) * 32 + cx + tx, 32, m);
             s.satd[mode][t] = hadamard8_satd(m);
         }
     });
@@ -322,7 +351,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
     ex.phase([&](int tid) {
         const int mode = (int)(s.mode_key & 63);
         const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
-        const int ang = mode_angle(mode), inv = mode_inv_angle(mode);
+        const int ang = s.tab_angle[mode], inv = s.tab_inv[mode];
         for (int k = tid; k < rcnt; k += NT) {
             const int i = rg.index(k);
             SampleLoc l = locate(s.rs, i);
@@ -382,6 +411,218 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
     });
 }
 
+// ------------------------------------------------------------------------------------------ NxN (four 4x4 PUs)
+// part_mode NxN trial of the 8x8 CU at (cx, cy), run right after its 2Nx2N evaluation (whose result sits in the
+// accumulated state): park the 2Nx2N result, code four 4x4 PUs in z-order in place, then the two 4x4 chroma TUs with
+// PU 0's mode (DM), and keep NxN only if its cost is lower.  The 4x4 blocks depend on each other, so the whole trial runs
+// on wave 0 as wave-local steps (ex.wave_step: no workgroup barriers): 17 lanes build the reference samples, 35 lanes rank
+// the modes by 4x4-Hadamard SATD, 16 lanes (one per sample) predict, transform (DST-VII luma / DCT chroma), quantise and
+// reconstruct.  Arithmetic as residual_pipeline / oracle code_tu.
+template <typename T, class Ex>
+DEV void intra_cu_nxn(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int y0, int cx, int cy)
+{
+    const int ctu_x = x0 >> CTU_LOG2, ctu_y = y0 >> CTU_LOG2, bd = a.prm.bit_depth, maxv = (1 << bd) - 1;
+    const int tcn = a.prm.tile_cols > 1 ? a.prm.tile_cols : 1, trn = a.prm.tile_rows > 1 ? a.prm.tile_rows : 1;
+    const int tci = tile_of(ctu_x, tcn, a.ctus_w), tri = tile_of(ctu_y, trn, a.ctus_h);
+    const int tx_lo = tile_bd(tci, tcn, a.ctus_w) << CTU_LOG2, tx_hi = tile_bd(tci + 1, tcn, a.ctus_w) << CTU_LOG2;
+    const int ty_lo = tile_bd(tri, trn, a.ctus_h) << CTU_LOG2;
+    const int tile = (cy >> 3) * 4 + (cx >> 3);
+    Nx4<T> &w = s.nx;
+    // the trial of CU column c runs on wave c: wave 0 of every workgroup tends to share one SIMD, and a serial chain pinned to
+    // it left the other three SIMDs of the CU idle
+    const int wbase = ((cx >> 3) & 3) * 64;
+    ex.phase([&](int tid) {
+        if (tid < 96) {
+            int pl, x, y;
+            if (tid < 64) { pl = 0; x = cx + (tid & 7); y = cy + (tid >> 3); } else { int k = tid - 64; pl = 1 + (k >> 4); k &= 15; x = (cx >> 1) + (k & 3); y = (cy >> 1) + (k >> 2); }
+            s.nx_rec[tid] = pl ? s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : s.rec_y[(y + 1) * RY_STRIDE + x + 1];
+            s.nx_coef[tid] = s.coef_acc[(pl ? 1024 + (pl - 1) * 256 + y * 16 : y * 32) + x];
+        }
+        if (tid == 0) {
+            s.nx_cu = s.cu_acc[tile];
+            s.nx_j2n = s.j_cu;
+            mihevc_cu_rec r = s.cu_acc[tile];
+            r.flags = CU_NXN; r.cbf_y4 = 0;
+            r.intra_mode[0] = r.intra_mode[1] = r.intra_mode[2] = r.intra_mode[3] = 1;
+            s.cu_acc[tile] = r;
+            s.nx_sse = 0; s.nx_bits = 16 + 24; s.nx_cbf_c = 0;
+            s.mode_key = ~0ull;
+            w.av[0] = w.av[1] = 0; w.nz[0] = w.nz[1] = 0;
+        }
+    });
+    // one pass codes `nb` 4x4 blocks of the same kind side by side (lane group g = lane / 32): a luma PU (nb = 1) or Cb + Cr (nb = 2)
+    auto code_blocks = [&](int nb, int pl0, int bx, int by, int k) {
+        const bool luma = pl0 == 0;
+        const int sh = luma ? 0 : 1, qp = luma ? a.prm.qp : a.prm.qp_c, q = qp + 6 * (bd - 8);
+        const int qbits = 14 + q / 6 + (15 - bd - 2), qs = s.tab_qs[q % 6], ls = s.tab_ls[q % 6], bsh = bd + 2 - 5;
+        const int16_t *M = s.nx_mat[luma ? 0 : 1];
+        const int zc = zaddr(x0 + (bx << sh), y0 + (by << sh), a.ctus_w);
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // reference samples: availability (6.4.1 incl. tiles) + raw values
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 17) return;
+            const int pl = pl0 + g;
+            int xn, yn;
+            if (i < 8) { xn = bx - 1; yn = by + 7 - i; } else if (i == 8) { xn = bx - 1; yn = by - 1; } else { xn = bx + i - 9; yn = by - 1; }
+            const int lx = x0 + xn * (1 << sh), ly = y0 + yn * (1 << sh);
+            const bool ok = lx >= tx_lo && ly >= ty_lo && lx < a.w && lx < tx_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zc;
+            w.ref_raw[g][i] = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
+            if (ok) ex.atomic_or(&w.av[g], 1u << i);
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // substitution 8.4.4.2.2: nearest available below, else the first available
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 17) return;
+            const unsigned av = w.av[g], below = av & ((2u << i) - 1);
+            w.ref[g][i] = !av ? (T)(1 << (bd - 1)) : below ? w.ref_raw[g][31 - __builtin_clz(below)] : w.ref_raw[g][__builtin_ctz(av)];
+        });
+        if (luma) ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;   // 35 modes ranked by SATD + MPM-aware mode bits
+            if (tid >= 35) return;
+            const T *ref = w.ref[0];
+            int cand[3], m[16], sum = 4;
+            mpm_cand(s, bx, by, x0 > tx_lo, cand);
+#pragma unroll
+            for (int i = 0; i < 4; i++) sum += ref_top(ref, 4, i) + ref_left(ref, 4, i);
+            const int ang = s.tab_angle[tid], inv = s.tab_inv[tid], dc = sum >> 3;
+#pragma unroll
+            for (int i = 0; i < 16; i++) m[i] = (int)s.src[(by + (i >> 2)) * 32 + bx + (i & 3)] - intra_sample<T>(ref, 2, tid, ang, inv, i & 3, i >> 2, 0, bd, dc);
+#pragma unroll
+            for (int y = 0; y < 4; y++) {
+                int p0 = m[y * 4] + m[y * 4 + 1], p1 = m[y * 4] - m[y * 4 + 1], p2 = m[y * 4 + 2] + m[y * 4 + 3], p3 = m[y * 4 + 2] - m[y * 4 + 3];
+                m[y * 4] = p0 + p2; m[y * 4 + 1] = p1 + p3; m[y * 4 + 2] = p0 - p2; m[y * 4 + 3] = p1 - p3;
+            }
+            int sat = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                int p0 = m[x] + m[4 + x], p1 = m[x] - m[4 + x], p2 = m[8 + x] + m[12 + x], p3 = m[8 + x] - m[12 + x];
+                sat += iabs(p0 + p2) + iabs(p1 + p3) + iabs(p0 - p2) + iabs(p1 - p3);
+            }
+            const int bits = tid == cand[0] ? 2 : (tid == cand[1] || tid == cand[2]) ? 3 : 6;
+            const unsigned cost = ((unsigned)((sat + 1) >> 1) << 4) + (unsigned)(a.prm.lambda_sad_q4 * bits);
+            ex.atomic_min(&s.mode_key, ((unsigned long long)cost << 6) | (unsigned)tid);
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // prediction + residual, one lane per sample
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 16) return;
+            const int pl = pl0 + g, mode = luma ? (int)(s.mode_key & 63) : (int)s.cu_acc[tile].intra_mode[0];
+            const T *ref = w.ref[g];
+            int sum = 4;
+#pragma unroll
+            for (int j = 0; j < 4; j++) sum += ref_top(ref, 4, j) + ref_left(ref, 4, j);
+            const int x = i & 3, y = i >> 2;
+            const int v = intra_sample<T>(ref, 2, mode, s.tab_angle[mode], s.tab_inv[mode], x, y, pl, bd, sum >> 3);
+            const int sidx = luma ? (by + y) * 32 + bx + x : 1024 + (pl - 1) * 256 + (by + y) * 16 + bx + x;
+            w.pred[g][i] = (int16_t)v;
+            w.res[g][i] = (int16_t)((int)s.src[sidx] - v);
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // forward stage 1 (rows)
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 16) return;
+            const int u = i & 3, y = i >> 2, s1 = bd - 7;
+            int acc = 0;
+#pragma unroll
+            for (int x = 0; x < 4; x++) acc += M[u * 4 + x] * w.res[g][y * 4 + x];
+            w.tmp[g][i] = (acc + (1 << (s1 - 1))) >> s1;
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // forward stage 2 (columns) + quantisation (intra dead zone 171/512)
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 16) return;
+            const int u = i & 3, v = i >> 2;
+            int acc = 0;
+#pragma unroll
+            for (int y = 0; y < 4; y++) acc += M[v * 4 + y] * w.tmp[g][y * 4 + u];
+            const int c = clip3(-32768, 32767, (acc + 128) >> 8);
+            long long l = ((long long)iabs(c) * qs + ((long long)171 << (qbits - 9))) >> qbits;
+            if (l > 32767) l = 32767;
+            w.lvl[g][i] = (int16_t)(c < 0 ? -(int)l : (int)l);
+            if (l) ex.atomic_or(&w.nz[g], 1u);
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // scaling + inverse stage 1 (columns, 16-bit clip)
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 16 || !w.nz[g]) return;
+            const int x = i & 3, y = i >> 2;
+            const long long scale = (long long)16 * ls << (q / 6);
+            int acc = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc += M[j * 4 + y] * clip3(-32768, 32767, (int)((w.lvl[g][j * 4 + x] * scale + ((long long)1 << (bsh - 1))) >> bsh));
+            w.tmp[g][i] = clip3(-32768, 32767, (acc + 64) >> 7);
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // inverse stage 2 (rows), reconstruction, distortion, rate, records
+            const int g = tid >> 5, i = tid & 31;
+            if (g >= nb || i >= 16) return;
+            const int pl = pl0 + g, x = i & 3, y = i >> 2, s3 = 20 - bd, nz = (int)w.nz[g];
+            int r = 0;
+            if (nz) {
+                int acc = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) acc += M[j * 4 + x] * w.tmp[g][y * 4 + j];
+                r = (int)(int16_t)((acc + (1 << (s3 - 1))) >> s3);
+            }
+            const int v = clip3(0, maxv, (int)w.pred[g][i] + r);
+            const int sidx = luma ? (by + y) * 32 + bx + x : 1024 + (pl - 1) * 256 + (by + y) * 16 + bx + x;
+            if (luma) s.rec_y[(by + y + 1) * RY_STRIDE + bx + x + 1] = (T)v; else s.rec_c[pl - 1][(by + y + 1) * RC_STRIDE + bx + x + 1] = (T)v;
+            s.coef_acc[sidx] = w.lvl[g][i];
+            const int d = (int)s.src[sidx] - v, al = iabs((int)w.lvl[g][i]);
+            int bits = al ? (al == 1 ? 40 : al == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(al - 1))) : 0;
+            if (i == 0) {
+                if (nz) bits += 24 + 16;
+                if (luma) {
+                    const int mode = (int)(s.mode_key & 63);
+                    int cand[3];
+                    mpm_cand(s, bx, by, x0 > tx_lo, cand);
+                    bits += 16 * (mode == cand[0] ? 2 : (mode == cand[1] || mode == cand[2]) ? 3 : 6);
+                    s.cu_acc[tile].intra_mode[k] = (uint8_t)mode;
+                    if (k == 0) s.cu_acc[tile].chroma_mode = (uint8_t)mode;
+                    if (nz) { s.cu_acc[tile].cbf_y4 |= (uint8_t)(1 << k); s.cu_acc[tile].flags |= CU_CBF_Y; }
+                } else if (nz) {
+                    ex.atomic_or(&s.nx_cbf_c, (unsigned)(pl == 1 ? CU_CBF_CB : CU_CBF_CR));
+                }
+            }
+            if (d) ex.atomic_add(&s.nx_sse, (unsigned)(d * d));
+            if (bits) ex.atomic_add(&s.nx_bits, bits);
+        });
+        ex.wave_step([&](int tid0) {
+            const int tid = tid0 - wbase;
+            if (tid < 0 || tid >= 64) return;          // reset the per-block scratch for the next block
+            if (tid == 0) { s.mode_key = ~0ull; w.av[0] = w.av[1] = 0; w.nz[0] = w.nz[1] = 0; }
+        });
+    };
+    for (int k = 0; k < 4; k++) code_blocks(1, 0, cx + (k & 1) * 4, cy + (k >> 1) * 4, k);
+    code_blocks(2, 1, cx >> 1, cy >> 1, 0);
+    ex.phase([&](int) {});      // the wave steps carry no barrier: the other waves wait here for the trial to finish
+    ex.phase([&](int tid) {
+        if (tid != 0) return;
+        s.cu_acc[tile].flags |= (uint8_t)s.nx_cbf_c;
+        const unsigned long long j = ((unsigned long long)s.nx_sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)s.nx_bits) >> 4);
+        s.nx_keep = j < s.nx_j2n;
+        if (s.nx_keep) s.j_cu = j;
+    });
+    ex.phase([&](int tid) {
+        if (s.nx_keep) return;
+        if (tid < 96) {
+            int pl, x, y;
+            if (tid < 64) { pl = 0; x = cx + (tid & 7); y = cy + (tid >> 3); } else { int k = tid - 64; pl = 1 + (k >> 4); k &= 15; x = (cx >> 1) + (k & 3); y = (cy >> 1) + (k >> 2); }
+            if (pl) s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] = s.nx_rec[tid]; else s.rec_y[(y + 1) * RY_STRIDE + x + 1] = s.nx_rec[tid];
+            s.coef_acc[(pl ? 1024 + (pl - 1) * 256 + y * 16 : y * 32) + x] = s.nx_coef[tid];
+        }
+        if (tid == 0) s.cu_acc[tile] = s.nx_cu;
+    });
+}
+
 // copy the region (cx,cy,n) of the accumulated state to the save area (dir = 0) or back (dir = 1)
 template <typename T, class Ex> DEV void intra_save_restore(Ex &ex, IntraShared<T> &s, int cx, int cy, int n, int dir)
 {
@@ -420,6 +661,9 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             s.coef_acc[i] = 0;
         }
         if (tid == 0) s.est = 0;
+        if (tid >= 64 && tid < 99) { s.tab_angle[tid - 64] = (int16_t)mode_angle(tid - 64); s.tab_inv[tid - 64] = (int16_t)mode_inv_angle(tid - 64); }
+        if (tid >= 128 && tid < 134) { s.tab_qs[tid - 128] = g_tab.quant_scale[tid - 128]; s.tab_ls[tid - 128] = g_tab.level_scale[tid - 128]; }
+        if (tid < 32) s.nx_mat[tid >> 4][tid & 15] = tid < 16 ? g_tab.dst4[(tid >> 2) & 3][tid & 3] : g_tab.mat[((tid >> 2) & 3) * 8][tid & 3];
         if (tid < 4 && x0 > 0 && y0 + tid * 8 < a.h) s.left_cu[tid] = a.cu[(size_t)((y0 >> 3) + tid) * (a.w >> 3) + ((x0 - 1) >> 3)];
         // neighbourhood: row -1 (cols -1..63 luma / -1..31 chroma) and column -1 (rows 0..31 / 0..15) from the picture
         for (int u = tid; u < 65 + 32 + 2 * (33 + 16); u += NT) {
@@ -446,6 +690,8 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             const int bx = qx + (b & 1) * 8, by = qy + (b >> 1) * 8;
             if (x0 + bx >= a.w || y0 + by >= a.h) continue;
             intra_cu(ex, s, a, x0, y0, bx, by, 3);
+            // NxN trial only when the 2Nx2N CU left a luma residual (uniform over the workgroup: read after intra_cu's last barrier)
+            if (a.prm.intra_nxn && (s.cu_acc[(by >> 3) * 4 + (bx >> 3)].flags & CU_CBF_Y)) intra_cu_nxn(ex, s, a, x0, y0, bx, by);
             jsplit += s.j_cu;
         }
         const bool fits = x0 + qx + 16 <= a.w && y0 + qy + 16 <= a.h;

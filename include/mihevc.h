@@ -63,7 +63,9 @@ typedef struct mihevc_config {
     int32_t profile_stages;           /* 1: bracket every stage launch with HIP events on the compute stream (mihevc_stats.stage_ms) */
     int32_t intra_tiles;              /* 1 (default): IDR pictures use the largest uniform tile grid the level allows (PPS 1), which
                                        * cuts the intra CTU wavefront from W+2H to w+2h CTUs of one tile; 0: one tile */
-    int32_t reserved[6];
+    int32_t intra_nxn;                /* 1: 8x8 intra CUs are also tried as four 4x4 PUs (part_mode NxN, DST-VII 4x4 luma TUs).  Default 0:
+                                       * on the bench clip the trial costs 2 ms per IDR picture (-15 % fps) and wins in 0.4 % of the CUs */
+    int32_t reserved[5];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -115,8 +117,9 @@ const char *mihevc_last_error(const mihevc_session *s);
 typedef struct mihevc_cost_params {
     int32_t qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
     int32_t tile_cols, tile_rows;     /* intra pictures: uniform tile grid (0/1 = one tile); see mihevc_tile_grid */
+    int32_t intra_nxn;                /* 1: try part_mode NxN (four 4x4 PUs, DST-VII) for 8x8 intra CUs */
 } mihevc_cost_params;
-void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1 */
+void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, intra_nxn 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every
  * column >= 256 and every row >= 64 luma samples (A.4.1), uniform spacing; 1x1 when cfg->intra_tiles == 0. */
 int  mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows);

@@ -679,16 +679,18 @@ typedef struct {
 } intra_ctx;
 
 /* 8.4.2: candModeList from the left (x-1,y) and above (x,y-1) CUs; above is DC outside the current CTU row */
+/* (x, y) is the top-left luma sample of the PU (a CU, or one 4x4 PU of an NxN CU); a neighbouring NxN CU answers with the
+ * mode of the 4x4 PU that holds the neighbouring sample */
 static void mpm_list(const intra_ctx *c, int x, int y, int cand[3])
 {
     int a = 1, b = 1;
     if (x > 0 && same_tile(x - 1, y, x, y, c->w, c->h, c->prm->tile_cols, c->prm->tile_rows)) {
         const orc_cu_rec *r = &c->cu[(y >> 3) * c->w8 + ((x - 1) >> 3)];
-        if (!(r->flags & ORC_F_INTER)) a = r->intra_mode[0];
+        if (!(r->flags & ORC_F_INTER)) a = r->intra_mode[(r->flags & ORC_F_NXN) ? ((y >> 2) & 1) * 2 + (((x - 1) >> 2) & 1) : 0];
     }
     if (y > 0 && ((y - 1) >> ORC_CTU_LOG2) == (y >> ORC_CTU_LOG2)) {
         const orc_cu_rec *r = &c->cu[((y - 1) >> 3) * c->w8 + (x >> 3)];
-        if (!(r->flags & ORC_F_INTER)) b = r->intra_mode[0];
+        if (!(r->flags & ORC_F_INTER)) b = r->intra_mode[(r->flags & ORC_F_NXN) ? (((y - 1) >> 2) & 1) * 2 + ((x >> 2) & 1) : 0];
     }
     if (a == b) {
         if (a < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
@@ -753,6 +755,54 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
     return ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);
 }
 
+/* the same 8x8 CU as four 4x4 PUs (part_mode NxN): per PU in z-order a 35-mode SATD search on the reconstructed
+ * neighbourhood (earlier PUs included), DST-VII luma TU; chroma is one 4x4 TU per plane predicted with PU 0's mode (DM).
+ * Overwrites the CU's reconstruction, levels and record; returns the RD cost in the units of intra_cu. */
+static uint64_t intra_cu_nxn(intra_ctx *c, int x, int y)
+{
+    const orc_params *prm = c->prm;
+    int bd = prm->bit_depth;
+    orc_cu_rec *r = &c->cu[(y >> 3) * c->w8 + (x >> 3)];
+    memset(r, 0, sizeof *r);
+    r->log2_size = 3; r->flags = ORC_F_NXN; r->qp = (uint8_t)prm->qp;
+    r->intra_mode[0] = r->intra_mode[1] = r->intra_mode[2] = r->intra_mode[3] = 1;
+    int64_t sse, sse_total = 0;
+    int bits, bits_total = 16 + 24;
+    pix ref[17], filt[17], pred[16];
+    for (int k = 0; k < 4; k++) {
+        int xp = x + (k & 1) * 4, yp = y + (k >> 1) * 4, cand[3];
+        mpm_list(c, xp, yp, cand);
+        orc_intra_build_ref_tiles(c->rec[0], c->rstride[0], xp, yp, 2, c->w, c->h, 0, bd, prm->tile_cols, prm->tile_rows, ref);
+        const pix *s = c->src[0] + yp * c->sstride[0] + xp;
+        uint64_t best = ~0ull;
+        for (int mode = 0; mode < 35; mode++) {
+            orc_intra_filter_ref(ref, filt, 2, mode, 0, bd, 1);         /* 4x4: never filtered */
+            orc_intra_pred(filt, pred, 4, 2, mode, 0, bd);
+            uint32_t cst = ((uint32_t)orc_satd(s, c->sstride[0], pred, 4, 4, 4) << 4) + (uint32_t)(prm->lambda_sad_q4 * intra_mode_bits(cand, mode));
+            uint64_t key = ((uint64_t)cst << 6) | (uint32_t)mode;
+            if (key < best) best = key;
+        }
+        int mode = (int)(best & 63);
+        r->intra_mode[k] = (uint8_t)mode;
+        orc_intra_filter_ref(ref, filt, 2, mode, 0, bd, 1);
+        orc_intra_pred(filt, pred, 4, 2, mode, 0, bd);
+        if (code_tu(s, c->sstride[0], pred, 4, c->rec[0] + yp * c->rstride[0] + xp, c->rstride[0], c->coef[0] + yp * c->w + xp, c->w,
+                    2, prm->qp, bd, 1, 1 /* DST-VII */, &sse, &bits)) { r->cbf_y4 |= (uint8_t)(1 << k); r->flags |= ORC_F_CBF_Y; }
+        sse_total += sse; bits_total += 16 * intra_mode_bits(cand, mode) + bits;
+    }
+    int cmode = r->intra_mode[0];
+    r->chroma_mode = (uint8_t)cmode;
+    for (int ci = 1; ci < 3; ci++) {
+        int xc = x >> 1, yc = y >> 1;
+        orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, 2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
+        orc_intra_pred(ref, pred, 4, 2, cmode, ci, bd);
+        if (code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, 4, c->rec[ci] + yc * c->rstride[ci] + xc, c->rstride[ci],
+                    c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1, 2, prm->qp_c, bd, 1, 0, &sse, &bits)) r->flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
+        sse_total += sse; bits_total += bits;
+    }
+    return ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);
+}
+
 static void region_copy(pix *dst, int ds, const pix *src, int ss, int w, int h)
 {
     for (int y = 0; y < h; y++) memcpy(dst + y * ds, src + y * ss, w * sizeof(pix));
@@ -767,7 +817,30 @@ static uint64_t intra_tree(intra_ctx *c, int x, int y, int log2n)
 {
     if (x >= c->w || y >= c->h) return 0;
     int n = 1 << log2n;
-    if (log2n == ORC_MINCU_LOG2) return intra_cu(c, x, y, log2n);
+    if (log2n == ORC_MINCU_LOG2) {
+        uint64_t j2n = intra_cu(c, x, y, log2n);
+        if (!c->prm->intra_nxn) return j2n;
+        /* a 2Nx2N CU whose luma residual quantised to nothing is predicted well enough: no NxN trial */
+        if (!(c->cu[(y >> 3) * c->w8 + (x >> 3)].flags & ORC_F_CBF_Y)) return j2n;
+        /* try NxN on top of the 2Nx2N result; 2Nx2N wins ties */
+        pix sv[3][64];
+        int16_t sc[3][64];
+        orc_cu_rec scu = c->cu[(y >> 3) * c->w8 + (x >> 3)];
+        for (int ci = 0; ci < 3; ci++) {
+            int sh = ci ? 1 : 0;
+            region_copy(sv[ci], 8 >> sh, c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], 8 >> sh, 8 >> sh);
+            region_copy16(sc[ci], 8 >> sh, c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, 8 >> sh, 8 >> sh);
+        }
+        uint64_t jnxn = intra_cu_nxn(c, x, y);
+        if (jnxn < j2n) return jnxn;
+        for (int ci = 0; ci < 3; ci++) {
+            int sh = ci ? 1 : 0;
+            region_copy(c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], sv[ci], 8 >> sh, 8 >> sh, 8 >> sh);
+            region_copy16(c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, sc[ci], 8 >> sh, 8 >> sh, 8 >> sh);
+        }
+        c->cu[(y >> 3) * c->w8 + (x >> 3)] = scu;
+        return j2n;
+    }
     int fits = x + n <= c->w && y + n <= c->h;
     uint64_t jsplit = ((uint64_t)c->prm->lambda_q4 * 16) >> 4;
     for (int q = 0; q < 4; q++) jsplit += intra_tree(c, x + (q & 1) * (n / 2), y + (q >> 1) * (n / 2), log2n - 1);

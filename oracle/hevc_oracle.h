@@ -68,6 +68,7 @@ typedef struct {
     int me_range;      /* integer search +-range, <= 64 */
     int tile_cols, tile_rows; /* intra pictures: uniform tile grid (6.5.1); 0 or 1 = one tile.  Neighbours in another tile
                                 * are unavailable for prediction (6.4.1), which is what shortens the CTU wavefront */
+    int intra_nxn;            /* 1: every 8x8 intra CU is also tried as four 4x4 PUs (part_mode NxN, DST-VII luma TUs) */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */

@@ -11,7 +11,7 @@ from oracle import oracle as O
 from tests import util
 
 
-def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000):
+def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0):
     lib = _lib.load()
     buf = (C.c_uint8 * (4 << 20))()
     n = lib.mihevc_write_parameter_sets(C.byref(cfg), buf, len(buf))
@@ -20,6 +20,8 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000):
     stream, recs, packets, ref = headers, [], [], None
     prm_i, prm_p = O.default_params(max(0, qp - 3), bd, me_range), O.default_params(qp, bd, me_range)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # IDR pictures are analysed for the grid PPS 1 signals
+    prm_i.intra_nxn = nxn
+    cus = []
     for i, src in enumerate(srcs):
         intra = i % keyint == 0
         prm = prm_i if intra else prm_p
@@ -30,8 +32,10 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000):
                                            util.ptr(a.coef_v), util.ptr(sao) if cfg.sao else None, buf, len(buf))
         assert n > 0, n
         packets.append((bytes(buf[:n]), i, intra))
+        cus.append(a.cu)
         stream += packets[-1][0]
         recs.append(ref)
+    encode_pictures.last_cus = cus
     return headers, stream, recs, packets
 
 
@@ -91,6 +95,24 @@ def test_tile_entry_points_are_checked():
     bad[headers_len + 4 + 2 + 2] ^= 0x04         # start code (4) + NAL header (2) + 2 bytes into the slice header: offset bits
     with pytest.raises(Exception):
         O.decode(bytes(bad))
+
+
+@pytest.mark.parametrize("w,h,qp,bd", [(64, 64, 22, 8), (136, 72, 30, 8), (72, 104, 18, 10), (544, 160, 26, 8)])
+def test_intra_nxn_with_dst_decodes_to_the_oracle_reconstruction(w, h, qp, bd):
+    # 8x8 intra CUs may split into four 4x4 PUs (part_mode NxN): four modes with PU-level MPM derivation, DST-VII 4x4 luma
+    # TUs with mode-dependent scans, 4x4 chroma TUs at the CU level, cbf per 4x4 block; also inside the IDR tile grid
+    cfg = make_cfg(w, h, bd)
+    srcs = [util.synth_frame(h, w, seed=31, shift=(i, 2 * i), bit_depth=bd) for i in range(2)]
+    _, stream, recs, _ = encode_pictures(cfg, srcs, qp, bd, keyint=1, nxn=1)
+    cus = encode_pictures.last_cus
+    assert any((cu["flags"] & 16).any() for cu in cus), "the content must make the analysis choose NxN somewhere"
+    nx = cus[0][(cus[0]["flags"] & 16) != 0]
+    assert (nx["log2_size"] == 3).all() and len({tuple(m) for m in nx["intra_mode"]}) > 1
+    frames, _ = O.decode(stream)
+    for i, (f, r) in enumerate(zip(frames, recs)):
+        assert f.same(r), f"picture {i} differs after decode"
+    _, stream0, _, _ = encode_pictures(cfg, srcs, qp, bd, keyint=1, nxn=0)
+    assert len(stream) != len(stream0)
 
 
 def test_sao_off_and_skip_heavy_static_content():

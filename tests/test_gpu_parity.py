@@ -95,6 +95,20 @@ def test_intra_tile_grid_parity(lib, api, w, h, grid, qp, bd):
     assert util.same_analysis(want, got), util.describe_diff(want, got)
 
 
+@pytest.mark.parametrize("w,h,grid,qp,bd", [(64, 64, (1, 1), 22, 8), (136, 72, (1, 1), 30, 8), (72, 104, (1, 1), 18, 10), (544, 160, (2, 2), 26, 8),
+                                            (1920, 1080, (5, 5), 27, 8)])
+def test_intra_nxn_parity(lib, api, w, h, grid, qp, bd):
+    """K2/K3 with part_mode NxN: four 4x4 PUs per 8x8 CU, DST-VII 4x4 luma TUs, against the oracle."""
+    prm, cp = lib_params(lib, qp, bd, 8)
+    prm.tile_cols, prm.tile_rows = grid
+    cp.tile_cols, cp.tile_rows = grid
+    prm.intra_nxn = cp.intra_nxn = 1
+    src = util.synth_frame(h, w, seed=31, bit_depth=bd)
+    want, got = O.analyze_intra(src, prm), api.intra(src, cp)
+    assert (want.cu["flags"] & 16).any()
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+
+
 def test_search_centres(lib, api):
     w, h = 96, 64
     prm, cp = lib_params(lib, 26, 8, 8)
@@ -126,14 +140,14 @@ def _encode(cfg, frames, keep=True):
         return out, recs, st, enc.coded_size()
 
 
-@pytest.mark.parametrize("w,h,bd,keyint,n", [(96, 80, 8, 4, 10), (132, 76, 8, 5, 7), (64, 64, 10, 3, 7), (544, 160, 8, 3, 7)])
-def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint, n):
+@pytest.mark.parametrize("w,h,bd,keyint,n,nxn", [(96, 80, 8, 4, 10, 0), (132, 76, 8, 5, 7, 1), (64, 64, 10, 3, 7, 1), (544, 160, 8, 3, 7, 0), (544, 160, 8, 3, 4, 1)])
+def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint, n, nxn):
     """End to end: session -> Annex-B -> oracle decoder must equal the encoder's own reconstruction AND the oracle
     pipeline run with the same QPs; includes non-multiple-of-8 sizes (conformance window) and a short last GOP."""
     from hevc_amd import _lib
     cfg = _lib.default_config()
     cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint = w, h, bd, keyint, 2
-    cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud = 27, 8, 2, 1
+    cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud, cfg.intra_nxn = 27, 8, 2, 1, nxn
     if bd == 10:
         cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers = 1, 9, 16, 9, 0, 1
     frames = [util.synth_frame(h, w, seed=9, shift=(i, i // 2), bit_depth=bd) for i in range(n)]
@@ -147,6 +161,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_i, _ = lib_params(lib, qp_i, bd, 8)
     prm_p, _ = lib_params(lib, qp_p, bd, 8)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
+    prm_i.intra_nxn = cfg.intra_nxn                              # NxN trial in IDR pictures when the session asks for it
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     ref = None
     for i, f in enumerate(frames):
@@ -197,6 +212,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     ref = None
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
+        prm.intra_nxn = cfg.intra_nxn
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"

@@ -68,6 +68,18 @@ def test_stepped_intra_with_tile_grid(emu, w, h, grid, qp, bd):
     assert not util.same_analysis(O.analyze_intra(src, flat), want)       # the grid changes the prediction at the borders
 
 
+@pytest.mark.parametrize("w,h,grid,qp,bd", [(64, 64, (1, 1), 22, 8), (136, 72, (1, 1), 30, 8), (72, 104, (1, 1), 18, 10), (544, 160, (2, 2), 26, 8)])
+def test_stepped_intra_nxn(emu, w, h, grid, qp, bd):
+    """8x8 intra CUs tried as four 4x4 PUs (NxN, DST-VII): same decisions, levels, records and reconstruction as the oracle."""
+    prm = O.default_params(qp, bit_depth=bd)
+    prm.tile_cols, prm.tile_rows = grid
+    prm.intra_nxn = 1
+    src = util.synth_frame(h, w, seed=31, bit_depth=bd)
+    want, got = O.analyze_intra(src, prm), emu.intra(src, prm)
+    assert (want.cu["flags"] & 16).any(), "content must make NxN win somewhere"
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+
+
 def test_search_centres_are_honoured(emu):
     w, h, bd = 96, 64, 8
     prm = O.default_params(26, me_range=8)
