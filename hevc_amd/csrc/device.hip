@@ -298,6 +298,52 @@ __global__ __launch_bounds__(NT) void k_transform_blocks(const int16_t *res, int
     });
 }
 
+// 4x4 TUs (DCT, or DST-VII for intra luma): 16 lanes per block, four blocks per wave, the same step sequence and arithmetic as the
+// NxN trial of k_intra_diag (kernels/intra.h code_blocks): rows, columns + quantisation, scaling + inverse columns, inverse rows.
+__global__ __launch_bounds__(NT) void k_transform4_blocks(const int16_t *res, int16_t *lvl, int16_t *rec, int n_blocks, int qp, int bit_depth, int intra, int dst)
+{
+    __shared__ int16_t M[16], sres[NT], slvl[NT];
+    __shared__ int tmp[NT];
+    __shared__ unsigned nz[NT / 16];
+    const int tid = (int)threadIdx.x, g = tid >> 4, i = tid & 15, blk = (int)blockIdx.x * (NT / 16) + g;
+    if (tid < 16) M[tid] = dst ? g_tab.dst4[tid >> 2][tid & 3] : g_tab.mat[(tid >> 2) * 8][tid & 3];
+    if (i == 0) nz[g] = 0;
+    sres[tid] = blk < n_blocks ? res[(size_t)blk * 16 + i] : (int16_t)0;
+    __syncthreads();
+    const int bd = bit_depth, q = qp + 6 * (bd - 8), qbits = 14 + q / 6 + (15 - bd - 2), bsh = bd + 2 - 5, s1 = bd - 7, s3 = 20 - bd;
+    const int16_t *r = sres + g * 16;
+    int *t = tmp + g * 16;
+    int16_t *l = slvl + g * 16;
+    {   const int u = i & 3, y = i >> 2;
+        int acc = 0;
+        for (int x = 0; x < 4; x++) acc += M[u * 4 + x] * r[y * 4 + x];
+        t[i] = (acc + (1 << (s1 - 1))) >> s1; }
+    __syncthreads();
+    {   const int u = i & 3, v = i >> 2;
+        int acc = 0;
+        for (int y = 0; y < 4; y++) acc += M[v * 4 + y] * t[y * 4 + u];
+        const int c = clip3(-32768, 32767, (acc + 128) >> 8);
+        long long a = ((long long)iabs(c) * g_tab.quant_scale[q % 6] + ((long long)(intra ? 171 : 85) << (qbits - 9))) >> qbits;
+        if (a > 32767) a = 32767;
+        l[i] = (int16_t)(c < 0 ? -(int)a : (int)a);
+        if (a) atomicOr(&nz[g], 1u); }
+    __syncthreads();
+    {   const int x = i & 3, y = i >> 2;
+        const long long scale = (long long)16 * g_tab.level_scale[q % 6] << (q / 6);
+        int acc = 0;
+        for (int j = 0; j < 4; j++) acc += M[j * 4 + y] * clip3(-32768, 32767, (int)((l[j * 4 + x] * scale + ((long long)1 << (bsh - 1))) >> bsh));
+        __syncthreads();
+        t[i] = clip3(-32768, 32767, (acc + 64) >> 7); }
+    __syncthreads();
+    {   const int x = i & 3, y = i >> 2;
+        int acc = 0;
+        for (int j = 0; j < 4; j++) acc += M[j * 4 + x] * t[y * 4 + j];
+        if (blk < n_blocks) {
+            lvl[(size_t)blk * 16 + i] = l[i];
+            rec[(size_t)blk * 16 + i] = nz[g] ? (int16_t)((acc + (1 << (s3 - 1))) >> s3) : (int16_t)0;
+        } }
+}
+
 }  // namespace mihevc
 
 // ================================================================================================ C ABI: stages
@@ -473,15 +519,22 @@ int mihevc_device_count(void) { return gfx950_device_count(); }
 int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int16_t *recon_residual, int n_blocks, int log2n, int qp,
                        int bit_depth, int intra, int dst4)
 {
-    if (!residual || !levels || !recon_residual || n_blocks <= 0 || log2n < 2 || log2n > 5 || dst4) return MIHEVC_EINVAL;
+    if (!residual || !levels || !recon_residual || n_blocks <= 0 || log2n < 2 || log2n > 5 || (dst4 && log2n != 2)) return MIHEVC_EINVAL;
     if (bit_depth != 8 && bit_depth != 10) return MIHEVC_EINVAL;
     if (int e = select_device(device)) return e;
     const size_t bytes = (size_t)n_blocks << (2 * log2n + 1);
     DevBuf dres, dlvl, drec;
     CK(dres.alloc(bytes)); CK(dlvl.alloc(bytes)); CK(drec.alloc(bytes));
     CK(hipMemcpy(dres.p, residual, bytes, hipMemcpyHostToDevice));
-    // 4x4 blocks are packed as chroma-style TUs of an 8x8 luma grid: run them through the 8x8 tile map with log2 2
-    if (log2n == 2) return MIHEVC_EINVAL;     // 4x4 is exercised through the chroma planes of the frame stages
+    if (log2n == 2) {     // 4-point DCT, or DST-VII (intra luma 4x4)
+        hipLaunchKernelGGL(k_transform4_blocks, dim3((unsigned)((n_blocks + NT / 16 - 1) / (NT / 16))), dim3(NT), 0, 0, dres.as<int16_t>(), dlvl.as<int16_t>(),
+                           drec.as<int16_t>(), n_blocks, qp, bit_depth, intra, dst4);
+        CK(hipGetLastError());
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(levels, dlvl.p, bytes, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(recon_residual, drec.p, bytes, hipMemcpyDeviceToHost));
+        return MIHEVC_OK;
+    }
     const int per = 1024 >> (2 * log2n);
     hipLaunchKernelGGL(k_transform_blocks, dim3((unsigned)((n_blocks + per - 1) / per)), dim3(NT), 0, 0, dres.as<int16_t>(), dlvl.as<int16_t>(),
                        drec.as<int16_t>(), n_blocks, log2n, qp, bit_depth, intra);

@@ -147,7 +147,8 @@ typedef struct mihevc_sao_ctu {
 /* ---- per-stage entry points: host buffers in, host buffers out, one device pass each.  They run the SAME kernels
  *      the session runs, so the parity tests (tests/test_gpu_parity.py) hit each stage alone.  Sample planes are
  *      uint8_t when bit_depth == 8 and uint16_t otherwise; pitches are in samples. ---- */
-/* K3: forward transform + quantisation + dequantisation + inverse transform of n_blocks residual blocks */
+/* K3: forward transform + quantisation + dequantisation + inverse transform of n_blocks residual blocks; log2n 2..5 (4/8/16/32-point
+ * DCT); dst4 = 1 with log2n = 2 selects the 4x4 DST-VII of intra luma TUs (8.6.4.2) */
 int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int16_t *recon_residual,
                        int n_blocks, int log2n, int qp, int bit_depth, int intra, int dst4);
 /* K2+K3: intra picture analysis -> pre-deblock reconstruction, CU records, levels */

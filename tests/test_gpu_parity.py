@@ -30,9 +30,9 @@ def lib_params(lib, qp, bd, rng):
     return O.Params(p.qp, p.qp_c, p.bit_depth, p.lambda_sad_q4, p.lambda_q4, p.me_range), p
 
 
-@pytest.mark.parametrize("log2n", [3, 4, 5])
+@pytest.mark.parametrize("log2n,dst", [(2, 0), (2, 1), (3, 0), (4, 0), (5, 0)])
 @pytest.mark.parametrize("qp,bd,intra", [(22, 8, 1), (37, 8, 0), (27, 10, 1)])
-def test_k3_transform_quant_roundtrip(lib, log2n, qp, bd, intra):
+def test_k3_transform_quant_roundtrip(lib, log2n, dst, qp, bd, intra):
     n = 1 << log2n
     rng = np.random.default_rng(log2n * 100 + qp)
     nb = 70
@@ -43,11 +43,11 @@ def test_k3_transform_quant_roundtrip(lib, log2n, qp, bd, intra):
     res[2] = rng.integers(-3, 4, (n, n))
     lv = np.zeros_like(res)
     rc = np.zeros_like(res)
-    assert lib.mihevc_k_transform(0, util.ptr(res), util.ptr(lv), util.ptr(rc), nb, log2n, qp, bd, intra, 0) == 0
+    assert lib.mihevc_k_transform(0, util.ptr(res), util.ptr(lv), util.ptr(rc), nb, log2n, qp, bd, intra, dst) == 0
     for b in range(nb):
-        coef = O.fwd_transform(res[b], bit_depth=bd)
+        coef = O.fwd_transform(res[b], dst=bool(dst), bit_depth=bd)
         want_l = O.quant(coef, qp, bit_depth=bd, intra=bool(intra))
-        want_r = O.inv_transform(O.dequant(want_l, qp, bit_depth=bd), bit_depth=bd)
+        want_r = O.inv_transform(O.dequant(want_l, qp, bit_depth=bd), dst=bool(dst), bit_depth=bd) if want_l.any() else np.zeros_like(want_l)
         assert np.array_equal(lv[b], want_l), (b, log2n)
         assert np.array_equal(rc[b], want_r), (b, log2n)
     assert not lv[0].any() and not rc[0].any()
