@@ -269,6 +269,30 @@ DEV void load_row15(const uint16_t *base, int idx, int (&px)[15])
     for (int i = 0; i < 15; i++) px[i] = (int)((r[i >> 1] >> (16 * (i & 1))) & 65535);
 }
 
+// 8 consecutive samples base[idx .. idx+7], same aligned-read scheme
+DEV void load_row8(const uint8_t *base, int idx, int (&px)[8])
+{
+    const int off = idx & 3;
+    const uint8_t *p = base + (idx - off);
+    const uint32_t d0 = load_u32_aligned(p), d1 = load_u32_aligned(p + 4), d2 = load_u32_aligned(p + 8);
+    const uint32_t r0 = align_bytes(d1, d0, off), r1 = align_bytes(d2, d1, off);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { px[i] = (int)((r0 >> (8 * i)) & 255); px[4 + i] = (int)((r1 >> (8 * i)) & 255); }
+}
+DEV void load_row8(const uint16_t *base, int idx, int (&px)[8])
+{
+    const int off = idx & 1;
+    const uint16_t *p = base + (idx - off);
+    uint32_t d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = load_u32_aligned(p + 2 * k);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t r = align_bytes(d[k + 1], d[k], 2 * off);
+        px[2 * k] = (int)(r & 65535); px[2 * k + 1] = (int)(r >> 16);
+    }
+}
+
 // sum of four signed-byte products + acc (v_dot4_i32_i8)
 DEV int dot4_i8(uint32_t a, uint32_t b, int acc)
 {

@@ -6,8 +6,9 @@
 // search window are staged through LDS with row-contiguous loads; nothing else is read from HBM.
 // Decisions are defined by oracle/hevc_oracle.c orc_analyze_inter_frame and reproduced exactly:
 //   integer:  cost = (SAD << 4) + lambda_sad_q4 * (bits(4dx) + bits(4dy)), ties -> smaller raster position
-//   fraction: half-pel ring then quarter-pel ring, cost = (SATD << 4) + lambda * mvd bits, ties -> lower index
-//   tree:     bottom-up, J = cost + 4 lambda per CU, split adds 2 lambda, whole wins ties
+//   tree:     bottom-up on the integer-vector SATD costs, J = (SATD << 4) + lambda * mvd bits + 4 lambda per CU, split adds 2 lambda,
+//             whole wins ties
+//   fraction: chosen CUs only: half-pel ring then quarter-pel ring, cost = (SATD << 4) + lambda * mvd bits, ties -> lower index
 // Motion compensation is H.265 8.5.3.3.3 (luma 8-tap, chroma 4-tap, uni-prediction rounding).
 #pragma once
 #include "common.h"
@@ -190,6 +191,7 @@ template <typename T> struct InterShared {
     uint8_t alias[3][16];        // level whose SATDs stand for (level, tile): a coarser node with the SAME vector as a finer one is not recomputed
     int tile_mvx[16], tile_mvy[16];
     uint8_t tile_node[16];
+    uint8_t chosen[21];          // node is a CU of the decided quadtree
     unsigned est;                // CTU rate estimate, 1/16 bit
     // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
 };
@@ -310,6 +312,20 @@ DEV int luma_tile(const uint8_t *win, int i00, int ws, int fx, int fy, int bit_d
     return diff_src ? hadamard8_satd(acc) : 0;
 }
 
+// SATD of one 8x8 tile against the window at an INTEGER vector (both fractions zero: the prediction is the window itself)
+template <typename T> DEV int luma_tile_int(const T *win, int i00, int ws, const T *src, int src_stride)
+{
+    int m[8][8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        int px[8];
+        load_row8(win, i00 + j * ws, px);
+#pragma unroll
+        for (int i = 0; i < 8; i++) m[j][i] = (int)src[j * src_stride + i] - px[i];
+    }
+    return hadamard8_satd(m);
+}
+
 // four horizontally adjacent predicted luma samples (8.5.3.3.3.1) starting at window element i00: the final motion
 // compensation of a CTU spread over all 256 lanes (16 tiles x 8 rows x 2 halves)
 template <typename T>
@@ -375,48 +391,36 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.valid[tid] = m[2] >= 0; s.cost[tid] = 0;
         }
     });
-    // fractional refinement: round 0 = centre + half-pel ring, round 1 = quarter-pel ring
-    for (int round = 0; round < 2; round++) {
-        const int step = round == 0 ? 2 : 1, k0 = round == 0 ? 0 : 1;
-        ex.phase([&](int tid) {
-            for (int u = tid; u < 3 * 9 * 16; u += NT) {
-                int level = u / 144, k = (u / 16) % 9, t = u & 15;
-                if (k < k0) continue;
-                int txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
-                if (!s.valid[node]) continue;
-                // identical vectors give identical tile SATDs: let the finest level that shares the vector do the work
-                int al = level;
-                for (int fl = 2; fl > level; fl--) {
-                    int fn = node_of_tile(fl, txp, typ);
-                    if (s.valid[fn] && s.mvx[fn] == s.mvx[node] && s.mvy[fn] == s.mvy[node]) { al = fl; break; }
-                }
-                if (k == k0) s.alias[level][t] = (uint8_t)al;
-                if (al != level) continue;
-                int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
-                int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                s.satd[level][k][t] = luma_tile((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8), 32, (T *)nullptr, 0);
+    // SATD of every node at its INTEGER vector: the quadtree is decided on these (+ lambda * mvd bits), the fractional search then
+    // runs for the chosen CUs only — 16 tiles x 8 ring positions = 128 lanes = two full waves per round, instead of one
+    // pass per tree level (the search was 43 % of this kernel: profiles/r01)
+    ex.phase([&](int tid) {
+        for (int u = tid; u < 3 * 16; u += NT) {
+            int level = u >> 4, t = u & 15;
+            int txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
+            if (!s.valid[node]) continue;
+            // identical vectors give identical tile SATDs: let the finest level that shares the vector do the work
+            int al = level;
+            for (int fl = 2; fl > level; fl--) {
+                int fn = node_of_tile(fl, txp, typ);
+                if (s.valid[fn] && s.mvx[fn] == s.mvx[node] && s.mvy[fn] == s.mvy[node]) { al = fl; break; }
             }
-        });
-        ex.phase([&](int tid) {
-            if (tid >= 21 || !s.valid[tid]) return;
-            int nx, ny, nl;
-            node_geom(tid, nx, ny, nl);
-            int level = 5 - nl, tiles = 1 << (nl - 3);
-            unsigned long long best = round == 0 ? ~0ull : ((unsigned long long)s.cost[tid] << 4);
-            for (int k = k0; k < 9; k++) {
-                unsigned satd = 0;
-                for (int j = 0; j < tiles; j++)
-                    for (int i = 0; i < tiles; i++) { int t = ((ny >> 3) + j) * 4 + (nx >> 3) + i; satd += (unsigned)s.satd[s.alias[level][t]][k][t]; }
-                int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
-                unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
-                unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
-                if (key < best) best = key;
-            }
-            int k = (int)(best & 15);
-            s.mvx[tid] += kOff[k][0] * step; s.mvy[tid] += kOff[k][1] * step;
-            s.cost[tid] = (unsigned)(best >> 4);
-        });
-    }
+            s.alias[level][t] = (uint8_t)al;
+            if (al != level) continue;
+            int px = x0 + txp * 8 + (s.mvx[node] >> 2) - oy_x, py = y0 + typ * 8 + (s.mvy[node] >> 2) - oy_y;
+            s.satd[level][0][t] = luma_tile_int<T>(win_y, py * wys + px, wys, s.src + typ * 8 * 32 + txp * 8, 32);
+        }
+    });
+    ex.phase([&](int tid) {
+        if (tid >= 21 || !s.valid[tid]) return;
+        int nx, ny, nl;
+        node_geom(tid, nx, ny, nl);
+        int level = 5 - nl, tiles = 1 << (nl - 3);
+        unsigned satd = 0;
+        for (int j = 0; j < tiles; j++)
+            for (int i = 0; i < tiles; i++) { int t = ((ny >> 3) + j) * 4 + (nx >> 3) + i; satd += (unsigned)s.satd[s.alias[level][t]][0][t]; }
+        s.cost[tid] = (satd << 4) + (unsigned)(lam * (mvd_bits(s.mvx[tid] - 4 * sx) + mvd_bits(s.mvy[tid] - 4 * sy)));
+    });
     // quadtree decision
     ex.phase([&](int tid) {
         if (tid != 0) return;
@@ -433,16 +437,53 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             js32 += J16[q];
         }
         use32 = s.valid[0] && J[0] <= js32;
+        for (int n = 0; n < 21; n++) s.chosen[n] = 0;
         for (int t = 0; t < 16; t++) {
             int txp = t & 3, typ = t >> 2, q = (typ >> 1) * 2 + (txp >> 1);
             int n8 = node_of_tile(2, txp, typ);
             int node = use32 ? 0 : use16[q] ? 1 + q : n8;
             int inside = s.valid[n8];                 // the 8x8 tile itself lies inside the picture
             s.tile_node[t] = (uint8_t)node;
-            s.tile_mvx[t] = s.mvx[node]; s.tile_mvy[t] = s.mvy[node];
+            if (inside) s.chosen[node] = 1;
             s.rs.tu_log2[t] = inside ? (uint8_t)(node == 0 ? 5 : node < 5 ? 4 : 3) : 0;
             s.rs.tu_intra[t] = 0;
         }
+    });
+    // fractional refinement of the chosen CUs: half-pel ring, then quarter-pel ring (the centre's cost is known)
+    for (int round = 0; round < 2; round++) {
+        const int step = round == 0 ? 2 : 1;
+        ex.phase([&](int tid) {
+            for (int u = tid; u < 8 * 16; u += NT) {
+                int k = 1 + (u >> 4), t = u & 15;
+                if (!s.rs.tu_log2[t]) continue;
+                int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
+                int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
+                int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
+                s.satd[0][k][t] = luma_tile((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8), 32, (T *)nullptr, 0);
+            }
+        });
+        ex.phase([&](int tid) {
+            if (tid >= 21 || !s.valid[tid] || !s.chosen[tid]) return;
+            int nx, ny, nl;
+            node_geom(tid, nx, ny, nl);
+            int tiles = 1 << (nl - 3);
+            unsigned long long best = (unsigned long long)s.cost[tid] << 4;
+            for (int k = 1; k < 9; k++) {
+                unsigned satd = 0;
+                for (int j = 0; j < tiles; j++)
+                    for (int i = 0; i < tiles; i++) { int t = ((ny >> 3) + j) * 4 + (nx >> 3) + i; satd += (unsigned)s.satd[0][k][t]; }
+                int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
+                unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
+                unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
+                if (key < best) best = key;
+            }
+            int k = (int)(best & 15);
+            s.mvx[tid] += kOff[k][0] * step; s.mvy[tid] += kOff[k][1] * step;
+            s.cost[tid] = (unsigned)(best >> 4);
+        });
+    }
+    ex.phase([&](int tid) {
+        if (tid < 16) { s.tile_mvx[tid] = s.mvx[s.tile_node[tid]]; s.tile_mvy[tid] = s.mvy[s.tile_node[tid]]; }
     });
     // motion compensation of the chosen CUs: every lane predicts 4 luma samples and 2 chroma samples
     ex.phase([&](int tid) {

@@ -586,18 +586,45 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                     me_dump[(ctu * 21 + nd) * 3 + 1] = valid[nd] ? mvy[nd] : 0;
                     me_dump[(ctu * 21 + nd) * 3 + 2] = valid[nd] ? (int32_t)cost[nd] : -1;
                 }
-            /* --- fractional refinement with SATD: half-pel ring then quarter-pel ring --- */
-            uint32_t J[21];
+            /* --- quadtree decision, bottom-up, on the SATD of every node at its INTEGER vector (+ lambda * mvd bits).  The
+             *     fractional search then runs for the chosen CUs only: a CTU is covered once (16 tiles x 8 ring positions per round
+             *     on the device) instead of once per tree level --- */
+            uint32_t J[21], cint[21];
             pix pred[32 * 32];
             for (int nd = 0; nd < 21; nd++) {
-                J[nd] = 0;
+                J[nd] = cint[nd] = 0;
                 if (!valid[nd]) continue;
+                int n = 1 << nl[nd], bx = x0 + nx[nd], by = y0 + ny[nd];
+                orc_interp_luma(ref_y, ref_stride, bx, by, mvx[nd], mvy[nd], n, n, bd, pred, n);
+                cint[nd] = ((uint32_t)orc_satd(src_y + by * src_stride + bx, src_stride, pred, n, n, n) << 4) +
+                           (uint32_t)(lam * (orc_mvd_bits(mvx[nd] - 4 * sx) + orc_mvd_bits(mvy[nd] - 4 * sy)));
+                J[nd] = cint[nd] + (uint32_t)(lam * 4);
+            }
+            int use16[4], use32;
+            uint32_t J16[4];
+            for (int q = 0; q < 4; q++) {
+                uint32_t js = (uint32_t)(lam * 2);
+                for (int s = 0; s < 4; s++) if (valid[5 + 4 * q + s]) js += J[5 + 4 * q + s];
+                use16[q] = valid[1 + q] && J[1 + q] <= js;
+                J16[q] = use16[q] ? J[1 + q] : js;
+            }
+            {
+                uint32_t js = (uint32_t)(lam * 2);
+                for (int q = 0; q < 4; q++) js += J16[q];
+                use32 = valid[0] && J[0] <= js;
+            }
+            /* --- fractional refinement of the chosen CUs with SATD: half-pel ring then quarter-pel ring --- */
+            for (int nd = 0; nd < 21; nd++) {
+                if (!valid[nd]) continue;
+                int chosen;
+                if (nd == 0) chosen = use32;
+                else if (nd < 5) chosen = !use32 && use16[nd - 1];
+                else chosen = !use32 && !use16[(nd - 5) >> 2];
+                if (!chosen) continue;
                 int n = 1 << nl[nd], bx = x0 + nx[nd], by = y0 + ny[nd];
                 const pix *s = src_y + by * src_stride + bx;
                 int cmx = mvx[nd], cmy = mvy[nd];
-                orc_interp_luma(ref_y, ref_stride, bx, by, cmx, cmy, n, n, bd, pred, n);
-                uint32_t cbest = ((uint32_t)orc_satd(s, src_stride, pred, n, n, n) << 4) +
-                                 (uint32_t)(lam * (orc_mvd_bits(cmx - 4 * sx) + orc_mvd_bits(cmy - 4 * sy)));
+                uint32_t cbest = cint[nd];
                 for (int step = 2; step >= 1; step--) {
                     uint64_t best = ((uint64_t)cbest << 4) | 0;
                     for (int k = 0; k < 8; k++) {
@@ -613,21 +640,6 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                     cbest = (uint32_t)(best >> 4);
                 }
                 mvx[nd] = cmx; mvy[nd] = cmy;
-                J[nd] = cbest + (uint32_t)(lam * 4);
-            }
-            /* --- quadtree decision, bottom-up --- */
-            int use16[4], use32;
-            uint32_t J16[4];
-            for (int q = 0; q < 4; q++) {
-                uint32_t js = (uint32_t)(lam * 2);
-                for (int s = 0; s < 4; s++) if (valid[5 + 4 * q + s]) js += J[5 + 4 * q + s];
-                use16[q] = valid[1 + q] && J[1 + q] <= js;
-                J16[q] = use16[q] ? J[1 + q] : js;
-            }
-            {
-                uint32_t js = (uint32_t)(lam * 2);
-                for (int q = 0; q < 4; q++) js += J16[q];
-                use32 = valid[0] && J[0] <= js;
             }
             /* --- residual coding of the chosen CUs --- */
             for (int nd = 0; nd < 21; nd++) {
