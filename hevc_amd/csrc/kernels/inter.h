@@ -67,27 +67,31 @@ DEV void quad_block_row(const uint8_t *src, const uint8_t *ref, int ws, unsigned
 }
 DEV void quad_block_row(const uint16_t *src, const uint16_t *ref, int ws, unsigned (&out)[4][4])
 {
-    // 16-bit samples: no quad-SAD instruction; v_sad_u16 on sample pairs, odd positions realigned with v_alignbyte
-    unsigned acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int r = 0; r < 8; r++) {
-        uint32_t rr[18], cc[16];
+    // 16-bit samples: no quad-SAD instruction; v_sad_u16 on sample pairs, odd positions realigned with v_alignbyte.  Two 8x8
+    // blocks at a time: a whole block row kept 50 dwords live per lane and spilled (256 VGPRs + 56 spills at 2 workgroups per CU)
 #pragma unroll
-        for (int d = 0; d < 18; d++) rr[d] = load_u32_aligned(ref + r * ws + 2 * d);
+    for (int bp = 0; bp < 2; bp++) {
+        unsigned acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int r = 0; r < 8; r++) {
+            uint32_t rr[10], cc[8];
 #pragma unroll
-        for (int d = 0; d < 16; d++) cc[d] = load_u32_aligned(src + r * 32 + 2 * d);
+            for (int d = 0; d < 10; d++) rr[d] = load_u32_aligned(ref + r * ws + 16 * bp + 2 * d);
 #pragma unroll
-        for (int j = 0; j < 4; j++)
+            for (int d = 0; d < 8; d++) cc[d] = load_u32_aligned(src + r * 32 + 16 * bp + 2 * d);
 #pragma unroll
-            for (int d = 0; d < 16; d++) {
-                const int k = d + (j >> 1);
-                uint32_t v = (j & 1) ? align_bytes(rr[k + 1], rr[k], 2) : rr[k];
-                acc[d >> 2][j] = sad_packed_u16(v, cc[d], acc[d >> 2][j]);
-            }
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int d = 0; d < 8; d++) {
+                    const int k = d + (j >> 1);
+                    uint32_t v = (j & 1) ? align_bytes(rr[k + 1], rr[k], 2) : rr[k];
+                    acc[d >> 2][j] = sad_packed_u16(v, cc[d], acc[d >> 2][j]);
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) out[2 * bp + b][j] = acc[b][j];
     }
-#pragma unroll
-    for (int b = 0; b < 4; b++)
-#pragma unroll
-        for (int j = 0; j < 4; j++) out[b][j] = acc[b][j];
 }
 
 template <typename T, class Ex>
@@ -308,6 +312,69 @@ DEV int luma_tile(const uint8_t *win, int i00, int ws, int fx, int fy, int bit_d
             int v = clip3(0, 255, ((acc[j][i] >> 6) + 32) >> 6);
             if (diff_src) acc[j][i] = (int)diff_src[j * src_stride + i] - v;
             else pred_out[j * pred_stride + i] = (uint8_t)v;
+        }
+    return diff_src ? hadamard8_satd(acc) : 0;
+}
+
+// 16-bit specialisation (Main10): samples are already int16 pairs in the window's dwords, so the horizontal 8-tap filter is
+// 4 v_dot2_i32_i16 per output (odd outputs on dwords realigned by one sample), the column filter 4 v_dot2 on row pairs as in
+// the 8-bit form.  Intermediates stay below 2^15 (8.5.3.3.3: 14-bit intermediate precision), results equal the generic form.
+DEV int luma_tile(const uint16_t *win, int i00, int ws, int fx, int fy, int bit_depth, const uint16_t *diff_src, int src_stride, uint16_t *pred_out,
+                  int pred_stride)
+{
+    uint32_t txp[4], typ[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        txp[m] = pack_lo16(g_tab.luma_tap[fx][2 * m], g_tab.luma_tap[fx][2 * m + 1]);
+        typ[m] = pack_lo16(g_tab.luma_tap[fy][2 * m], g_tab.luma_tap[fy][2 * m + 1]);
+    }
+    const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1;
+    int acc[8][8], prev[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+        const int idx = i00 + (r - 3) * ws - 3, off = idx & 1;
+        const uint16_t *p = win + (idx - off);
+        uint32_t d[9], e[8], o[7];
+#pragma unroll
+        for (int k = 0; k < 9; k++) d[k] = load_u32_aligned(p + 2 * k);
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = align_bytes(d[k + 1], d[k], 2 * off);     // samples (2k, 2k+1) of the row
+#pragma unroll
+        for (int k = 0; k < 7; k++) o[k] = align_bytes(e[k + 1], e[k], 2);           // samples (2k+1, 2k+2)
+        int hv[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int v = 0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) v = dot2_i16((i & 1) ? o[(i >> 1) + m] : e[(i >> 1) + m], txp[m], v);
+            hv[i] = v >> shift1;
+        }
+        if (r > 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t pr = pack_lo16(prev[i], hv[i]);
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int j = r - 1 - 2 * m;
+                    if (j >= 0 && j < 8) acc[j][i] = dot2_i16(pr, typ[m], acc[j][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) prev[i] = hv[i];
+    }
+    const int off3 = 1 << (shift3 - 1);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int v = clip3(0, maxv, ((acc[j][i] >> 6) + off3) >> shift3);
+            if (diff_src) acc[j][i] = (int)diff_src[j * src_stride + i] - v;
+            else pred_out[j * pred_stride + i] = (uint16_t)v;
         }
     return diff_src ? hadamard8_satd(acc) : 0;
 }

@@ -139,7 +139,7 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
-            if (!l.log2n) continue;
+            if (!l.log2n || !((s.cbf[l.plane] >> l.tile0) & 1)) continue;     // a TU without levels reconstructs to zero: nothing to invert
             const int n = 1 << l.log2n, yy = l.y - l.ty0;
             const uint32_t *m = s.mq + pair_off(l.log2n) + yy;
             const int16_t *d = s.tmp + l.base + l.ty0 * l.stride + 2 * l.x;
@@ -152,7 +152,7 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
         for (int k = tid; k < cnt; k += NT) {
             const int idx = rg.index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
-            if (!l.log2n) { s.res[idx] = 0; continue; }
+            if (!l.log2n || !((s.cbf[l.plane] >> l.tile0) & 1)) { s.res[idx] = 0; continue; }
             const int n = 1 << l.log2n, xx = l.x - l.tx0, sh = 20 - bit_depth;
             const uint32_t *m = s.mq + pair_off(l.log2n) + xx;
             const int16_t *g = s.coef + l.base + l.y * l.stride + l.tx0;
