@@ -355,9 +355,18 @@ DEV int hadamard8_satd(int (&m)[8][8])
 // ------------------------------------------------------------------------------------------ executors
 #if MIHEVC_GPU
 struct GpuExec {
+    // The lane id reaches every phase through an opaque asm: without it LLVM hoists each phase's lane-index arithmetic to the
+    // kernel entry and keeps it all live across the whole CTU program (k_intra_diag: 88 VGPR spill stores at entry, 92 MB of
+    // scratch writes per launch, profiles/r01_c_bench); recomputing a few integer ops per phase is far cheaper.
+    static DEV int lane_id()
+    {
+        int t = (int)threadIdx.x;
+        asm volatile("" : "+v"(t));
+        return t;
+    }
     template <class F> DEV void phase(F &&f)
     {
-        f((int)threadIdx.x);
+        f(lane_id());
         __syncthreads();
     }
     // A step whose producers and consumers all sit in ONE wave (lanes tid < 64): no workgroup barrier, only wave-scope
@@ -365,7 +374,7 @@ struct GpuExec {
     // The caller closes the sequence of wave steps with a full phase() before other waves look at the results.
     template <class F> DEV void wave_step(F &&f)
     {
-        f((int)threadIdx.x);
+        f(lane_id());
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }

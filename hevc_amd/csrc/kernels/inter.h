@@ -310,8 +310,12 @@ DEV int luma_tile(const uint8_t *win, int i00, int ws, int fx, int fy, int bit_d
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             int v = clip3(0, 255, ((acc[j][i] >> 6) + 32) >> 6);
-            if (diff_src) acc[j][i] = (int)diff_src[j * src_stride + i] - v;
-            else pred_out[j * pred_stride + i] = (uint8_t)v;
+            if (diff_src) {
+                // source rows as two aligned dwords (the tile is 8-aligned in the CTU image): 64 single-byte LDS loads issued up
+                // front cost 64 VGPRs and pushed the kernel into scratch spills
+                const uint32_t w = load_u32_aligned(diff_src + j * src_stride + (i & 4));
+                acc[j][i] = (int)((w >> (8 * (i & 3))) & 255) - v;
+            } else pred_out[j * pred_stride + i] = (uint8_t)v;
         }
     return diff_src ? hadamard8_satd(acc) : 0;
 }
