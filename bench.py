@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-threads", type=int, default=0, help="CABAC worker threads (0 = library default)")
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
+    ap.add_argument("--intra-nxn", type=int, default=None, help="experiments only: override cfg.intra_nxn (4x4 PUs + DST in IDR pictures)")
+    ap.add_argument("--intra-tiles", type=int, default=None, help="experiments only: override cfg.intra_tiles (IDR tile grid)")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -106,6 +108,10 @@ def main():
     cfg.me_range, cfg.profile_stages = args.me_range, 1
     cfg.qp = args.qp
     cfg.host_threads = args.host_threads
+    if args.intra_nxn is not None:
+        cfg.intra_nxn = args.intra_nxn
+    if args.intra_tiles is not None:
+        cfg.intra_tiles = args.intra_tiles
 
     # synthetic clip -> HBM (untimed).  torch is plumbing for device memory only.
     clip = SyntheticClip("motion", rank, W, H, N)

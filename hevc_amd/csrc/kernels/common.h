@@ -239,6 +239,20 @@ DEV uint32_t load_u32_aligned(const void *p)
     __builtin_memcpy(&v, __builtin_assume_aligned(p, 4), 4);
     return v;
 }
+DEV void store_u32_aligned(void *p, uint32_t v) { __builtin_memcpy(__builtin_assume_aligned(p, 4), &v, 4); }
+// four horizontally adjacent samples / levels as dword stores (p is 4-sample aligned): single-byte global stores cost one
+// instruction and one partial-line write request each
+DEV void store4(uint8_t *p, int v0, int v1, int v2, int v3) { store_u32_aligned(p, (uint32_t)v0 | (uint32_t)v1 << 8 | (uint32_t)v2 << 16 | (uint32_t)v3 << 24); }
+DEV void store4(uint16_t *p, int v0, int v1, int v2, int v3)
+{
+    store_u32_aligned(p, (uint32_t)v0 | (uint32_t)v1 << 16);
+    store_u32_aligned(p + 2, (uint32_t)v2 | (uint32_t)v3 << 16);
+}
+DEV void store4(int16_t *p, int v0, int v1, int v2, int v3)
+{
+    store_u32_aligned(p, ((uint32_t)v0 & 0xffffu) | (uint32_t)v1 << 16);
+    store_u32_aligned(p + 2, ((uint32_t)v2 & 0xffffu) | (uint32_t)v3 << 16);
+}
 // 15 consecutive samples base[idx .. idx+14] from an LDS image whose `base` is 4-byte aligned, fetched with aligned
 // dword reads + v_alignbyte (unaligned ds_read_b64 stalls: SQ_LDS_UNALIGNED_STALL, profiles/r01_a_first)
 DEV void load_row15(const uint8_t *base, int idx, int (&px)[15])

@@ -584,13 +584,15 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     // reconstruction + outputs
     ex.phase([&](int tid) {
         const int maxv = (1 << bd) - 1;
-        for (int i = tid; i < 1536; i += NT) {
+        for (int i = 4 * tid; i < 1536; i += 4 * NT) {      // four samples of one row per lane (a TU is at least 4 wide)
             SampleLoc l = locate(s.rs, i);
             if (!l.log2n) continue;
-            int gx = (l.plane ? x0 >> 1 : x0) + l.x, gy = (l.plane ? y0 >> 1 : y0) + l.y;
-            int v = clip3(0, maxv, (int)s.pred[i] + s.rs.res[i]);
-            a.rec[l.plane].p[(ptrdiff_t)gy * a.rec[l.plane].stride + gx] = (T)v;
-            if (!a.sparse_coef || ((s.rs.cbf[l.plane] >> l.tile0) & 1)) a.coef[l.plane][(size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx] = s.rs.lvl[i];
+            int gx = (l.plane ? x0 >> 1 : x0) + l.x, gy = (l.plane ? y0 >> 1 : y0) + l.y, v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = clip3(0, maxv, (int)s.pred[i + j] + s.rs.res[i + j]);
+            store4(a.rec[l.plane].p + (ptrdiff_t)gy * a.rec[l.plane].stride + gx, v[0], v[1], v[2], v[3]);
+            if (!a.sparse_coef || ((s.rs.cbf[l.plane] >> l.tile0) & 1))
+                store4(a.coef[l.plane] + (size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx, s.rs.lvl[i], s.rs.lvl[i + 1], s.rs.lvl[i + 2], s.rs.lvl[i + 3]);
         }
         if (a.est) {       // rate estimate: coefficient sub-block costs + a header per CU (oracle: inter estimate)
             unsigned e = 0;

@@ -710,15 +710,17 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
     }
     // the CTU is final: reconstruction, levels and CU records to memory
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1536; i += NT) {
+        for (int i = 4 * tid; i < 1536; i += 4 * NT) {      // four samples of one row per lane, dword stores
             int pl, x, y;
             if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
             int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
-            if (gx >= pw || gy >= ph) continue;
-            a.rec[pl].p[(ptrdiff_t)gy * a.rec[pl].stride + gx] = pl ? s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : s.rec_y[(y + 1) * RY_STRIDE + x + 1];
+            if (gx >= pw || gy >= ph) continue;            // widths are multiples of 4 in both planes: a quad is inside or outside
+            const T *r = pl ? &s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : &s.rec_y[(y + 1) * RY_STRIDE + x + 1];
+            store4(a.rec[pl].p + (ptrdiff_t)gy * a.rec[pl].stride + gx, r[0], r[1], r[2], r[3]);
             {
                 const int sh = pl ? 2 : 3, fl = s.cu_acc[(y >> sh) * 4 + (x >> sh)].flags;
-                if (!a.sparse_coef || (fl & (pl == 0 ? CU_CBF_Y : pl == 1 ? CU_CBF_CB : CU_CBF_CR))) a.coef[pl][(size_t)gy * pw + gx] = s.coef_acc[i];
+                if (!a.sparse_coef || (fl & (pl == 0 ? CU_CBF_Y : pl == 1 ? CU_CBF_CB : CU_CBF_CR)))
+                    store4(a.coef[pl] + (size_t)gy * pw + gx, s.coef_acc[i], s.coef_acc[i + 1], s.coef_acc[i + 2], s.coef_acc[i + 3]);
             }
         }
         if (tid < 16) {
