@@ -198,7 +198,7 @@ def main():
                                    f"keyint {gop}, IPPP, full-search +-{args.me_range}, one clip per GPU"},
             "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1),
                         "libx265_parity": "unavailable: no ffmpeg/libx265 on this host"},
-            "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(stage_ms[i] / max(1.0, stage_pics[i]), 4) for i in range(7)},
+            "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(stage_ms[i] / max(1.0, stage_pics[i]), 4) for i in range(8)},
             "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count(),
                      "step_phases_ms": dict(zip(("open", "send", "flush_drain", "close"), [round(x / args.steps * 1e3, 2) for x in phase_s])),
                      "device_ms_per_step": round(st.device_ms, 2)},

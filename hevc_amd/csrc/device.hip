@@ -70,6 +70,20 @@ template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_d
     intra_ctu_program<T>(ex, s, a, cx, cy);
 }
 
+// intra second pass of P pictures: one workgroup per CTU, most of them leave at once (not a candidate of this round)
+template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_p(const IntraArgs<T> *args, int n_ctu, int round)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const IntraArgs<T> &a = args[blockIdx.y];
+    const int ctu = (int)blockIdx.x;
+    if (ctu >= n_ctu || !a.ip) return;
+    const int cx = ctu % a.ctus_w, cy = ctu / a.ctus_w;
+    if (!ip_eligible(a.ip, a.ctus_w, a.ctus_h, cx, cy, round)) return;
+    IntraShared<T> &s = *reinterpret_cast<IntraShared<T> *>(smem);
+    GpuExec ex;
+    intra_ctu_program<T>(ex, s, a, cx, cy);
+}
+
 template <typename T> __global__ __launch_bounds__(256) void k_deblock(const DeblockArgs<T> *args)
 {
     deblock_segment<T>(args[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
@@ -196,6 +210,16 @@ template <typename T> hipError_t launch_intra_picture(hipStream_t st, const Intr
     return hipGetLastError();
 }
 
+template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch)
+{
+    size_t smem = round16(sizeof(IntraShared<T>));
+    hipError_t e = ensure_smem(k_intra_p<T>, smem);
+    if (e != hipSuccess) return e;
+    for (int round = 0; round < 2; round++)
+        hipLaunchKernelGGL(k_intra_p<T>, dim3((unsigned)n_ctu, (unsigned)batch), dim3(NT), smem, st, d_args, n_ctu, round);
+    return hipGetLastError();
+}
+
 template <typename T> hipError_t launch_deblock(hipStream_t st, const DeblockArgs<T> *d_v, const DeblockArgs<T> *d_h, int w, int h, int batch)
 {
     int segs = (w >> 3) * (h >> 3) * 2;
@@ -251,7 +275,8 @@ int gfx950_device_count()
 #define INSTANTIATE(T)                                                                                                   \
     template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
-    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                      \
+    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                 \
+    template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                      \
     template hipError_t launch_deblock<T>(hipStream_t, const DeblockArgs<T> *, const DeblockArgs<T> *, int, int, int);  \
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
@@ -390,7 +415,7 @@ template <typename T> struct Planes3 {
     ~Planes3() { for (auto &x : p) free_plane<T>(x); }
 };
 
-CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn}; }
+CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p}; }
 
 bool geometry_ok(int w, int h) { return w >= 16 && h >= 16 && !(w & 7) && !(h & 7) && w <= 8192 && h <= 4352; }
 
@@ -409,7 +434,7 @@ int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, co
     IntraArgs<T> a;
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.rec[i] = rec.p[i].pl; }
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
-    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0;
+    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0; a.ip = nullptr;
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows));
     CK(hipDeviceSynchronize());
@@ -449,9 +474,22 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.centers = centers ? dcen.as<int16_t>() : nullptr; a.me = dme.as<int32_t>();
     a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>();
     a.est = dest.as<unsigned long long>(); a.sparse_coef = 0;
+    DevBuf dip, diargs;
+    a.ip = nullptr;
+    if (a.prm.intra_in_p) { CK(dip.alloc((size_t)n_ctu * sizeof(IpInfo))); CK(hipMemset(dip.p, 0, (size_t)n_ctu * sizeof(IpInfo))); a.ip = dip.as<IpInfo>(); }
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
     CK(launch_inter_ctu<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
+    if (a.prm.intra_in_p) {       // intra second pass on the same reconstruction / records / levels
+        IntraArgs<T> ia;
+        for (int i = 0; i < 3; i++) { ia.src[i] = a.src[i]; ia.rec[i] = a.rec[i]; ia.coef[i] = a.coef[i]; }
+        ia.w = w; ia.h = h; ia.ctus_w = ctus_w; ia.ctus_h = (h + CTU - 1) / CTU;
+        ia.prm = a.prm; ia.prm.tile_cols = ia.prm.tile_rows = 1;
+        ia.cu = a.cu; ia.diagonal = 0; ia.est = a.est; ia.sparse_coef = 0; ia.ip = a.ip;
+        CK(diargs.alloc(sizeof ia));
+        CK(hipMemcpy(diargs.p, &ia, sizeof ia, hipMemcpyHostToDevice));
+        CK(launch_intra_p<T>(0, diargs.as<IntraArgs<T>>(), n_ctu, 1));
+    }
     CK(hipDeviceSynchronize());
     if (int e = rec.download(ry, ru, rv)) return e;
     CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));

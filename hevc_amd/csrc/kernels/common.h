@@ -51,6 +51,13 @@ struct CostParams {
     int qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
     int tile_cols, tile_rows;     // intra pictures: uniform tile grid (6.5.1), 1x1 = no tiles
     int intra_nxn;                // 1: 8x8 intra CUs are also tried as four 4x4 PUs (NxN, DST-VII luma TUs)
+    int intra_in_p;               // 1: P pictures run the intra second pass (kernels/intra.h intra_p_eligible)
+};
+// per-CTU hand-over from the inter pass of a P picture to its intra second pass
+struct IpInfo {
+    unsigned long long jinter;    // J of the inter version: SSE << 4 + lambda * estimated bits
+    unsigned est;                 // the inter version's share of the picture's rate estimate (1/16 bit)
+    unsigned cand;                // 1: the inter cost exceeds the source's own activity -> try intra
 };
 // uniform tile spacing (6.5.1): first CTB of tile i of n over n_ctb CTBs, and the tile holding a CTB
 HDI int tile_bd(int i, int n, int n_ctb) { return i * n_ctb / n; }
@@ -366,6 +373,31 @@ DEV int hadamard8_satd(int (&m)[8][8])
     return (s + 2) >> 2;
 }
 
+// the same transform of a source tile with the DC term left out of the sum: its activity around its own mean
+DEV int hadamard8_ac(int (&m)[8][8])
+{
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[y][i], q = m[y][i + st]; m[y][i] = p + q; m[y][i + st] = p - q; }
+    }
+    int s = 0;
+#pragma unroll
+    for (int x = 0; x < 8; x++) {
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[i][x], q = m[i + st][x]; m[i][x] = p + q; m[i + st][x] = p - q; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (x || i) s += iabs(m[i][x]);
+    }
+    return (s + 2) >> 2;
+}
+
 // ------------------------------------------------------------------------------------------ executors
 #if MIHEVC_GPU
 struct GpuExec {
@@ -394,6 +426,7 @@ struct GpuExec {
     }
     DEV void atomic_add(int *p, int v) { atomicAdd(p, v); }
     DEV void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
+    DEV void atomic_add(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
     DEV void atomic_or(unsigned *p, unsigned v) { atomicOr(p, v); }
     DEV void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
     DEV void atomic_add_global(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
@@ -410,6 +443,7 @@ struct SeqExec {      // sequential stepping of a phase program (tests/emu)
     }
     void atomic_add(int *p, int v) { *p += v; }
     void atomic_add(unsigned *p, unsigned v) { *p += v; }
+    void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }
     void atomic_or(unsigned *p, unsigned v) { *p |= v; }
     void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
     void atomic_add_global(unsigned long long *p, unsigned long long v) { *p += v; }

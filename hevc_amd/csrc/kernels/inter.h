@@ -29,6 +29,7 @@ template <typename T> struct InterArgs {
     unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit), see DESIGN.md rate control
     int sparse_coef;             // 1: store levels only for TUs that have a non-zero one (the host coder never reads the others);
                                  //    lets `coef` point at pinned host memory so no 6 MB/picture D2H blit is needed
+    IpInfo *ip;                  // per CTU, or nullptr: hand-over to the intra second pass (prm.intra_in_p)
 };
 
 // candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
@@ -197,6 +198,8 @@ template <typename T> struct InterShared {
     uint8_t tile_node[16];
     uint8_t chosen[21];          // node is a CU of the decided quadtree
     unsigned est;                // CTU rate estimate, 1/16 bit
+    unsigned ip_cost, ip_act, ip_tiles;   // intra second pass: chosen CUs' cost, source AC activity, tiles inside the picture
+    unsigned long long ip_sse;
     // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
 };
 // motion-compensation windows cover every vector the search can return: |mv| <= R + 3 (widened horizontal span)
@@ -495,7 +498,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     // quadtree decision
     ex.phase([&](int tid) {
         if (tid != 0) return;
-        s.est = 0;
+        s.est = 0; s.ip_cost = 0; s.ip_act = 0; s.ip_tiles = 0; s.ip_sse = 0;
         unsigned J[21];
         for (int n = 0; n < 21; n++) J[n] = s.valid[n] ? s.cost[n] + (unsigned)(lam * 4) : 0;
         int use16[4], use32;
@@ -555,7 +558,25 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     }
     ex.phase([&](int tid) {
         if (tid < 16) { s.tile_mvx[tid] = s.mvx[s.tile_node[tid]]; s.tile_mvy[tid] = s.mvy[s.tile_node[tid]]; }
+        if (a.ip) {
+            if (tid >= 64 && tid < 85 && s.valid[tid - 64] && s.chosen[tid - 64]) ex.atomic_add(&s.ip_cost, s.cost[tid - 64]);
+            if (tid >= 128 && tid < 144 && s.rs.tu_log2[tid - 128]) ex.atomic_add(&s.ip_tiles, 1u);
+        }
     });
+    // intra second-pass candidate (oracle: orc_analyze_inter_frame): the inter cost is above 4 per sample AND above the source's
+    // own AC activity (8x8 Hadamard without the DC term).  The activity is only computed when the first test passes.
+    if (a.ip && s.ip_cost >= ((4u * 64u * s.ip_tiles) << 4)) {
+        ex.phase([&](int tid) {
+            if (tid >= 16 || !s.rs.tu_log2[tid]) return;
+            const T *sp = s.src + (tid >> 2) * 8 * 32 + (tid & 3) * 8;
+            int m[8][8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) m[j][i] = (int)sp[j * 32 + i];
+            ex.atomic_add(&s.ip_act, (unsigned)hadamard8_ac(m));
+        });
+    }
     // motion compensation of the chosen CUs: every lane predicts 4 luma samples and 2 chroma samples
     ex.phase([&](int tid) {
         {
@@ -591,10 +612,16 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
 #pragma unroll
             for (int j = 0; j < 4; j++) v[j] = clip3(0, maxv, (int)s.pred[i + j] + s.rs.res[i + j]);
             store4(a.rec[l.plane].p + (ptrdiff_t)gy * a.rec[l.plane].stride + gx, v[0], v[1], v[2], v[3]);
+            if (a.ip) {
+                unsigned sse = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int d = (int)s.src[i + j] - v[j]; sse += (unsigned)(d * d); }
+                if (sse) ex.atomic_add(&s.ip_sse, (unsigned long long)sse);
+            }
             if (!a.sparse_coef || ((s.rs.cbf[l.plane] >> l.tile0) & 1))
                 store4(a.coef[l.plane] + (size_t)gy * (l.plane ? a.w >> 1 : a.w) + gx, s.rs.lvl[i], s.rs.lvl[i + 1], s.rs.lvl[i + 2], s.rs.lvl[i + 3]);
         }
-        if (a.est) {       // rate estimate: coefficient sub-block costs + a header per CU (oracle: inter estimate)
+        if (a.est || a.ip) {       // rate estimate: coefficient sub-block costs + a header per CU (oracle: inter estimate)
             unsigned e = 0;
             for (int sb = tid; sb < 96; sb += NT) {
                 int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
@@ -623,7 +650,17 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             a.cu[(size_t)((y0 >> 3) + typ) * (a.w >> 3) + (x0 >> 3) + txp] = r;
         }
     });
-    if (a.est) ex.phase([&](int tid) { if (tid == 0 && s.est) ex.atomic_add_global(a.est, s.est); });
+    if (a.est || a.ip) ex.phase([&](int tid) {
+        if (tid != 0) return;
+        if (a.est && s.est) ex.atomic_add_global(a.est, s.est);
+        if (a.ip) {
+            IpInfo o;
+            o.jinter = (s.ip_sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)s.est) >> 4);
+            o.est = s.est;
+            o.cand = s.ip_cost > (s.ip_act << 4) && s.ip_cost >= ((4u * 64u * s.ip_tiles) << 4);
+            a.ip[ctu] = o;
+        }
+    });
 }
 
 }  // namespace mihevc

@@ -25,7 +25,27 @@ template <typename T> struct IntraArgs {
     int diagonal;                // informational: the launch passes the diagonal as a kernel argument
     unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit)
     int sparse_coef;             // 1: store levels only for TUs with a non-zero level (see InterArgs)
+    const IpInfo *ip;            // P pictures' intra second pass: per-CTU hand-over from the inter pass; nullptr in I pictures
 };
+
+// Second pass of a P picture (oracle: intra_in_p_pass).  Candidates may only run together when the CTUs they predict from are
+// settled: round 0 takes candidates none of whose four causal neighbours (left, top-left, top, top-right) is a candidate,
+// round 1 those whose candidate neighbours all ran in round 0.  Pure functions of the candidate map, so a round is one launch.
+DEV bool ip_cand_at(const IpInfo *ip, int ctus_w, int ctus_h, int cx, int cy) { return cx >= 0 && cy >= 0 && cx < ctus_w && cy < ctus_h && ip[cy * ctus_w + cx].cand; }
+DEV bool ip_eligible_a(const IpInfo *ip, int ctus_w, int ctus_h, int cx, int cy)
+{
+    return ip_cand_at(ip, ctus_w, ctus_h, cx, cy) && !ip_cand_at(ip, ctus_w, ctus_h, cx - 1, cy) && !ip_cand_at(ip, ctus_w, ctus_h, cx - 1, cy - 1) &&
+           !ip_cand_at(ip, ctus_w, ctus_h, cx, cy - 1) && !ip_cand_at(ip, ctus_w, ctus_h, cx + 1, cy - 1);
+}
+DEV bool ip_eligible(const IpInfo *ip, int ctus_w, int ctus_h, int cx, int cy, int round)
+{
+    if (round == 0) return ip_eligible_a(ip, ctus_w, ctus_h, cx, cy);
+    if (!ip_cand_at(ip, ctus_w, ctus_h, cx, cy) || ip_eligible_a(ip, ctus_w, ctus_h, cx, cy)) return false;
+    const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    for (int k = 0; k < 4; k++)
+        if (ip_cand_at(ip, ctus_w, ctus_h, cx + nb[k][0], cy + nb[k][1]) && !ip_eligible_a(ip, ctus_w, ctus_h, cx + nb[k][0], cy + nb[k][1])) return false;
+    return true;
+}
 
 constexpr int RY_STRIDE = 68;    // LDS luma neighbourhood: rows -1..31, cols -1..63 (+ pad)
 constexpr int RC_STRIDE = 36;    // chroma: rows -1..15, cols -1..31
@@ -702,12 +722,16 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
         if (jwhole <= jsplit) j16[q] = jwhole;
         else { intra_save_restore(ex, s, qx, qy, 16, 1); j16[q] = jsplit; }
     }
+    unsigned long long jctu = lam_split + j16[0] + j16[1] + j16[2] + j16[3];
     if (x0 + 32 <= a.w && y0 + 32 <= a.h) {
-        const unsigned long long jsplit = lam_split + j16[0] + j16[1] + j16[2] + j16[3];
+        const unsigned long long jsplit = jctu;
         intra_save_restore(ex, s, 0, 0, 32, 0);
         intra_cu(ex, s, a, x0, y0, 0, 0, 5);
         if (s.j_cu + lam_split > jsplit) intra_save_restore(ex, s, 0, 0, 32, 1);
+        else jctu = s.j_cu + lam_split;
     }
+    // P picture: the intra version replaces the inter one only when it is cheaper (uniform over the workgroup)
+    if (a.ip && jctu >= a.ip[ctu_y * a.ctus_w + ctu_x].jinter) return;
     // the CTU is final: reconstruction, levels and CU records to memory
     ex.phase([&](int tid) {
         for (int i = 4 * tid; i < 1536; i += 4 * NT) {      // four samples of one row per lane, dword stores
@@ -743,7 +767,8 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             if (e) ex.atomic_add(&s.est, e);
         }
     });
-    if (a.est) ex.phase([&](int tid) { if (tid == 0 && s.est) ex.atomic_add_global(a.est, s.est); });
+    // in a P picture the CTU's inter estimate is already in the picture total: add the difference (modulo 2^64)
+    if (a.est) ex.phase([&](int tid) { if (tid == 0) ex.atomic_add_global(a.est, (unsigned long long)s.est - (a.ip ? (unsigned long long)a.ip[ctu_y * a.ctus_w + ctu_x].est : 0ull)); });
 }
 
 }  // namespace mihevc

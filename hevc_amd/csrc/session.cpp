@@ -157,6 +157,7 @@ struct mihevc_session {
         void *work_base[3], *work_p[3]; int work_stride[3];           // pre-deblock / deblocked picture (unpadded)
         void *var_base[kVariants - 1][3], *var_p[kVariants - 1][3];   // work pictures of IDR variants 1..
         int32_t *me = nullptr;
+        IpInfo *ip = nullptr;      // per CTU: inter pass -> intra second pass of P pictures
         uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
     };
     std::vector<Lane> lane;
@@ -230,6 +231,7 @@ int ensure_lanes(mihevc_session *s, int n)
         for (int v = 0; v < kVariants - 1; v++)
             if (int e = alloc_planes(s, L.var_base[v], L.var_p[v], L.work_stride, false)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
+        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         for (int k = 0; k < kRing; k++) {
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, true, (void **)&L.sym_host[k]));
@@ -325,7 +327,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto prm_for = [&](int qp) {
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
-        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0};
+        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0};
     };
     const int64_t first_index = s->frames_in - n;
     {
@@ -368,6 +370,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.sparse_coef = A.inter.sparse_coef = 1;
             A.intra.diagonal = 0;
             A.inter.centers = nullptr; A.inter.me = L.me;
+            // P pictures: the inter pass leaves per-CTU costs for the intra second pass, which runs on the same work picture,
+            // records and levels with the one-tile PPS 0 geometry
+            const bool ipass = t > 0 && s->cfg.intra_in_p;
+            A.inter.ip = ipass ? L.ip : nullptr;
+            A.intra.ip = ipass ? L.ip : nullptr;
+            if (t > 0) { A.intra.prm.tile_cols = A.intra.prm.tile_rows = 1; }
             A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
             A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
             A.sao.sse = (unsigned long long *)(sym + sl.sse);
@@ -433,6 +441,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto patch_qp = [&](int t, int g, int qp) {
         StepView<T> hv(ha, lay, t);
         hv.intra[g].prm = hv.inter[g].prm = hv.sao[g].prm = prm_for(qp);
+        if (t > 0) { hv.intra[g].prm.tile_cols = hv.intra[g].prm.tile_rows = 1; }
         std::lock_guard<std::mutex> l(s->m);
         auto &fr = s->frames[(size_t)(first_index + g * s->keyint + t)];
         fr.qp = qp; fr.type = t == 0 ? 2 : 1;
@@ -551,6 +560,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
             STAGE(1, B, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
             STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            if (s->cfg.intra_in_p) STAGE(7, B, launch_intra_p<T>(s->st_compute, dv.intra, s->n_ctu, B));
         }
         STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
         STAGE(4, B, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
@@ -844,6 +854,7 @@ void mihevc_close(mihevc_session *s)
         free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
         for (int v = 0; v < kVariants - 1; v++) free3(L.var_base[v], 0);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
+        bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
         for (int k = 0; k < kRing; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     if (s->d_args) (void)hipFree(s->d_args);

@@ -65,7 +65,10 @@ typedef struct mihevc_config {
                                        * cuts the intra CTU wavefront from W+2H to w+2h CTUs of one tile; 0: one tile */
     int32_t intra_nxn;                /* 1: 8x8 intra CUs are also tried as four 4x4 PUs (part_mode NxN, DST-VII 4x4 luma TUs).  Default 0:
                                        * on the bench clip the trial costs 2 ms per IDR picture (-15 % fps) and wins in 0.4 % of the CUs */
-    int32_t reserved[5];
+    int32_t intra_in_p;               /* 1: P pictures run an intra second pass over CTUs the reference predicts badly (two independent-set
+                                       * rounds, so isolated CTUs and the first CTUs of a blob).  Default 0: each round costs one
+                                       * serial CTU-program latency, 0.12 ms per 1080p picture, and the bench clip gains nothing from it */
+    int32_t reserved[4];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -78,7 +81,7 @@ typedef struct mihevc_stats {
     int32_t reserved[7];
     /* per-stage device time, filled when cfg.profile_stages: sum of HIP-event intervals and number of launches.
      * index: 0 intra (all anti-diagonals of a step), 1 me_search, 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
-     * 5 border pad, 6 sse, 7 unused.  One launch covers `pictures` pictures (the lock-step batch). */
+     * 5 border pad, 6 sse, 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
     double  stage_ms[8];
     int64_t stage_launches[8];
     int64_t stage_pictures[8];
@@ -118,8 +121,9 @@ typedef struct mihevc_cost_params {
     int32_t qp, qp_c, bit_depth, lambda_sad_q4, lambda_q4, me_range;
     int32_t tile_cols, tile_rows;     /* intra pictures: uniform tile grid (0/1 = one tile); see mihevc_tile_grid */
     int32_t intra_nxn;                /* 1: try part_mode NxN (four 4x4 PUs, DST-VII) for 8x8 intra CUs */
+    int32_t intra_in_p;               /* 1: mihevc_k_inter_frame also runs the intra second pass of P pictures */
 } mihevc_cost_params;
-void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, intra_nxn 0 */
+void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, intra_nxn 0, intra_in_p 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every
  * column >= 256 and every row >= 64 luma samples (A.4.1), uniform spacing; 1x1 when cfg->intra_tiles == 0. */
 int  mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows);

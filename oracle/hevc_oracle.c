@@ -515,6 +515,42 @@ static uint64_t estimate_bits(const orc_cu_rec *cu, const int16_t *coef_y, const
     return est;
 }
 
+/* the same estimate restricted to CTU (cx, cy) */
+static uint64_t estimate_bits_ctu(const orc_cu_rec *cu, const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v, int w, int h,
+                                  const int16_t *centers, int cx, int cy)
+{
+    uint64_t est = 0;
+    int w8 = w >> 3, wc = (w + ORC_CTU - 1) / ORC_CTU, ctu = cy * wc + cx;
+    int x0 = cx * ORC_CTU, y0 = cy * ORC_CTU, x1 = x0 + ORC_CTU < w ? x0 + ORC_CTU : w, y1 = y0 + ORC_CTU < h ? y0 + ORC_CTU : h;
+    for (int by = y0 >> 3; by < y1 >> 3; by++)
+        for (int bx = x0 >> 3; bx < x1 >> 3; bx++) {
+            const orc_cu_rec *r = &cu[by * w8 + bx];
+            int mask = (1 << r->log2_size) - 1;
+            if (((bx * 8) & mask) || ((by * 8) & mask)) continue;
+            if (r->flags & ORC_F_INTER) {
+                int sx = centers ? centers[2 * ctu] : 0, sy = centers ? centers[2 * ctu + 1] : 0;
+                est += 16u * (unsigned)(6 + orc_mvd_bits(r->mvx - 4 * sx) + orc_mvd_bits(r->mvy - 4 * sy));
+            } else est += 16u * 8u;
+        }
+    for (int pl = 0; pl < 3; pl++) {
+        const int16_t *c = pl == 0 ? coef_y : pl == 1 ? coef_u : coef_v;
+        int sh = pl ? 1 : 0, pw = w >> sh;
+        for (int y = y0 >> sh; y < y1 >> sh; y += 4)
+            for (int x = x0 >> sh; x < x1 >> sh; x += 4) {
+                int bits = 0, any = 0;
+                for (int j = 0; j < 4; j++)
+                    for (int i = 0; i < 4; i++) {
+                        int a = iabs(c[(y + j) * pw + x + i]);
+                        if (!a) continue;
+                        any = 1;
+                        bits += a == 1 ? 40 : a == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(a - 1));
+                    }
+                if (any) est += (unsigned)(bits + 24);
+            }
+    }
+    return est;
+}
+
 /* ================================================================================================
  * K1 + K3 : inter frame
  * ================================================================================================ */
@@ -529,6 +565,30 @@ static void node_geom(int node, int *x, int *y, int *log2n)
     *x = (q & 1) * 16 + (s & 1) * 8; *y = (q >> 1) * 16 + (s >> 1) * 8; *log2n = 3;
 }
 
+/* 8x8 Hadamard "activity" of a source tile: the SATD it would have against a flat prediction of its own mean (the DC term
+ * dropped) -- the yardstick a CTU's inter cost is held against before the intra second pass looks at it */
+static int hadamard8_ac(const pix *a, int as)
+{
+    int m[8][8];
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) m[y][x] = a[y * as + x];
+    for (int y = 0; y < 8; y++)
+        for (int st = 1; st < 8; st <<= 1)
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[y][i], q = m[y][i + st]; m[y][i] = p + q; m[y][i + st] = p - q; }
+    for (int x = 0; x < 8; x++)
+        for (int st = 1; st < 8; st <<= 1)
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[i][x], q = m[i + st][x]; m[i][x] = p + q; m[i + st][x] = p - q; }
+    int s = 0;
+    for (int y = 0; y < 8; y++)
+        for (int x = 0; x < 8; x++) if (x || y) s += iabs(m[y][x]);
+    return (s + 2) >> 2;
+}
+static void intra_in_p_pass(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride, int w, int h,
+                            const orc_params *prm, pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                            orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, const uint8_t *cand, const uint64_t *jinter);
+
 void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
                              const pix *ref_y, const pix *ref_u, const pix *ref_v, int ref_stride, int ref_cstride,
                              int w, int h, const orc_params *prm, const int16_t *centers,
@@ -540,6 +600,8 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
     const int R = prm->me_range, spany = 2 * R + 1, spanx = (spany + 3) & ~3, bd = prm->bit_depth, lam = prm->lambda_sad_q4;
     const int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU, w8 = w >> 3;
     uint32_t *sad8 = (uint32_t *)malloc(sizeof(uint32_t) * 16 * spanx * spany);
+    uint8_t *ip_cand = (uint8_t *)calloc((size_t)wc * hc, 1);
+    uint64_t *ip_jinter = (uint64_t *)calloc((size_t)wc * hc, sizeof(uint64_t));
     for (int cy = 0; cy < hc; cy++)
         for (int cx = 0; cx < wc; cx++) {
             int ctu = cy * wc + cx, x0 = cx * ORC_CTU, y0 = cy * ORC_CTU;
@@ -614,6 +676,7 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                 use32 = valid[0] && J[0] <= js;
             }
             /* --- fractional refinement of the chosen CUs with SATD: half-pel ring then quarter-pel ring --- */
+            uint32_t cost_sum = 0;
             for (int nd = 0; nd < 21; nd++) {
                 if (!valid[nd]) continue;
                 int chosen;
@@ -640,6 +703,7 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                     cbest = (uint32_t)(best >> 4);
                 }
                 mvx[nd] = cmx; mvy[nd] = cmy;
+                cost_sum += cbest;
             }
             /* --- residual coding of the chosen CUs --- */
             for (int nd = 0; nd < 21; nd++) {
@@ -673,7 +737,35 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                         r->intra_mode[0] = 1; r->chroma_mode = 1;
                     }
             }
+            if (prm->intra_in_p) {
+                /* second-pass candidate: the inter cost (SATD << 4 + lambda * mvd bits of the chosen CUs) exceeds both 4 per sample
+                 * and the source's own AC activity -- predicting every tile by its mean would have done better */
+                uint32_t act = 0, tiles = 0;
+                for (int t = 0; t < 16; t++) {
+                    int tx = x0 + (t & 3) * 8, ty = y0 + (t >> 2) * 8;
+                    if (tx + 8 > w || ty + 8 > h) continue;
+                    act += (uint32_t)hadamard8_ac(src_y + ty * src_stride + tx, src_stride);
+                    tiles++;
+                }
+                ip_cand[ctu] = cost_sum > (act << 4) && cost_sum >= ((4u * 64u * tiles) << 4);
+                /* J of the inter version in the units of the intra decision: SSE << 4 + lambda * estimated bits */
+                uint64_t sse = 0;
+                for (int pl = 0; pl < 3; pl++) {
+                    const pix *sp = pl == 0 ? src_y : pl == 1 ? src_u : src_v, *rp = pl == 0 ? rec_y : pl == 1 ? rec_u : rec_v;
+                    int ss = pl ? src_cstride : src_stride, rs = pl ? rec_cstride : rec_stride, sh = pl ? 1 : 0;
+                    int bx = x0 >> sh, by = y0 >> sh, bw = (w >> sh) - bx < (ORC_CTU >> sh) ? (w >> sh) - bx : (ORC_CTU >> sh);
+                    int bh = (h >> sh) - by < (ORC_CTU >> sh) ? (h >> sh) - by : (ORC_CTU >> sh);
+                    for (int y = 0; y < bh; y++)
+                        for (int x = 0; x < bw; x++) { int d = sp[(by + y) * ss + bx + x] - rp[(by + y) * rs + bx + x]; sse += (uint64_t)(d * d); }
+                }
+                uint64_t bits = estimate_bits_ctu(cu, coef_y, coef_u, coef_v, w, h, centers, cx, cy);
+                ip_jinter[ctu] = (sse << 4) + (((uint64_t)prm->lambda_q4 * bits) >> 4);
+            }
         }
+    if (prm->intra_in_p)
+        intra_in_p_pass(src_y, src_u, src_v, src_stride, src_cstride, w, h, prm, rec_y, rec_u, rec_v, rec_stride, rec_cstride, cu, coef_y, coef_u, coef_v,
+                        ip_cand, ip_jinter);
+    free(ip_cand); free(ip_jinter);
     free(sad8);
     if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers);
 }
@@ -877,6 +969,74 @@ static uint64_t intra_tree(intra_ctx *c, int x, int y, int log2n)
     for (int yy = 0; yy < n / 8; yy++)
         for (int xx = 0; xx < n / 8; xx++) c->cu[((y >> 3) + yy) * c->w8 + (x >> 3) + xx] = scu[yy * 4 + xx];
     return jsplit;
+}
+
+/* Intra second pass of a P picture.  The first pass coded every CTU inter; CTUs flagged in cand[] are re-coded as intra
+ * (the I-picture quadtree search, predicting from the reconstruction around them) and keep the intra version when its
+ * J is lower than the inter J.  An intra CTU predicts from its left / top-left / top / top-right neighbours, so only CTUs
+ * whose candidate neighbours are settled may run together: round A takes candidates none of whose four causal
+ * neighbours is a candidate, round B those whose candidate neighbours all ran in round A; the rest stay inter.  CTUs of a
+ * round are mutually independent -- the device runs each round as one launch. */
+static int ip_eligible_a(const uint8_t *cand, int wc, int hc, int cx, int cy)
+{
+    static const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    if (!cand[cy * wc + cx]) return 0;
+    for (int k = 0; k < 4; k++) {
+        int x = cx + nb[k][0], y = cy + nb[k][1];
+        if (x >= 0 && y >= 0 && x < wc && y < hc && cand[y * wc + x]) return 0;
+    }
+    return 1;
+}
+static int ip_eligible_b(const uint8_t *cand, int wc, int hc, int cx, int cy)
+{
+    static const int nb[4][2] = {{-1, 0}, {-1, -1}, {0, -1}, {1, -1}};
+    if (!cand[cy * wc + cx] || ip_eligible_a(cand, wc, hc, cx, cy)) return 0;
+    for (int k = 0; k < 4; k++) {
+        int x = cx + nb[k][0], y = cy + nb[k][1];
+        if (x >= 0 && y >= 0 && x < wc && y < hc && cand[y * wc + x] && !ip_eligible_a(cand, wc, hc, x, y)) return 0;
+    }
+    return 1;
+}
+static void intra_in_p_pass(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride, int w, int h,
+                            const orc_params *prm, pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                            orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, const uint8_t *cand, const uint64_t *jinter)
+{
+    orc_params ip = *prm;
+    ip.tile_cols = ip.tile_rows = 1;               /* P pictures use PPS 0: one tile */
+    intra_ctx c;
+    c.src[0] = src_y; c.src[1] = src_u; c.src[2] = src_v;
+    c.sstride[0] = src_stride; c.sstride[1] = c.sstride[2] = src_cstride;
+    c.rec[0] = rec_y; c.rec[1] = rec_u; c.rec[2] = rec_v;
+    c.rstride[0] = rec_stride; c.rstride[1] = c.rstride[2] = rec_cstride;
+    c.coef[0] = coef_y; c.coef[1] = coef_u; c.coef[2] = coef_v;
+    c.cu = cu; c.w = w; c.h = h; c.w8 = w >> 3; c.prm = &ip;
+    int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU;
+    for (int round = 0; round < 2; round++)
+        for (int cy = 0; cy < hc; cy++)
+            for (int cx = 0; cx < wc; cx++) {
+                if (!(round == 0 ? ip_eligible_a(cand, wc, hc, cx, cy) : ip_eligible_b(cand, wc, hc, cx, cy))) continue;
+                int x0 = cx * ORC_CTU, y0 = cy * ORC_CTU;
+                int bw = w - x0 < ORC_CTU ? w - x0 : ORC_CTU, bh = h - y0 < ORC_CTU ? h - y0 : ORC_CTU;
+                pix sv[3][32 * 32];
+                int16_t sc[3][32 * 32];
+                orc_cu_rec scu[16];
+                for (int ci = 0; ci < 3; ci++) {
+                    int sh = ci ? 1 : 0;
+                    region_copy(sv[ci], 32 >> sh, c.rec[ci] + (y0 >> sh) * c.rstride[ci] + (x0 >> sh), c.rstride[ci], bw >> sh, bh >> sh);
+                    region_copy16(sc[ci], 32 >> sh, c.coef[ci] + (y0 >> sh) * (w >> sh) + (x0 >> sh), w >> sh, bw >> sh, bh >> sh);
+                }
+                for (int yy = 0; yy < bh / 8; yy++)
+                    for (int xx = 0; xx < bw / 8; xx++) scu[yy * 4 + xx] = cu[((y0 >> 3) + yy) * c.w8 + (x0 >> 3) + xx];
+                uint64_t jintra = intra_tree(&c, x0, y0, ORC_CTU_LOG2);
+                if (jintra < jinter[cy * wc + cx]) continue;
+                for (int ci = 0; ci < 3; ci++) {
+                    int sh = ci ? 1 : 0;
+                    region_copy(c.rec[ci] + (y0 >> sh) * c.rstride[ci] + (x0 >> sh), c.rstride[ci], sv[ci], 32 >> sh, bw >> sh, bh >> sh);
+                    region_copy16(c.coef[ci] + (y0 >> sh) * (w >> sh) + (x0 >> sh), w >> sh, sc[ci], 32 >> sh, bw >> sh, bh >> sh);
+                }
+                for (int yy = 0; yy < bh / 8; yy++)
+                    for (int xx = 0; xx < bw / 8; xx++) cu[((y0 >> 3) + yy) * c.w8 + (x0 >> 3) + xx] = scu[yy * 4 + xx];
+            }
 }
 
 void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,

@@ -69,6 +69,7 @@ typedef struct {
     int tile_cols, tile_rows; /* intra pictures: uniform tile grid (6.5.1); 0 or 1 = one tile.  Neighbours in another tile
                                 * are unavailable for prediction (6.4.1), which is what shortens the CTU wavefront */
     int intra_nxn;            /* 1: every 8x8 intra CU is also tried as four 4x4 PUs (part_mode NxN, DST-VII luma TUs) */
+    int intra_in_p;           /* 1: P pictures get a second pass that re-codes badly predicted CTUs as intra (see orc_analyze_inter_frame) */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */

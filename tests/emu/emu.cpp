@@ -37,7 +37,7 @@ template <typename T> struct Padded {
 
 static CostParams to_prm(const mihevc_cost_params *p)
 {
-    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn};
+    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p};
 }
 
 template <typename T>
@@ -54,9 +54,12 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU;
     a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0;
     if (est) *est = 0;
+    std::vector<IpInfo> ipv;
+    a.ip = nullptr;
     int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU), R = a.prm.me_range;
     std::vector<int32_t> me((size_t)n_ctu * 63);
     a.me = me.data();
+    if (a.prm.intra_in_p) { ipv.assign((size_t)n_ctu, IpInfo{0, 0, 0}); a.ip = ipv.data(); }
     SeqExec ex;
     std::vector<T> win((size_t)me_win_elems(R) + 8);
     std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16), wu((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16), wv(wu.size());
@@ -71,6 +74,20 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
         inter_ctu_program<T>(ex, *is, wy.data(), wu.data(), wv.data(), a, c);
         delete is;
     }
+    if (a.ip) {       // intra second pass, two rounds like the device's two launches
+        IntraArgs<T> ia;
+        for (int i = 0; i < 3; i++) { ia.src[i] = a.src[i]; ia.rec[i] = a.rec[i]; ia.coef[i] = a.coef[i]; }
+        ia.w = w; ia.h = h; ia.ctus_w = a.ctus_w; ia.ctus_h = (h + CTU - 1) / CTU;
+        ia.prm = a.prm; ia.prm.tile_cols = ia.prm.tile_rows = 1;
+        ia.cu = cu; ia.diagonal = 0; ia.est = est; ia.sparse_coef = 0; ia.ip = a.ip;
+        for (int round = 0; round < 2; round++)
+            for (int c = 0; c < n_ctu; c++) {
+                if (!ip_eligible(ia.ip, ia.ctus_w, ia.ctus_h, c % ia.ctus_w, c / ia.ctus_w, round)) continue;
+                IntraShared<T> *is = new IntraShared<T>();
+                intra_ctu_program<T>(ex, *is, ia, c % ia.ctus_w, c / ia.ctus_w);
+                delete is;
+            }
+    }
     return 0;
 }
 
@@ -82,7 +99,7 @@ static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, cons
     a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU;
-    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0;
+    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0; a.ip = nullptr;
     if (est) *est = 0;
     SeqExec ex;
     // same launch order as the device: per tile, one anti-diagonal (cx + 2 cy inside the tile) at a time

@@ -11,7 +11,7 @@ from oracle import oracle as O
 from tests import util
 
 
-def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0):
+def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0, intra_in_p=0):
     lib = _lib.load()
     buf = (C.c_uint8 * (4 << 20))()
     n = lib.mihevc_write_parameter_sets(C.byref(cfg), buf, len(buf))
@@ -20,7 +20,8 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0):
     stream, recs, packets, ref = headers, [], [], None
     prm_i, prm_p = O.default_params(max(0, qp - 3), bd, me_range), O.default_params(qp, bd, me_range)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # IDR pictures are analysed for the grid PPS 1 signals
-    prm_i.intra_nxn = nxn
+    prm_i.intra_nxn = prm_p.intra_nxn = nxn
+    prm_p.intra_in_p = intra_in_p
     cus = []
     for i, src in enumerate(srcs):
         intra = i % keyint == 0
@@ -113,6 +114,40 @@ def test_intra_nxn_with_dst_decodes_to_the_oracle_reconstruction(w, h, qp, bd):
         assert f.same(r), f"picture {i} differs after decode"
     _, stream0, _, _ = encode_pictures(cfg, srcs, qp, bd, keyint=1, nxn=0)
     assert len(stream) != len(stream0)
+
+
+def occluded_clip(w, h, bd, n=3):
+    """Frame i = the texture shifted by (2i, i) with a fresh, unrelated patch pasted in: nothing in the reference predicts the patch."""
+    out = []
+    for i in range(n):
+        f = util.synth_frame(h, w, seed=41, shift=(2 * i, i), bit_depth=bd)
+        if i:
+            g = util.synth_frame(h, w, seed=900 + i, bit_depth=bd)
+            x0, y0, pw, ph = 32 * (i % 2), 32, min(w, 96), min(h - 32, 64)
+            f.y[y0:y0 + ph, x0:x0 + pw] = g.y[y0:y0 + ph, x0:x0 + pw]
+            f.u[y0 // 2:(y0 + ph) // 2, x0 // 2:(x0 + pw) // 2] = g.u[y0 // 2:(y0 + ph) // 2, x0 // 2:(x0 + pw) // 2]
+            f.v[y0 // 2:(y0 + ph) // 2, x0 // 2:(x0 + pw) // 2] = g.v[y0 // 2:(y0 + ph) // 2, x0 // 2:(x0 + pw) // 2]
+        out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("w,h,qp,bd,nxn", [(160, 128, 28, 8, 0), (136, 104, 24, 8, 1), (128, 96, 30, 10, 0)])
+def test_intra_ctus_in_p_pictures_decode_to_the_oracle_reconstruction(w, h, qp, bd, nxn):
+    # second pass of P pictures: CTUs the reference cannot predict are re-coded as intra (pred_mode_flag = 1 inside a P slice:
+    # MPM from inter neighbours = DC, no merge/AMVP candidates from intra neighbours, Bs 2 at their edges)
+    cfg = make_cfg(w, h, bd)
+    srcs = occluded_clip(w, h, bd)
+    _, stream, recs, _ = encode_pictures(cfg, srcs, qp, bd, nxn=nxn, intra_in_p=1)
+    cus = encode_pictures.last_cus
+    n_intra = [int(((cu["flags"] & 1) == 0).sum()) for cu in cus[1:]]
+    assert all(n > 0 for n in n_intra), n_intra                      # the pasted patch went intra in both P pictures
+    assert all(((cu["flags"] & 1) != 0).any() for cu in cus[1:])     # ... and the rest stayed inter
+    frames, _ = O.decode(stream)
+    for i, (f, r) in enumerate(zip(frames, recs)):
+        assert f.same(r), f"picture {i} differs after decode"
+    _, stream0, recs0, _ = encode_pictures(cfg, srcs, qp, bd, nxn=nxn, intra_in_p=0)
+    assert len(stream) < len(stream0)                                # the intra CTUs are cheaper than coding the patch as inter residual
+    assert util.psnr(recs[2].y, srcs[2].y) >= util.psnr(recs0[2].y, srcs[2].y) - 0.3
 
 
 def test_sao_off_and_skip_heavy_static_content():

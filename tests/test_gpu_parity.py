@@ -109,6 +109,25 @@ def test_intra_nxn_parity(lib, api, w, h, grid, qp, bd):
     assert util.same_analysis(want, got), util.describe_diff(want, got)
 
 
+@pytest.mark.parametrize("w,h,qp,bd,nxn", [(160, 128, 28, 8, 0), (136, 104, 24, 8, 1), (128, 96, 30, 10, 0), (640, 352, 26, 8, 0)])
+def test_intra_second_pass_of_p_pictures_parity(lib, api, w, h, qp, bd, nxn):
+    """K2 in P pictures: the inter pass hands per-CTU costs to k_intra_p, which re-codes badly predicted CTUs as intra in two
+    independent-set rounds; decisions, records, levels, reconstruction and rate estimate equal the oracle."""
+    from tests.test_bitstream_cpu import occluded_clip
+    prm, cp = lib_params(lib, qp, bd, 8)
+    prm.intra_in_p = cp.intra_in_p = 1
+    prm.intra_nxn = cp.intra_nxn = nxn
+    srcs = occluded_clip(w, h, bd)
+    a0 = O.analyze_intra(srcs[0], prm)
+    ref = O.sao(srcs[0], O.deblock(a0.rec, a0.cu, bd), prm)[0]
+    for i in (1, 2):
+        want = O.analyze_inter(srcs[i], ref, prm, dump_me=True)
+        got = api.inter(srcs[i], ref, cp)
+        assert ((want.cu["flags"] & 1) == 0).any(), "the occluded patch must go intra"
+        assert util.same_analysis(want, got), f"picture {i}: " + util.describe_diff(want, got)
+        ref = O.sao(srcs[i], O.deblock(want.rec, want.cu, bd), prm)[0]
+
+
 def test_search_centres(lib, api):
     w, h = 96, 64
     prm, cp = lib_params(lib, 26, 8, 8)
@@ -140,17 +159,24 @@ def _encode(cfg, frames, keep=True):
         return out, recs, st, enc.coded_size()
 
 
-@pytest.mark.parametrize("w,h,bd,keyint,n,nxn", [(96, 80, 8, 4, 10, 0), (132, 76, 8, 5, 7, 1), (64, 64, 10, 3, 7, 1), (544, 160, 8, 3, 7, 0), (544, 160, 8, 3, 4, 1)])
-def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint, n, nxn):
+@pytest.mark.parametrize("w,h,bd,keyint,n,nxn,ipass", [(96, 80, 8, 4, 10, 0, 0), (132, 76, 8, 5, 7, 1, 1), (64, 64, 10, 3, 7, 1, 0), (544, 160, 8, 3, 7, 0, 1),
+                                                         (544, 160, 8, 3, 4, 1, 0)])
+def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint, n, nxn, ipass):
     """End to end: session -> Annex-B -> oracle decoder must equal the encoder's own reconstruction AND the oracle
     pipeline run with the same QPs; includes non-multiple-of-8 sizes (conformance window) and a short last GOP."""
     from hevc_amd import _lib
     cfg = _lib.default_config()
     cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint = w, h, bd, keyint, 2
-    cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud, cfg.intra_nxn = 27, 8, 2, 1, nxn
+    cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud, cfg.intra_nxn, cfg.intra_in_p = 27, 8, 2, 1, nxn, ipass
     if bd == 10:
         cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers = 1, 9, 16, 9, 0, 1
     frames = [util.synth_frame(h, w, seed=9, shift=(i, i // 2), bit_depth=bd) for i in range(n)]
+    if ipass:          # paste an unrelated patch into every second picture so the intra second pass has work
+        for i in range(1, n, 2):
+            g = util.synth_frame(h, w, seed=500 + i, bit_depth=bd)
+            frames[i].y[32:64, 32:96] = g.y[32:64, 32:96]
+            frames[i].u[16:32, 16:48] = g.u[16:32, 16:48]
+            frames[i].v[16:32, 16:48] = g.v[16:32, 16:48]
     stream, recs, st, (cw, ch) = _encode(cfg, frames)
     assert st.frames_out == n and cw % 8 == 0 and ch % 8 == 0
     dec, info = O.decode(stream)
@@ -161,7 +187,8 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_i, _ = lib_params(lib, qp_i, bd, 8)
     prm_p, _ = lib_params(lib, qp_p, bd, 8)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
-    prm_i.intra_nxn = cfg.intra_nxn                              # NxN trial in IDR pictures when the session asks for it
+    prm_i.intra_nxn = prm_p.intra_nxn = cfg.intra_nxn            # NxN trial when the session asks for it
+    prm_p.intra_in_p = cfg.intra_in_p                            # default 1: intra second pass in P pictures
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     ref = None
     for i, f in enumerate(frames):
@@ -212,7 +239,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     ref = None
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
-        prm.intra_nxn = cfg.intra_nxn
+        prm.intra_nxn, prm.intra_in_p = cfg.intra_nxn, cfg.intra_in_p
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"

@@ -80,6 +80,22 @@ def test_stepped_intra_nxn(emu, w, h, grid, qp, bd):
     assert util.same_analysis(want, got), util.describe_diff(want, got)
 
 
+@pytest.mark.parametrize("w,h,qp,bd,nxn", [(160, 128, 28, 8, 0), (136, 104, 24, 8, 1), (128, 96, 30, 10, 0)])
+def test_stepped_intra_second_pass_of_p_pictures(emu, w, h, qp, bd, nxn):
+    """P pictures: CTUs the reference cannot predict are re-coded as intra in two independent-set rounds, exactly as the oracle."""
+    from tests.test_bitstream_cpu import occluded_clip
+    prm = O.default_params(qp, bit_depth=bd, me_range=8)
+    prm.intra_in_p, prm.intra_nxn = 1, nxn
+    srcs = occluded_clip(w, h, bd)
+    ref = O.sao(srcs[0], O.deblock(*(lambda a: (a.rec, a.cu))(O.analyze_intra(srcs[0], prm)), bd), prm)[0]
+    for i in (1, 2):
+        want = O.analyze_inter(srcs[i], ref, prm, dump_me=True)
+        got = emu.inter(srcs[i], ref, prm)
+        assert ((want.cu["flags"] & 1) == 0).any(), "the occluded patch must go intra"
+        assert util.same_analysis(want, got), f"picture {i}: " + util.describe_diff(want, got)
+        ref = O.sao(srcs[i], O.deblock(want.rec, want.cu, bd), prm)[0]
+
+
 def test_search_centres_are_honoured(emu):
     w, h, bd = 96, 64, 8
     prm = O.default_params(26, me_range=8)
