@@ -293,3 +293,34 @@ def test_convert_video_end_to_end_on_the_gpu(tmp_path):
     (tmp_path / "x").mkdir()
     res = T.convert_video(inp, tmp_path / "x", skip_validator=True, stop_event=ev)
     assert res["status"] == "CANCELLED"
+
+
+@pytest.mark.parametrize("w,h,bd,keyint,lanes,n", [(16, 16, 8, 3, 4, 5), (24, 40, 8, 1, 2, 3), (48, 32, 10, 90, 1, 4), (322, 182, 8, 2, 3, 7), (64, 64, 8, 4, 4, 1)])
+def test_session_edge_geometries(lib, w, h, bd, keyint, lanes, n):
+    """Smallest picture, sizes off the 8 grid in both directions, all-IDR (keyint 1), a GOP longer than the clip, a single frame:
+    the stream decodes to the encoder reconstruction and the conformance window restores the display size."""
+    from hevc_amd import _lib
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight = w, h, bd, keyint, 1, lanes
+    cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits, cfg.me_range = 22, -1, 300, 360, 8
+    cw, ch = (w + 7) & ~7, (h + 7) & ~7
+    frames = [util.synth_frame(ch, cw, seed=77, shift=(i, i), bit_depth=bd, detail=min(cw, ch) >= 64) for i in range(n)]
+    for f in frames:                       # hand over the display-size part only
+        f.y, f.u, f.v = f.y[:h, :w].copy(), f.u[:h // 2, :w // 2].copy(), f.v[:h // 2, :w // 2].copy()
+    stream, recs, st, (gw, gh) = _encode(cfg, frames)
+    assert (gw, gh) == (cw, ch) and st.frames_out == n
+    dec, info = O.decode(stream)
+    assert len(dec) == n and (info["conf_width"], info["conf_height"]) == (w, h)
+    for i in range(n):
+        assert dec[i].same(O.Frame(*recs[i])), f"frame {i}"
+
+
+def test_flush_without_frames_and_reuse_after_flush(lib):
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.keyint = 64, 64, 4
+    with Encoder(cfg, device=0) as enc:
+        enc.flush()
+        assert list(enc.packets()) == []
+        assert enc.stats().frames_out == 0
