@@ -23,7 +23,7 @@ class Config(C.Structure):
         "aud", "repeat_headers", "hdr10")] +
         [("md_primaries", (C.c_uint16 * 2) * 3), ("md_white", C.c_uint16 * 2), ("md_max_lum", C.c_uint32), ("md_min_lum", C.c_uint32),
          ("max_cll", C.c_uint16), ("max_fall", C.c_uint16)] +
-        [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages", "intra_tiles", "intra_nxn", "intra_in_p")] + [("reserved", C.c_int32 * 4)])
+        [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages", "intra_tiles", "intra_nxn", "intra_in_p", "hrd")] + [("reserved", C.c_int32 * 3)])
 
 
 class Stats(C.Structure):

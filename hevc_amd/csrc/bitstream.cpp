@@ -176,7 +176,24 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
         w.put((uint32_t)c.fps_den, 32);
         w.put((uint32_t)c.fps_num, 32);
         w.put1(0);        // vui_poc_proportional_to_timing_flag
-        w.put1(0);        // vui_hrd_parameters_present_flag (HRD/buffering SEI: not emitted yet)
+        const HrdInfo hi = hrd_info(c);
+        w.put1(hi.on);    // vui_hrd_parameters_present_flag
+        if (hi.on) {      // E.2.2 hrd_parameters(1, 0)
+            w.put1(1);            // nal_hrd_parameters_present_flag
+            w.put1(0);            // vcl_hrd_parameters_present_flag
+            w.put1(0);            // sub_pic_hrd_params_present_flag
+            w.put(0, 4);          // bit_rate_scale: 64 bit/s units
+            w.put(0, 4);          // cpb_size_scale: 16 bit units
+            w.put(23, 5);         // initial_cpb_removal_delay_length_minus1
+            w.put(23, 5);         // au_cpb_removal_delay_length_minus1
+            w.put(4, 5);          // dpb_output_delay_length_minus1
+            w.put1(1);            // fixed_pic_rate_general_flag (within_cvs inferred 1)
+            w.ue(0);              // elemental_duration_in_tc_minus1
+            w.ue(0);              // cpb_cnt_minus1 (low_delay_hrd_flag inferred 0)
+            w.ue(hi.bit_rate_value_minus1);
+            w.ue(hi.cpb_size_value_minus1);
+            w.put1(0);            // cbr_flag
+        }
         w.put1(0);        // bitstream_restriction_flag
     }
     w.put1(0);            // sps_extension_present_flag
@@ -271,6 +288,55 @@ void write_sei_hdr10(const mihevc_config &c, std::vector<uint8_t> &out)
         w.trailing();
         append_nal(out, 39, w.bytes());
     }
+}
+
+HrdInfo hrd_info(const mihevc_config &c)
+{
+    HrdInfo h{};
+    h.on = c.hrd && c.vbv_maxrate_kbps > 0 && c.vbv_bufsize_kbits > 0;
+    if (!h.on) return h;
+    const uint64_t rate = (uint64_t)c.vbv_maxrate_kbps * 1000, cpb = (uint64_t)c.vbv_bufsize_kbits * 1000;
+    h.bit_rate_value_minus1 = (uint32_t)(rate / 64 - 1);
+    h.cpb_size_value_minus1 = (uint32_t)(cpb / 16 - 1);
+    const uint64_t full = 90000ull * (((uint64_t)h.cpb_size_value_minus1 + 1) * 16) / (((uint64_t)h.bit_rate_value_minus1 + 1) * 64);   // CPB in 90 kHz ticks
+    h.initial_delay = (uint32_t)(full * 9 / 10);
+    h.initial_offset = (uint32_t)(full - h.initial_delay);
+    return h;
+}
+
+static void append_sei(int payload_type, BitWriter &body, std::vector<uint8_t> &out)
+{
+    // sei_payload: data, then payload_bit_equal_to_one + zero bits when the data is not byte aligned (D.2.1)
+    if (!body.aligned()) { body.put1(1); body.align_zero(); }
+    BitWriter w;
+    w.put((uint32_t)payload_type, 8);
+    w.put((uint32_t)body.bytes().size(), 8);
+    w.append_bytes(body.bytes().data(), body.bytes().size());
+    w.trailing();
+    append_nal(out, 39, w.bytes());
+}
+
+void write_sei_buffering_period(const mihevc_config &c, std::vector<uint8_t> &out)
+{
+    const HrdInfo hi = hrd_info(c);
+    if (!hi.on) return;
+    BitWriter b;
+    b.ue(0);                      // bp_seq_parameter_set_id
+    b.put1(0);                    // irap_cpb_params_present_flag
+    b.put1(0);                    // concatenation_flag
+    b.put(0, 24);                 // au_cpb_removal_delay_delta_minus1
+    b.put(hi.initial_delay, 24);  // nal_initial_cpb_removal_delay[0]
+    b.put(hi.initial_offset, 24); // nal_initial_cpb_removal_offset[0]
+    append_sei(0, b, out);
+}
+
+void write_sei_pic_timing(const mihevc_config &c, uint32_t au_cpb_removal_delay_minus1, std::vector<uint8_t> &out)
+{
+    if (!hrd_info(c).on) return;
+    BitWriter b;                  // frame_field_info_present_flag = 0: only the CPB / DPB delays
+    b.put(au_cpb_removal_delay_minus1 & 0xffffffu, 24);
+    b.put(0, 5);                  // pic_dpb_output_delay: no reordering
+    append_sei(1, b, out);
 }
 
 void write_aud(int slice_type, std::vector<uint8_t> &out)
@@ -926,9 +992,9 @@ private:
 
 }  // namespace
 
-size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out)
+size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out, bool with_aud)
 {
-    if (cfg.aud) write_aud(pic.slice_type, out);
+    if (cfg.aud && with_aud) write_aud(pic.slice_type, out);
     // slice_segment_header (7.3.6.1)
     BitWriter w;
     bool idr = pic.slice_type == 2;

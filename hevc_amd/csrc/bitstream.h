@@ -70,6 +70,15 @@ struct TileGrid {
 TileGrid tile_grid(const mihevc_config &cfg);
 void write_sei_hdr10(const mihevc_config &cfg, std::vector<uint8_t> &out);
 void write_aud(int slice_type, std::vector<uint8_t> &out);
+// HRD signalling (cfg.hrd with a VBV): E.2.2 hrd_parameters in the VUI; D.2.2 buffering period at IRAP pictures, D.2.3 picture timing
+struct HrdInfo {
+    bool on;
+    uint32_t bit_rate_value_minus1, cpb_size_value_minus1;   // scales 0: units of 64 bit/s and 16 bits
+    uint32_t initial_delay, initial_offset;                  // 90 kHz: 0.9 x CPB fullness at the first removal, and the rest of the CPB
+};
+HrdInfo hrd_info(const mihevc_config &cfg);
+void write_sei_buffering_period(const mihevc_config &cfg, std::vector<uint8_t> &out);
+void write_sei_pic_timing(const mihevc_config &cfg, uint32_t au_cpb_removal_delay_minus1, std::vector<uint8_t> &out);
 void write_parameter_sets(const mihevc_config &cfg, std::vector<uint8_t> &out);
 
 // One picture's symbols (pointers into pinned host copies of the device outputs).
@@ -83,6 +92,8 @@ struct PictureSyms {
 };
 
 // CABAC-code the picture into one slice-segment NAL appended to out; returns the number of bins coded (stats).
-size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out);
+// with_aud: prepend the access unit delimiter when cfg.aud (callers that put parameter sets / SEI into the same access unit write
+// the AUD themselves, it must come first: 7.4.2.4.4)
+size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out, bool with_aud = true);
 
 }  // namespace mihevc

@@ -281,8 +281,15 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
     pic.sao = s->cfg.sao ? (const mihevc_sao_ctu *)(b + sl.sao) : nullptr;
     Packet pk;
     pk.pts = pts; pk.key = slice_type == 2;
-    if (slice_type == 2 && (first_of_stream || s->cfg.repeat_headers)) pk.data = s->headers;
-    encode_picture(s->cfg, pic, pk.data);
+    // access unit: AUD first (7.4.2.4.4), parameter sets (+ HDR10 SEI), buffering period at the IDR, picture timing, the slice
+    if (s->cfg.aud) write_aud(slice_type, pk.data);
+    if (slice_type == 2 && (first_of_stream || s->cfg.repeat_headers)) pk.data.insert(pk.data.end(), s->headers.begin(), s->headers.end());
+    if (s->cfg.hrd) {
+        if (slice_type == 2) write_sei_buffering_period(s->cfg, pk.data);
+        // clock ticks since the previous buffering period: position in the GOP, or the previous GOP's length at an IDR
+        write_sei_pic_timing(s->cfg, (uint32_t)(poc > 0 ? poc - 1 : (index > 0 ? s->keyint - 1 : 0)), pk.data);
+    }
+    encode_picture(s->cfg, pic, pk.data, false);
     const unsigned long long *sse = (const unsigned long long *)(b + sl.sse);
     pk.ready = true;
     auto t1 = std::chrono::steady_clock::now();

@@ -46,7 +46,7 @@ def config_for(info: VideoInfo, crf: int, vbv_maxrate: int, vbv_bufsize: int, go
     cfg.keyint, cfg.min_keyint = int(gop), max(2, int(gop) // 2)
     if hdr:   # the HDR10 set of core/utils.py:58-69
         cfg.colour_primaries, cfg.transfer, cfg.matrix = 9, 16, 9
-        cfg.chroma_loc, cfg.aud, cfg.repeat_headers, cfg.hdr10 = 0, 1, 1, 1
+        cfg.chroma_loc, cfg.aud, cfg.repeat_headers, cfg.hdr10, cfg.hrd = 0, 1, 1, 1, 1       # ... hrd=1:aud=1:chromaloc=0:repeat-headers=1
         md = parse_master_display(master_display or info.master_display)
         for i, (x, y) in enumerate((md.g, md.b, md.r)):
             cfg.md_primaries[i][0], cfg.md_primaries[i][1] = x, y

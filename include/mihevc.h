@@ -68,7 +68,9 @@ typedef struct mihevc_config {
     int32_t intra_in_p;               /* 1: P pictures run an intra second pass over CTUs the reference predicts badly (two independent-set
                                        * rounds, so isolated CTUs and the first CTUs of a blob).  Default 0: each round costs one
                                        * serial CTU-program latency, 0.12 ms per 1080p picture, and the bench clip gains nothing from it */
-    int32_t reserved[4];
+    int32_t hrd;                      /* 1: HRD parameters in the VUI + buffering-period SEI at every IDR + picture-timing SEI per picture
+                                       * (x265 hrd=1, part of the reference's HDR10 set, core/utils.py:66); needs vbv_maxrate/bufsize */
+    int32_t reserved[3];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;

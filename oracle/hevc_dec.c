@@ -176,6 +176,7 @@ struct orc_decoder {
     int init_qp, sign_hiding, cu_qp_delta, cb_off, cr_off, lf_across, dbk_control, dbk_override_en, pps_dbk_disabled,
         cabac_init_present, par_mrg_level, transform_skip;
     int tiles, tile_cols, tile_rows, lf_across_tiles, col_bd[22], row_bd[24];
+    int hrd_nal, hrd_init_len, hrd_au_len, hrd_dpb_len;     /* E.2.2, for the buffering period / picture timing SEI */
     struct pps_copy { int valid, v[12], tiles, tile_cols, tile_rows, lf_across_tiles, col_bd[22], row_bd[24]; } pps[4];
     /* pictures */
     picture *pics; int n_pics, cap_pics;
@@ -302,9 +303,11 @@ static int parse_hrd(orc_decoder *d, bitrd *b)
         if (subpic) { set_err(d, "hrd: sub-pic"); return -1; }
         put_kv(d, "hrd.bit_rate_scale", br_u(b, 4));
         put_kv(d, "hrd.cpb_size_scale", br_u(b, 4));
-        put_kv(d, "hrd.initial_cpb_removal_delay_length_minus1", br_u(b, 5));
-        put_kv(d, "hrd.au_cpb_removal_delay_length_minus1", br_u(b, 5));
-        put_kv(d, "hrd.dpb_output_delay_length_minus1", br_u(b, 5));
+        d->hrd_nal = nal;
+        d->hrd_init_len = 1 + (int)br_u(b, 5); d->hrd_au_len = 1 + (int)br_u(b, 5); d->hrd_dpb_len = 1 + (int)br_u(b, 5);
+        put_kv(d, "hrd.initial_cpb_removal_delay_length_minus1", d->hrd_init_len - 1);
+        put_kv(d, "hrd.au_cpb_removal_delay_length_minus1", d->hrd_au_len - 1);
+        put_kv(d, "hrd.dpb_output_delay_length_minus1", d->hrd_dpb_len - 1);
     }
     int fixed_general = br_bit(b), fixed_cvs = 1, low_delay = 0, cpb_cnt = 0;
     if (!fixed_general) fixed_cvs = br_bit(b);
@@ -512,7 +515,23 @@ static int parse_sei(orc_decoder *d, bitrd *b)
             put_kv(d, "sei.mdcv.max_lum", br_u(b, 32)); put_kv(d, "sei.mdcv.min_lum", br_u(b, 32));
         } else if (type == 144 && size == 4) {
             put_kv(d, "sei.cll.max_cll", br_u(b, 16)); put_kv(d, "sei.cll.max_fall", br_u(b, 16));
+        } else if (type == 0) {           /* D.2.2 buffering period (needs the SPS's HRD lengths) */
+            if (!d->hrd_nal) { set_err(d, "buffering period SEI without NAL HRD parameters"); return -1; }
+            if (br_ue(b)) { set_err(d, "bp: sps id"); return -1; }
+            int irap = br_bit(b);
+            if (irap) { br_u(b, d->hrd_au_len); br_u(b, d->hrd_dpb_len); }
+            put_kv(d, "sei.bp.concatenation", br_bit(b));
+            br_u(b, d->hrd_au_len);
+            put_kv(d, "sei.bp.initial_delay", br_u(b, d->hrd_init_len));
+            put_kv(d, "sei.bp.initial_offset", br_u(b, d->hrd_init_len));
+            long long n_bp = 0; orc_dec_query(d, "count.sei_bp", &n_bp); put_kv(d, "count.sei_bp", n_bp + 1);
+        } else if (type == 1) {           /* D.2.3 picture timing, frame_field_info_present_flag = 0 */
+            if (!d->hrd_nal) { set_err(d, "picture timing SEI without HRD parameters"); return -1; }
+            put_kv(d, "sei.pt.au_cpb_removal_delay_minus1", br_u(b, d->hrd_au_len));
+            put_kv(d, "sei.pt.dpb_output_delay", br_u(b, d->hrd_dpb_len));
+            long long n_pt = 0; orc_dec_query(d, "count.sei_pt", &n_pt); put_kv(d, "count.sei_pt", n_pt + 1);
         }
+        if (b->pos > end) { set_err(d, "sei %d: payload overrun", type); return -1; }
         b->pos = end;
     }
     if (!br_trailing_ok(b) || b->err) { set_err(d, "sei: trailing bits"); return -1; }
@@ -1156,7 +1175,7 @@ done:
 int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
 {
     size_t i = 0;
-    int n_aud = 0, n_slices = 0;
+    int n_aud = 0, n_slices = 0, au_open = 0;
     uint8_t *rbsp = (uint8_t *)malloc(size + 8);
     while (i + 3 < size) {
         /* find start code */
@@ -1183,6 +1202,9 @@ int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
         }
         bitrd b = {rbsp, m, 0, 0};
         int rc = 0;
+        /* 7.4.2.4.4: an access unit delimiter, when present, is the first NAL unit of its access unit (one slice per picture here) */
+        if (type == 35 && au_open) { set_err(d, "access unit delimiter is not the first NAL unit of its access unit"); break; }
+        au_open = !(type == 1 || type == 19 || type == 20);
         if (type == 32) rc = parse_vps(d, &b);
         else if (type == 33) rc = parse_sps(d, &b);
         else if (type == 34) rc = parse_pps(d, &b);

@@ -286,7 +286,8 @@ def decode(stream: bytes):
                   "vui.full_range", "vui.chroma_loc_present", "vui.chroma_loc_top", "vui.num_units_in_tick", "vui.time_scale",
                   "vui.hrd_present", "vps.num_units_in_tick", "vps.time_scale", "count.aud", "count.slices", "sei.137.size", "sei.144.size",
                   "sei.mdcv.gx", "sei.mdcv.gy", "sei.mdcv.bx", "sei.mdcv.by", "sei.mdcv.rx", "sei.mdcv.ry", "sei.mdcv.wpx", "sei.mdcv.wpy",
-                  "sei.mdcv.max_lum", "sei.mdcv.min_lum", "sei.cll.max_cll", "sei.cll.max_fall", "pps.init_qp", "pps.tile_cols", "pps.tile_rows", "slice.last_qp",
+                  "sei.mdcv.max_lum", "sei.mdcv.min_lum", "sei.cll.max_cll", "sei.cll.max_fall", "pps.init_qp", "pps.tile_cols", "pps.tile_rows", "vui.hrd_present", "hrd.bit_rate_value_minus1", "hrd.cpb_size_value_minus1", "hrd.cbr_flag",
+                  "sei.bp.initial_delay", "sei.bp.initial_offset", "count.sei_bp", "count.sei_pt", "sei.pt.au_cpb_removal_delay_minus1", "slice.last_qp",
                   "slice.max_merge", "sps.conf_right", "sps.conf_bottom", "sps.sao", "sps.amp", "sps.strong_intra", "sps.poc_bits",
                   "vps.level_idc", "hrd.bit_rate_value_minus1", "hrd.cpb_size_value_minus1", "hrd.bit_rate_scale", "hrd.cpb_size_scale"):
             info[k] = q(k)

@@ -17,7 +17,7 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0, intra_in_
     n = lib.mihevc_write_parameter_sets(C.byref(cfg), buf, len(buf))
     assert n > 0
     headers = bytes(buf[:n])
-    stream, recs, packets, ref = headers, [], [], None
+    stream, recs, packets, ref = b"", [], [], None
     prm_i, prm_p = O.default_params(max(0, qp - 3), bd, me_range), O.default_params(qp, bd, me_range)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # IDR pictures are analysed for the grid PPS 1 signals
     prm_i.intra_nxn = prm_p.intra_nxn = nxn
@@ -34,7 +34,11 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0, intra_in_
         assert n > 0, n
         packets.append((bytes(buf[:n]), i, intra))
         cus.append(a.cu)
-        stream += packets[-1][0]
+        pkt = packets[-1][0]
+        if i == 0:          # parameter sets belong to the first access unit, after its AUD when there is one (7.4.2.4.4)
+            cut = pkt.index(b"\0\0\0\1", 4) if cfg.aud else 0
+            pkt = pkt[:cut] + headers + pkt[cut:]
+        stream += pkt
         recs.append(ref)
     encode_pictures.last_cus = cus
     return headers, stream, recs, packets
@@ -191,7 +195,8 @@ def test_conformance_window_for_sizes_off_the_8_grid():
 
 def test_hdr10_signalling():
     # the HDR set of core/utils.py:58-69: bt2020 / smpte2084 / bt2020nc, chromaloc 0, aud, SEI 137 + 144 with the defaults
-    cfg = make_cfg(64, 64, 10, hdr10=1, colour_primaries=9, transfer=16, matrix=9, chroma_loc=0, aud=1, repeat_headers=1, level_idc=150)
+    cfg = make_cfg(64, 64, 10, hdr10=1, colour_primaries=9, transfer=16, matrix=9, chroma_loc=0, aud=1, repeat_headers=1, level_idc=150, hrd=1,
+                   vbv_maxrate_kbps=11760, vbv_bufsize_kbits=14112)
     cfg.fps_num, cfg.fps_den = 30000, 1001
     srcs = [util.synth_frame(64, 64, seed=4, bit_depth=10)]
     _, stream, recs, _ = encode_pictures(cfg, srcs, 24, 10)
@@ -206,6 +211,9 @@ def test_hdr10_signalling():
            (13250, 34500, 7500, 3000, 34000, 16000)
     assert (info["sei.mdcv.wpx"], info["sei.mdcv.wpy"], info["sei.mdcv.max_lum"], info["sei.mdcv.min_lum"]) == (15635, 16450, 10000000, 50)
     assert (info["sei.cll.max_cll"], info["sei.cll.max_fall"]) == (1000, 400)
+    # hrd=1: NAL HRD parameters in the VUI, bit rate in 64 bit/s units and CPB size in 16 bit units (scales 0), VBR
+    assert info["vui.hrd_present"] == 1 and info["hrd.cbr_flag"] == 0
+    assert (info["hrd.bit_rate_value_minus1"] + 1) * 64 == 11760000 and (info["hrd.cpb_size_value_minus1"] + 1) * 16 == 14112000
 
 
 def test_decoder_rejects_corruption():
@@ -258,7 +266,7 @@ def test_mp4_hvc1_container(tmp_path):
     assert off == top[2][1] and sum(sizes) == top[2][2] - top[2][1] and count == n
     ks, ke = find(["moov", "trak", "mdia", "minf", "stbl", "stss"], 0, len(data))
     assert [int.from_bytes(data[ks + 8 + 4 * i:ks + 12 + 4 * i], "big") for i in range(int.from_bytes(data[ks + 4:ks + 8], "big"))] == [1, 4]
-    annexb = headers
+    annexb = b""
     p = off
     for sz in sizes:
         q = p
@@ -267,6 +275,9 @@ def test_mp4_hvc1_container(tmp_path):
             nal = data[q + 4:q + 4 + ln]
             assert mp4.nal_type(nal) not in (32, 33, 34)
             annexb += b"\0\0\0\1" + nal
+            if q == off:            # the out-of-band parameter sets go after the first sample's AUD (it must lead its access unit)
+                assert mp4.nal_type(nal) == 35
+                annexb += headers
             q += 4 + ln
         p += sz
     frames, info = O.decode(annexb)

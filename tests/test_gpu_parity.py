@@ -169,7 +169,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint = w, h, bd, keyint, 2
     cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud, cfg.intra_nxn, cfg.intra_in_p = 27, 8, 2, 1, nxn, ipass
     if bd == 10:
-        cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers = 1, 9, 16, 9, 0, 1
+        cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers, cfg.hrd = 1, 9, 16, 9, 0, 1, 1
     frames = [util.synth_frame(h, w, seed=9, shift=(i, i // 2), bit_depth=bd) for i in range(n)]
     if ipass:          # paste an unrelated patch into every second picture so the intra second pass has work
         for i in range(1, n, 2):
@@ -205,6 +205,11 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
         assert dec[i].same(enc_rec), f"frame {i}: decoded picture != encoder reconstruction"
     if bd == 10:
         assert info["sei.mdcv.gx"] == 13250 and info["sei.cll.max_cll"] == 1000 and info["sps.profile_idc"] == 2
+        # hrd=1: a buffering period SEI at every IDR, a picture timing SEI in every access unit, AUD leading each of them
+        assert info["vui.hrd_present"] == 1 and info["count.sei_bp"] == (n + keyint - 1) // keyint and info["count.sei_pt"] == n
+        full = 90000 * cfg.vbv_bufsize_kbits // cfg.vbv_maxrate_kbps
+        assert abs(info["sei.bp.initial_delay"] - full * 9 // 10) <= 1 and abs(info["sei.bp.initial_delay"] + info["sei.bp.initial_offset"] - full) <= 1
+        assert info["sei.pt.au_cpb_removal_delay_minus1"] == (n - 1) % keyint - 1 if (n - 1) % keyint else True
 
 
 def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
