@@ -44,7 +44,15 @@ template <typename T> struct MeShared {
 };
 HDI int me_spanx(int R) { return ((2 * R + 1) + 3) & ~3; }   // horizontal positions, rounded up to whole quads
 HDI int me_win_w(int R) { return 32 + me_spanx(R); }           // columns a quad's 8-byte windows can touch
-HDI int me_win_stride(int R) { return me_win_w(R) + 4; }       // rows stay 4-sample aligned
+// row stride in samples: >= width + 4, 4-sample aligned, and (in 4-sample units) = 8 mod 16 -- a wave's 8 quads x 8 rows then
+// read 64 different LDS banks (17 units, the natural stride at R = 15, put rows 0 and 4 on the same banks: half of all window
+// reads were bank-conflict cycles, profiles/r01_d_bench pmc_summary)
+HDI int me_win_stride(int R)
+{
+    int u = (me_win_w(R) + 4 + 3) >> 2;
+    while ((u & 15) != 8) u++;
+    return u << 2;
+}
 HDI int me_win_elems(int R) { return (32 + 2 * R) * me_win_stride(R) + 16; }
 
 // SADs of the four 8x8 blocks of one block row (8 CTU rows x 32 samples) at the 4 horizontal positions of a quad.
