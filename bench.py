@@ -36,6 +36,7 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     cfg.width, cfg.height = width, height
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and NxN trial the device path runs
     prm_i.intra_nxn = cfg.intra_nxn
+    prm_p.intra_in_p, prm_p.pre_search = cfg.intra_in_p, cfg.pre_search
     t0 = time.perf_counter()
     ref = None
     for i, (y, u, v) in enumerate(clip.frames()):

@@ -70,6 +70,18 @@ template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_d
     intra_ctu_program<T>(ex, s, a, cx, cy);
 }
 
+template <typename T> __global__ __launch_bounds__(256) void k_lowres(const PreArgs<T> *args)
+{
+    lowres_sample<T>(args[blockIdx.y], (int)(blockIdx.x * 256 + threadIdx.x));
+}
+template <typename T> __global__ __launch_bounds__(NT) void k_pre_search(const PreArgs<T> *args, int n_ctu)
+{
+    __shared__ __align__(16) PreShared s;
+    if ((int)blockIdx.x >= n_ctu) return;
+    GpuExec ex;
+    pre_search_program<T>(ex, s, args[blockIdx.y], (int)blockIdx.x);
+}
+
 // intra second pass of P pictures: one workgroup per CTU, most of them leave at once (not a candidate of this round)
 template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_p(const IntraArgs<T> *args, int n_ctu, int round)
 {
@@ -210,6 +222,14 @@ template <typename T> hipError_t launch_intra_picture(hipStream_t st, const Intr
     return hipGetLastError();
 }
 
+template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int batch)
+{
+    const int n = 2 * (w >> 2) * (h >> 2);
+    hipLaunchKernelGGL(k_lowres<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
+    hipLaunchKernelGGL(k_pre_search<T>, dim3((unsigned)n_ctu, (unsigned)batch), dim3(NT), 0, st, d_args, n_ctu);
+    return hipGetLastError();
+}
+
 template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch)
 {
     size_t smem = round16(sizeof(IntraShared<T>));
@@ -276,7 +296,8 @@ int gfx950_device_count()
     template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                 \
-    template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                      \
+    template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                                       \
+    template hipError_t launch_pre_search<T>(hipStream_t, const PreArgs<T> *, int, int, int, int);                      \
     template hipError_t launch_deblock<T>(hipStream_t, const DeblockArgs<T> *, const DeblockArgs<T> *, int, int, int);  \
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
@@ -415,7 +436,7 @@ template <typename T> struct Planes3 {
     ~Planes3() { for (auto &x : p) free_plane<T>(x); }
 };
 
-CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p}; }
+CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search}; }
 
 bool geometry_ok(int w, int h) { return w >= 16 && h >= 16 && !(w & 7) && !(h & 7) && w <= 8192 && h <= 4352; }
 
@@ -477,6 +498,16 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     DevBuf dip, diargs;
     a.ip = nullptr;
     if (a.prm.intra_in_p) { CK(dip.alloc((size_t)n_ctu * sizeof(IpInfo))); CK(hipMemset(dip.p, 0, (size_t)n_ctu * sizeof(IpInfo))); a.ip = dip.as<IpInfo>(); }
+    DevBuf dls, dlr, dpre;
+    if (a.prm.pre_search && !centers) {       // search centres from the 1/4-size pictures
+        const size_t ln = (size_t)(w >> 2) * (h >> 2);
+        CK(dls.alloc(ln)); CK(dlr.alloc(ln)); CK(dpre.alloc(sizeof(PreArgs<T>)));
+        PreArgs<T> pa2;
+        pa2.src = a.src[0]; pa2.ref = a.ref[0]; pa2.lsrc = dls.as<uint8_t>(); pa2.lref = dlr.as<uint8_t>(); pa2.w = w; pa2.h = h; pa2.bit_depth = a.prm.bit_depth; pa2.centers = dcen.as<int16_t>();
+        CK(hipMemcpy(dpre.p, &pa2, sizeof pa2, hipMemcpyHostToDevice));
+        CK(launch_pre_search<T>(0, dpre.as<PreArgs<T>>(), w, h, n_ctu, 1));
+        a.centers = dcen.as<int16_t>();
+    }
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
     CK(launch_inter_ctu<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));

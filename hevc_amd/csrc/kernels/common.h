@@ -52,7 +52,9 @@ struct CostParams {
     int tile_cols, tile_rows;     // intra pictures: uniform tile grid (6.5.1), 1x1 = no tiles
     int intra_nxn;                // 1: 8x8 intra CUs are also tried as four 4x4 PUs (NxN, DST-VII luma TUs)
     int intra_in_p;               // 1: P pictures run the intra second pass (kernels/intra.h intra_p_eligible)
+    int pre_search;               // 1: search centres come from a +-PRE_RANGE full search on the 1/4-size pictures (kernels/inter.h)
 };
+constexpr int PRE_RANGE = 14;     // low-resolution samples: centres reach +-56 luma samples, window reads stay inside the 80-sample border
 // per-CTU hand-over from the inter pass of a P picture to its intra second pass
 struct IpInfo {
     unsigned long long jinter;    // J of the inter version: SSE << 4 + lambda * estimated bits

@@ -35,6 +35,93 @@ template <typename T> struct InterArgs {
 // candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
 DEVCONST int8_t kOff[9][2] = {{0, 0}, {-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
 
+// ------------------------------------------------------------------------------------------ search centres (pre-search)
+// 1/4-size 8-bit pictures (rounded mean of every 4x4 luma block, reduced to 8 bits) of the source and of the reference; every
+// CTU's 8x8 low-resolution block is searched over +-PRE_RANGE with clamped reads: cost = 4 * SAD + |dx| + |dy|, ties -> raster
+// order (oracle: orc_pre_search).  One lane = four horizontal positions (v_qsad_pk_u16_u8), 8 quads x 29 rows = 232 lanes.
+template <typename T> struct PreArgs {
+    Plane<const T> src, ref;     // full-size luma planes (reference: padded plane, interior origin)
+    uint8_t *lsrc, *lref;        // (w/4) x (h/4) each, row stride w/4
+    int w, h, bit_depth;         // coded size
+    int16_t *centers;            // out: 2 per CTU, integer luma samples
+};
+template <typename T> DEV void lowres_sample(const PreArgs<T> &a, int i)
+{
+    const int lw = a.w >> 2, n = lw * (a.h >> 2), sh = a.bit_depth - 8;
+    if (i >= 2 * n) return;
+    const Plane<const T> &p = i < n ? a.src : a.ref;
+    const int k = i < n ? i : i - n, x = k % lw, y = k / lw;
+    int s = 8 << sh;
+    for (int j = 0; j < 4; j++) {
+        const T *row = p.p + (ptrdiff_t)(4 * y + j) * p.stride + 4 * x;
+        s += (int)row[0] + (int)row[1] + (int)row[2] + (int)row[3];
+    }
+    (i < n ? a.lsrc : a.lref)[k] = (uint8_t)(s >> (4 + sh));
+}
+constexpr int PRE_SPAN = 2 * PRE_RANGE + 1;      // 29 positions per axis
+constexpr int PRE_WIN_W = 40;                    // columns a lane's 12-byte reads can touch: 8 quads x 4 + 8
+constexpr int PRE_WIN_STRIDE = 96;               // bytes; 24 dwords = 8 mod 16 -> a wave's 8 quads x 8 rows hit 64 different banks
+struct PreShared {
+    uint8_t blk[64];
+    uint8_t win[(8 + 2 * PRE_RANGE) * PRE_WIN_STRIDE + 16];
+    unsigned long long best;
+};
+template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s, const PreArgs<T> &a, int ctu)
+{
+    constexpr int R = PRE_RANGE, span = PRE_SPAN, wh = 8 + 2 * R;
+    const int lw = a.w >> 2, lh = a.h >> 2, wc = (lw + 7) >> 3, cx = ctu % wc, cy = ctu / wc;
+    const int bw = lw - 8 * cx < 8 ? lw - 8 * cx : 8, bh = lh - 8 * cy < 8 ? lh - 8 * cy : 8;
+    ex.phase([&](int tid) {
+        if (tid < 64) { const int x = tid & 7, y = tid >> 3; s.blk[tid] = (x < bw && y < bh) ? a.lsrc[(8 * cy + y) * lw + 8 * cx + x] : (uint8_t)0; }
+        for (int i = tid; i < wh * PRE_WIN_W; i += NT) {
+            const int wx = i % PRE_WIN_W, wy = i / PRE_WIN_W;
+            const int x = clip3(0, lw - 1, 8 * cx + wx - R), y = clip3(0, lh - 1, 8 * cy + wy - R);
+            s.win[wy * PRE_WIN_STRIDE + wx] = a.lref[y * lw + x];
+        }
+        if (tid == 0) s.best = ~0ull;
+    });
+    ex.phase([&](int tid) {
+        unsigned long long best = ~0ull;
+        if (bw == 8 && bh == 8) {
+            if (tid < 8 * span) {
+                const int q = tid & 7, dyi = tid >> 3;
+                uint64_t acc = 0;
+#pragma unroll
+                for (int y = 0; y < 8; y++) {
+                    const uint8_t *w = s.win + (y + dyi) * PRE_WIN_STRIDE + 4 * q;
+                    const uint32_t r0 = load_u32_aligned(w), r1 = load_u32_aligned(w + 4), r2 = load_u32_aligned(w + 8);
+                    acc = qsad_u8(((uint64_t)r1 << 32) | r0, load_u32_aligned(s.blk + 8 * y), acc);
+                    acc = qsad_u8(((uint64_t)r2 << 32) | r1, load_u32_aligned(s.blk + 8 * y + 4), acc);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int dxi = 4 * q + j;
+                    if (dxi >= span) continue;
+                    const unsigned sad = (unsigned)((acc >> (16 * j)) & 0xffff);
+                    const unsigned long long key = ((unsigned long long)(4 * sad + (unsigned)(iabs(dxi - R) + iabs(dyi - R))) << 12) | (unsigned)(dyi * span + dxi);
+                    best = key < best ? key : best;
+                }
+            }
+        } else {                 // partial block at the right / bottom picture edge: plain loops over the valid samples
+            for (int p = tid; p < span * span; p += NT) {
+                const int dxi = p % span, dyi = p / span;
+                unsigned sad = 0;
+                for (int y = 0; y < bh; y++)
+                    for (int x = 0; x < bw; x++) sad += (unsigned)iabs((int)s.blk[y * 8 + x] - (int)s.win[(y + dyi) * PRE_WIN_STRIDE + x + dxi]);
+                const unsigned long long key = ((unsigned long long)(4 * sad + (unsigned)(iabs(dxi - R) + iabs(dyi - R))) << 12) | (unsigned)p;
+                best = key < best ? key : best;
+            }
+        }
+        if (best != ~0ull) ex.atomic_min(&s.best, best);
+    });
+    ex.phase([&](int tid) {
+        if (tid != 0) return;
+        const int p = (int)(s.best & 4095);
+        a.centers[2 * ctu] = (int16_t)(4 * (p % span - R));
+        a.centers[2 * ctu + 1] = (int16_t)(4 * (p / span - R));
+    });
+}
+
 // ------------------------------------------------------------------------------------------ integer search
 template <typename T> struct MeShared {
     T src[32 * 32];

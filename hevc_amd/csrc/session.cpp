@@ -158,6 +158,8 @@ struct mihevc_session {
         void *var_base[kVariants - 1][3], *var_p[kVariants - 1][3];   // work pictures of IDR variants 1..
         int32_t *me = nullptr;
         IpInfo *ip = nullptr;      // per CTU: inter pass -> intra second pass of P pictures
+        void *lsrc = nullptr, *lref = nullptr;   // 1/4-size source / reference luma of the step's picture (pre-search)
+        int16_t *centers = nullptr;              // per CTU search centre
         uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
     };
     std::vector<Lane> lane;
@@ -232,6 +234,9 @@ int ensure_lanes(mihevc_session *s, int n)
             if (int e = alloc_planes(s, L.var_base[v], L.var_p[v], L.work_stride, false)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
+        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lsrc));
+        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lref));
+        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, (void **)&L.centers));
         for (int k = 0; k < kRing; k++) {
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, true, (void **)&L.sym_host[k]));
@@ -243,7 +248,7 @@ int ensure_lanes(mihevc_session *s, int n)
 
 // argument blocks of one lock-step step: five arrays of `gops` entries each, so one launch per stage covers all lanes
 template <typename T> struct StepLayout {
-    size_t intra, inter, dbk_v, dbk_h, sao, total;
+    size_t intra, inter, dbk_v, dbk_h, sao, pre, total;
     explicit StepLayout(int gops)
     {
         auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
@@ -252,16 +257,18 @@ template <typename T> struct StepLayout {
         dbk_v = al(inter + gops * sizeof(InterArgs<T>));
         dbk_h = al(dbk_v + gops * sizeof(DeblockArgs<T>));
         sao = al(dbk_h + gops * sizeof(DeblockArgs<T>));
-        total = al(sao + gops * sizeof(SaoArgs<T>));
+        pre = al(sao + gops * sizeof(SaoArgs<T>));
+        total = al(pre + gops * sizeof(PreArgs<T>));
     }
 };
 template <typename T> struct StepView {
-    IntraArgs<T> *intra; InterArgs<T> *inter; DeblockArgs<T> *dbk_v, *dbk_h; SaoArgs<T> *sao;
+    IntraArgs<T> *intra; InterArgs<T> *inter; DeblockArgs<T> *dbk_v, *dbk_h; SaoArgs<T> *sao; PreArgs<T> *pre;
     StepView(uint8_t *base, const StepLayout<T> &l, int t)
     {
         uint8_t *b = base + (size_t)t * l.total;
         intra = (IntraArgs<T> *)(b + l.intra); inter = (InterArgs<T> *)(b + l.inter);
         dbk_v = (DeblockArgs<T> *)(b + l.dbk_v); dbk_h = (DeblockArgs<T> *)(b + l.dbk_h); sao = (SaoArgs<T> *)(b + l.sao);
+        pre = (PreArgs<T> *)(b + l.pre);
     }
 };
 
@@ -334,7 +341,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto prm_for = [&](int qp) {
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
-        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0};
+        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0, s->cfg.pre_search != 0};
     };
     const int64_t first_index = s->frames_in - n;
     {
@@ -377,6 +384,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.sparse_coef = A.inter.sparse_coef = 1;
             A.intra.diagonal = 0;
             A.inter.centers = nullptr; A.inter.me = L.me;
+            if (t > 0 && s->cfg.pre_search) {       // search centres from the 1/4-size source and reference of this step
+                PreArgs<T> &P4 = hv.pre[g];
+                P4.src = A.inter.src[0]; P4.ref = A.inter.ref[0]; P4.lsrc = (uint8_t *)L.lsrc; P4.lref = (uint8_t *)L.lref; P4.w = s->w; P4.h = s->h; P4.bit_depth = s->cfg.bit_depth; P4.centers = L.centers;
+                A.inter.centers = L.centers;
+            }
             // P pictures: the inter pass leaves per-CTU costs for the intra second pass, which runs on the same work picture,
             // records and levels with the one-tile PPS 0 geometry
             const bool ipass = t > 0 && s->cfg.intra_in_p;
@@ -565,7 +577,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
             for (int g = 0; g < B; g++)      // zero the slot's SSE + estimate accumulators
                 HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
-            STAGE(1, B, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            // stage 1 = search centres from the 1/4-size pictures (k_lowres, k_pre_search) + the integer search around them
+            if (int e_ = mark(1, B, true)) return e_;
+            if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dv.pre, s->w, s->h, s->n_ctu, B));
+            HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            if (int e_ = mark(1, B, false)) return e_;
             STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
             if (s->cfg.intra_in_p) STAGE(7, B, launch_intra_p<T>(s->st_compute, dv.intra, s->n_ctu, B));
         }
@@ -862,6 +878,9 @@ void mihevc_close(mihevc_session *s)
         for (int v = 0; v < kVariants - 1; v++) free3(L.var_base[v], 0);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
+        bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lsrc);
+        bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lref);
+        bc.release(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, L.centers);
         for (int k = 0; k < kRing; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     if (s->d_args) (void)hipFree(s->d_args);

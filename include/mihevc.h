@@ -70,7 +70,9 @@ typedef struct mihevc_config {
                                        * serial CTU-program latency, 0.12 ms per 1080p picture, and the bench clip gains nothing from it */
     int32_t hrd;                      /* 1: HRD parameters in the VUI + buffering-period SEI at every IDR + picture-timing SEI per picture
                                        * (x265 hrd=1, part of the reference's HDR10 set, core/utils.py:66); needs vbv_maxrate/bufsize */
-    int32_t reserved[3];
+    int32_t pre_search;               /* 1 (default): search centres from a +-14 full search on the 1/4-size pictures, so the +-me_range
+                                       * integer search follows motion up to +-56 samples; 0: centres at zero */
+    int32_t reserved[2];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -82,7 +84,7 @@ typedef struct mihevc_stats {
     int32_t last_qp;
     int32_t reserved[7];
     /* per-stage device time, filled when cfg.profile_stages: sum of HIP-event intervals and number of launches.
-     * index: 0 intra (all anti-diagonals of a step), 1 me_search, 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
+     * index: 0 intra (all anti-diagonals of a step), 1 me_search (incl. the pre-search), 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
      * 5 border pad, 6 sse, 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
     double  stage_ms[8];
     int64_t stage_launches[8];
@@ -124,8 +126,9 @@ typedef struct mihevc_cost_params {
     int32_t tile_cols, tile_rows;     /* intra pictures: uniform tile grid (0/1 = one tile); see mihevc_tile_grid */
     int32_t intra_nxn;                /* 1: try part_mode NxN (four 4x4 PUs, DST-VII) for 8x8 intra CUs */
     int32_t intra_in_p;               /* 1: mihevc_k_inter_frame also runs the intra second pass of P pictures */
+    int32_t pre_search;               /* 1: without explicit centres, mihevc_k_inter_frame derives them from the 1/4-size pictures */
 } mihevc_cost_params;
-void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, intra_nxn 0, intra_in_p 0 */
+void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, intra_nxn 0, intra_in_p 0, pre_search 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every
  * column >= 256 and every row >= 64 luma samples (A.4.1), uniform spacing; 1x1 when cfg->intra_tiles == 0. */
 int  mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows);

@@ -565,6 +565,46 @@ static void node_geom(int node, int *x, int *y, int *log2n)
     *x = (q & 1) * 16 + (s & 1) * 8; *y = (q >> 1) * 16 + (s >> 1) * 8; *log2n = 3;
 }
 
+/* ---- search centres from the 1/4-size pictures ------------------------------------------------------------------
+ * The integer search covers +-me_range around a per-CTU centre.  With pre_search the centre comes from a full search of
+ * +-ORC_PRE_RANGE low-resolution samples (+-56 luma samples) of the CTU's 8x8 low-resolution block: cost = 4 * SAD + |dx| + |dy|
+ * (a slight pull towards zero), ties -> first position in raster order; samples outside the low-resolution picture clamp. */
+#define ORC_PRE_RANGE 14
+void orc_lowres(const pix *src, int stride, int w, int h, int bit_depth, pix *dst)
+{
+    int lw = w >> 2, lh = h >> 2, sh = bit_depth - 8;
+    for (int y = 0; y < lh; y++)
+        for (int x = 0; x < lw; x++) {
+            int s = 8 << sh;
+            for (int j = 0; j < 4; j++)
+                for (int i = 0; i < 4; i++) s += src[(4 * y + j) * stride + 4 * x + i];
+            dst[y * lw + x] = (pix)(s >> (4 + sh));
+        }
+}
+void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers)
+{
+    int wc = (lw + 7) >> 3, hc = (lh + 7) >> 3, R = ORC_PRE_RANGE, span = 2 * R + 1;
+    for (int cy = 0; cy < hc; cy++)
+        for (int cx = 0; cx < wc; cx++) {
+            int bw = lw - 8 * cx < 8 ? lw - 8 * cx : 8, bh = lh - 8 * cy < 8 ? lh - 8 * cy : 8;
+            uint64_t best = ~0ull;
+            for (int dy = -R; dy <= R; dy++)
+                for (int dx = -R; dx <= R; dx++) {
+                    uint32_t sad = 0;
+                    for (int y = 0; y < bh; y++)
+                        for (int x = 0; x < bw; x++) {
+                            int rx = CLIP3(0, lw - 1, 8 * cx + x + dx), ry = CLIP3(0, lh - 1, 8 * cy + y + dy);
+                            sad += (uint32_t)iabs(lsrc[(8 * cy + y) * lw + 8 * cx + x] - lref[ry * lw + rx]);
+                        }
+                    uint64_t key = ((uint64_t)(4 * sad + (uint32_t)(iabs(dx) + iabs(dy))) << 12) | (uint32_t)((dy + R) * span + dx + R);
+                    if (key < best) best = key;
+                }
+            int p = (int)(best & 4095);
+            centers[2 * (cy * wc + cx)] = (int16_t)(4 * (p % span - R));
+            centers[2 * (cy * wc + cx) + 1] = (int16_t)(4 * (p / span - R));
+        }
+}
+
 /* 8x8 Hadamard "activity" of a source tile: the SATD it would have against a flat prediction of its own mean (the DC term
  * dropped) -- the yardstick a CTU's inter cost is held against before the intra second pass looks at it */
 static int hadamard8_ac(const pix *a, int as)
@@ -600,6 +640,16 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
     const int R = prm->me_range, spany = 2 * R + 1, spanx = (spany + 3) & ~3, bd = prm->bit_depth, lam = prm->lambda_sad_q4;
     const int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU, w8 = w >> 3;
     uint32_t *sad8 = (uint32_t *)malloc(sizeof(uint32_t) * 16 * spanx * spany);
+    int16_t *own_centers = NULL;
+    if (!centers && prm->pre_search) {
+        pix *ls = (pix *)malloc(sizeof(pix) * (w >> 2) * (h >> 2)), *lr = (pix *)malloc(sizeof(pix) * (w >> 2) * (h >> 2));
+        own_centers = (int16_t *)malloc(sizeof(int16_t) * 2 * wc * hc);
+        orc_lowres(src_y, src_stride, w, h, bd, ls);
+        orc_lowres(ref_y, ref_stride, w, h, bd, lr);
+        orc_pre_search(ls, lr, w >> 2, h >> 2, own_centers);
+        centers = own_centers;
+        free(ls); free(lr);
+    }
     uint8_t *ip_cand = (uint8_t *)calloc((size_t)wc * hc, 1);
     uint64_t *ip_jinter = (uint64_t *)calloc((size_t)wc * hc, sizeof(uint64_t));
     for (int cy = 0; cy < hc; cy++)
@@ -767,6 +817,9 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                         ip_cand, ip_jinter);
     free(ip_cand); free(ip_jinter);
     free(sad8);
+    if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers);
+    free(own_centers);
+    return;
     if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers);
 }
 

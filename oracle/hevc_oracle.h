@@ -70,6 +70,7 @@ typedef struct {
                                 * are unavailable for prediction (6.4.1), which is what shortens the CTU wavefront */
     int intra_nxn;            /* 1: every 8x8 intra CU is also tried as four 4x4 PUs (part_mode NxN, DST-VII luma TUs) */
     int intra_in_p;           /* 1: P pictures get a second pass that re-codes badly predicted CTUs as intra (see orc_analyze_inter_frame) */
+    int pre_search;           /* 1: when no search centres are given, take them from a +-14 full search on the 1/4-size pictures (+-56 samples) */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */
@@ -111,6 +112,10 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                              orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
                              int32_t *me_dump /* optional: per CTU 21*(mvx,mvy,cost) after integer search, or NULL */,
                              uint64_t *est /* optional: picture rate estimate in 1/16 bit */);
+/* 1/4-size picture: every sample the rounded mean of a 4x4 luma block reduced to 8 bits (w, h multiples of 4) */
+void orc_lowres(const pix *src, int stride, int w, int h, int bit_depth, pix *dst /* (w/4) x (h/4), stride w/4 */);
+/* per CTU search centre (integer luma samples, 2 per CTU) from a +-14 full search of its 8x8 low-resolution block */
+void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers);
 /* K2+K3: intra (I) frame */
 void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
                              int w, int h, const orc_params *prm,

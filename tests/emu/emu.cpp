@@ -37,7 +37,7 @@ template <typename T> struct Padded {
 
 static CostParams to_prm(const mihevc_cost_params *p)
 {
-    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p};
+    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search};
 }
 
 template <typename T>
@@ -61,6 +61,16 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     a.me = me.data();
     if (a.prm.intra_in_p) { ipv.assign((size_t)n_ctu, IpInfo{0, 0, 0}); a.ip = ipv.data(); }
     SeqExec ex;
+    std::vector<uint8_t> ls, lr;
+    std::vector<int16_t> cen;
+    if (a.prm.pre_search && !centers) {
+        PreArgs<T> pa;
+        ls.assign((size_t)(w / 4) * (h / 4), 0); lr = ls; cen.assign((size_t)n_ctu * 2, 0);
+        pa.src = a.src[0]; pa.ref = a.ref[0]; pa.lsrc = ls.data(); pa.lref = lr.data(); pa.w = w; pa.h = h; pa.bit_depth = a.prm.bit_depth; pa.centers = cen.data();
+        for (int i = 0; i < 2 * (w / 4) * (h / 4); i++) lowres_sample<T>(pa, i);
+        for (int c = 0; c < n_ctu; c++) { PreShared ps; pre_search_program<T>(ex, ps, pa, c); }
+        a.centers = cen.data();
+    }
     std::vector<T> win((size_t)me_win_elems(R) + 8);
     std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16), wu((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16), wv(wu.size());
     for (int c = 0; c < n_ctu; c++) {

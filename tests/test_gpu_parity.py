@@ -128,6 +128,23 @@ def test_intra_second_pass_of_p_pictures_parity(lib, api, w, h, qp, bd, nxn):
         ref = O.sao(srcs[i], O.deblock(want.rec, want.cu, bd), prm)[0]
 
 
+@pytest.mark.parametrize("w,h,bd,shift", [(192, 128, 8, (38, -22)), (136, 104, 10, (-50, 17)), (640, 352, 8, (-56, 56))])
+def test_pre_search_parity(lib, api, w, h, bd, shift):
+    """k_lowres + k_pre_search: centres from the 1/4-size pictures, identical to the oracle; the integer search then finds the shift."""
+    prm, cp = lib_params(lib, 27, bd, 8)
+    prm.pre_search = cp.pre_search = 1
+    base = util.synth_frame(h + 128, w + 128, 5, bit_depth=bd)          # a pure translation: two crops of one larger picture
+    def crop(ox, oy):
+        return O.Frame(base.y[64 + oy:64 + oy + h, 64 + ox:64 + ox + w].copy(), base.u[32 + oy // 2:32 + (oy + h) // 2, 32 + ox // 2:32 + (ox + w) // 2].copy(),
+                       base.v[32 + oy // 2:32 + (oy + h) // 2, 32 + ox // 2:32 + (ox + w) // 2].copy())
+    a, b = crop(0, 0), crop(shift[0], shift[1])                        # b(x) = a(x + shift): every block of b sits at +shift in a
+    want = O.analyze_inter(b, a, prm, dump_me=True)
+    got = api.inter(b, a, cp)
+    assert np.array_equal(want.me, got.me) and util.same_analysis(want, got), util.describe_diff(want, got)
+    vals, counts = np.unique(want.cu["mvx"].astype(np.int32) * 4096 + want.cu["mvy"], return_counts=True)
+    assert vals[np.argmax(counts)] == 4 * shift[0] * 4096 + 4 * shift[1] and counts.max() > 0.35 * want.cu.size     # the true shift dominates (part of the picture has no counterpart in the reference)
+
+
 def test_search_centres(lib, api):
     w, h = 96, 64
     prm, cp = lib_params(lib, 26, 8, 8)
@@ -188,7 +205,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_p, _ = lib_params(lib, qp_p, bd, 8)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
     prm_i.intra_nxn = prm_p.intra_nxn = cfg.intra_nxn            # NxN trial when the session asks for it
-    prm_p.intra_in_p = cfg.intra_in_p                            # default 1: intra second pass in P pictures
+    prm_p.intra_in_p, prm_p.pre_search = cfg.intra_in_p, cfg.pre_search      # second pass knob; search centres from the 1/4-size pictures
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     ref = None
     for i, f in enumerate(frames):
@@ -244,7 +261,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     ref = None
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
-        prm.intra_nxn, prm.intra_in_p = cfg.intra_nxn, cfg.intra_in_p
+        prm.intra_nxn, prm.intra_in_p, prm.pre_search = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"

@@ -96,6 +96,26 @@ def test_stepped_intra_second_pass_of_p_pictures(emu, w, h, qp, bd, nxn):
         ref = O.sao(srcs[i], O.deblock(want.rec, want.cu, bd), prm)[0]
 
 
+@pytest.mark.parametrize("w,h,bd,shift", [(192, 128, 8, (38, -22)), (136, 104, 10, (-50, 17)), (160, 96, 8, (3, 1))])
+def test_stepped_pre_search_finds_fast_motion(emu, w, h, bd, shift):
+    """Search centres from the 1/4-size pictures: +-8 integer search around them follows a global shift far outside +-8."""
+    prm = O.default_params(27, bit_depth=bd, me_range=8)
+    prm.pre_search = 1
+    base = util.synth_frame(h + 128, w + 128, 5, bit_depth=bd)          # a pure translation: two crops of one larger picture
+    def crop(ox, oy):
+        return O.Frame(base.y[64 + oy:64 + oy + h, 64 + ox:64 + ox + w].copy(), base.u[32 + oy // 2:32 + (oy + h) // 2, 32 + ox // 2:32 + (ox + w) // 2].copy(),
+                       base.v[32 + oy // 2:32 + (oy + h) // 2, 32 + ox // 2:32 + (ox + w) // 2].copy())
+    a, b = crop(0, 0), crop(shift[0], shift[1])                        # b(x) = a(x + shift): every block of b sits at +shift in a
+    want = O.analyze_inter(b, a, prm, dump_me=True)
+    got = emu.inter(b, a, prm)
+    assert util.same_analysis(want, got) and np.array_equal(want.me, got.me), util.describe_diff(want, got)
+    vals, counts = np.unique(want.cu["mvx"].astype(np.int32) * 4096 + want.cu["mvy"], return_counts=True)
+    assert vals[np.argmax(counts)] == 4 * shift[0] * 4096 + 4 * shift[1] and counts.max() > 0.35 * want.cu.size     # the true shift dominates (part of the picture has no counterpart in the reference)
+    if max(abs(shift[0]), abs(shift[1])) > 8:
+        prm.pre_search = 0
+        assert O.analyze_inter(b, a, prm).est > 1.5 * want.est        # without the centres the motion is out of reach
+
+
 def test_search_centres_are_honoured(emu):
     w, h, bd = 96, 64, 8
     prm = O.default_params(26, me_range=8)
