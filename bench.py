@@ -36,7 +36,7 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     cfg.width, cfg.height = width, height
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and NxN trial the device path runs
     prm_i.intra_nxn = cfg.intra_nxn
-    prm_p.intra_in_p, prm_p.pre_search = cfg.intra_in_p, cfg.pre_search
+    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero
     t0 = time.perf_counter()
     ref = None
     for i, (y, u, v) in enumerate(clip.frames()):
@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
     ap.add_argument("--intra-nxn", type=int, default=None, help="experiments only: override cfg.intra_nxn (4x4 PUs + DST in IDR pictures)")
     ap.add_argument("--intra-tiles", type=int, default=None, help="experiments only: override cfg.intra_tiles (IDR tile grid)")
+    ap.add_argument("--pre-search", type=int, default=None, help="experiments only: override cfg.pre_search")
+    ap.add_argument("--rdo-zero", type=int, default=None, help="experiments only: override cfg.rdo_zero")
+    ap.add_argument("--intra-in-p", type=int, default=None, help="experiments only: override cfg.intra_in_p")
     args = ap.parse_args()
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -113,6 +116,9 @@ def main():
         cfg.intra_nxn = args.intra_nxn
     if args.intra_tiles is not None:
         cfg.intra_tiles = args.intra_tiles
+    for name in ("pre_search", "rdo_zero", "intra_in_p"):
+        if getattr(args, name) is not None:
+            setattr(cfg, name, getattr(args, name))
 
     # synthetic clip -> HBM (untimed).  torch is plumbing for device memory only.
     clip = SyntheticClip("motion", rank, W, H, N)

@@ -53,6 +53,7 @@ struct CostParams {
     int intra_nxn;                // 1: 8x8 intra CUs are also tried as four 4x4 PUs (NxN, DST-VII luma TUs)
     int intra_in_p;               // 1: P pictures run the intra second pass (kernels/intra.h intra_p_eligible)
     int pre_search;               // 1: search centres come from a +-PRE_RANGE full search on the 1/4-size pictures (kernels/inter.h)
+    int rdo_zero;                 // 1: inter TUs whose levels cost more than the distortion they remove are zeroed (inter_ctu_program)
 };
 constexpr int PRE_RANGE = 14;     // low-resolution samples: centres reach +-56 luma samples, window reads stay inside the 80-sample border
 // per-CTU hand-over from the inter pass of a P picture to its intra second pass
@@ -430,6 +431,7 @@ struct GpuExec {
     DEV void atomic_add(unsigned *p, unsigned v) { atomicAdd(p, v); }
     DEV void atomic_add(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
     DEV void atomic_or(unsigned *p, unsigned v) { atomicOr(p, v); }
+    DEV void atomic_and(unsigned *p, unsigned v) { atomicAnd(p, v); }
     DEV void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
     DEV void atomic_add_global(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 };
@@ -447,6 +449,7 @@ struct SeqExec {      // sequential stepping of a phase program (tests/emu)
     void atomic_add(unsigned *p, unsigned v) { *p += v; }
     void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }
     void atomic_or(unsigned *p, unsigned v) { *p |= v; }
+    void atomic_and(unsigned *p, unsigned v) { *p &= v; }
     void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
     void atomic_add_global(unsigned long long *p, unsigned long long v) { *p += v; }
 };

@@ -65,6 +65,7 @@ struct PreShared {
     uint8_t blk[64];
     uint8_t win[(8 + 2 * PRE_RANGE) * PRE_WIN_STRIDE + 16];
     unsigned long long best;
+    unsigned sad0;               // SAD at zero displacement
 };
 template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s, const PreArgs<T> &a, int ctu)
 {
@@ -98,6 +99,7 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
                     const int dxi = 4 * q + j;
                     if (dxi >= span) continue;
                     const unsigned sad = (unsigned)((acc >> (16 * j)) & 0xffff);
+                    if (dxi == R && dyi == R) s.sad0 = sad;
                     const unsigned long long key = ((unsigned long long)(4 * sad + (unsigned)(iabs(dxi - R) + iabs(dyi - R))) << 12) | (unsigned)(dyi * span + dxi);
                     best = key < best ? key : best;
                 }
@@ -108,6 +110,7 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
                 unsigned sad = 0;
                 for (int y = 0; y < bh; y++)
                     for (int x = 0; x < bw; x++) sad += (unsigned)iabs((int)s.blk[y * 8 + x] - (int)s.win[(y + dyi) * PRE_WIN_STRIDE + x + dxi]);
+                if (dxi == R && dyi == R) s.sad0 = sad;
                 const unsigned long long key = ((unsigned long long)(4 * sad + (unsigned)(iabs(dxi - R) + iabs(dyi - R))) << 12) | (unsigned)p;
                 best = key < best ? key : best;
             }
@@ -116,7 +119,10 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
     });
     ex.phase([&](int tid) {
         if (tid != 0) return;
-        const int p = (int)(s.best & 4095);
+        // the centre only moves when that halves the zero-displacement SAD (oracle: orc_pre_search)
+        int p = (int)(s.best & 4095);
+        const unsigned sad_best = (unsigned)(((s.best >> 12) - (unsigned)(iabs(p % span - R) + iabs(p / span - R))) >> 2);
+        if (2 * sad_best >= s.sad0) p = R * span + R;
         a.centers[2 * ctu] = (int16_t)(4 * (p % span - R));
         a.centers[2 * ctu + 1] = (int16_t)(4 * (p / span - R));
     });
@@ -295,6 +301,7 @@ template <typename T> struct InterShared {
     unsigned est;                // CTU rate estimate, 1/16 bit
     unsigned ip_cost, ip_act, ip_tiles;   // intra second pass: chosen CUs' cost, source AC activity, tiles inside the picture
     unsigned long long ip_sse;
+    unsigned tu_dc[3][16], tu_dz[3][16], tu_bits[3][16], tu_zero[3];   // RD zero-out: per TU (plane, first 8x8 tile) SSE coded / zeroed, level bits
     // followed in LDS by: T winY[(40 + 2R)^2 (stride padded)], T winU[(24 + R)^2], T winV[...]
 };
 // motion-compensation windows cover every vector the search can return: |mv| <= R + 3 (widened horizontal span)
@@ -695,8 +702,51 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.rs.res[i] = (int16_t)((int)s.src[i] - (int)s.pred[i]);
             s.rs.desc[i] = pack_loc(locate(s.rs, i));
         }
+        if (tid < 48) { s.tu_dc[tid >> 4][tid & 15] = 0; s.tu_dz[tid >> 4][tid & 15] = 0; s.tu_bits[tid >> 4][tid & 15] = 0; }
+        if (tid < 3) s.tu_zero[tid] = 0;
     });
     residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, whole_ctu());
+    // RD zero-out (oracle: code_tu_inter): a TU keeps its levels only if SSE_zero << 4 > (SSE_coded << 4) + (lambda * bits >> 4)
+    if (a.prm.rdo_zero) {
+        ex.phase([&](int tid) {
+            const int maxv = (1 << bd) - 1;
+            for (int i = 4 * tid; i < 1536; i += 4 * NT) {
+                SampleLoc l = locate(s.rs, i);
+                if (!l.log2n || !((s.rs.cbf[l.plane] >> l.tile0) & 1)) continue;
+                unsigned dc = 0, dz = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int sv = (int)s.src[i + j], pv = (int)s.pred[i + j], d0 = sv - pv, d1 = sv - clip3(0, maxv, pv + s.rs.res[i + j]);
+                    dz += (unsigned)(d0 * d0); dc += (unsigned)(d1 * d1);
+                }
+                if (dc) ex.atomic_add(&s.tu_dc[l.plane][l.tile0], dc);
+                if (dz) ex.atomic_add(&s.tu_dz[l.plane][l.tile0], dz);
+            }
+            for (int sb = tid; sb < 96; sb += NT) {       // level bits per 4x4 sub-block, summed per TU
+                int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
+                int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
+                SampleLoc l = locate(s.rs, base + by * stride + bx);
+                if (!l.log2n || !((s.rs.cbf[l.plane] >> l.tile0) & 1)) continue;
+                int b = subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
+                if (b) ex.atomic_add(&s.tu_bits[pl][l.tile0], (unsigned)b);
+            }
+        });
+        ex.phase([&](int tid) {
+            if (tid >= 48) return;
+            const int pl = tid >> 4, t = tid & 15;
+            if (!((s.rs.cbf[pl] >> t) & 1) || !s.tu_bits[pl][t]) return;      // only a TU's first tile carries its cbf bit and sums
+            const unsigned long long jz = (unsigned long long)s.tu_dz[pl][t] << 4;
+            const unsigned long long jc = ((unsigned long long)s.tu_dc[pl][t] << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)(s.tu_bits[pl][t] + 16)) >> 4);
+            if (jz <= jc) ex.atomic_or(&s.tu_zero[pl], 1u << t);
+        });
+        ex.phase([&](int tid) {
+            for (int i = tid; i < 1536; i += NT) {
+                SampleLoc l = locate(s.rs, i);
+                if (l.log2n && ((s.tu_zero[l.plane] >> l.tile0) & 1)) { s.rs.lvl[i] = 0; s.rs.res[i] = 0; }
+            }
+        });
+        ex.phase([&](int tid) { if (tid < 3) s.rs.cbf[tid] &= ~s.tu_zero[tid]; });
+    }
     // reconstruction + outputs
     ex.phase([&](int tid) {
         const int maxv = (1 << bd) - 1;

@@ -72,7 +72,9 @@ typedef struct mihevc_config {
                                        * (x265 hrd=1, part of the reference's HDR10 set, core/utils.py:66); needs vbv_maxrate/bufsize */
     int32_t pre_search;               /* 1 (default): search centres from a +-14 full search on the 1/4-size pictures, so the +-me_range
                                        * integer search follows motion up to +-56 samples; 0: centres at zero */
-    int32_t reserved[2];
+    int32_t rdo_zero;                 /* 1 (default): inter TUs whose levels cost more (lambda x bits) than the distortion they remove are
+                                       * coded as all-zero (-2.5 % bits at -0.01 dB on the bench clip's P pictures) */
+    int32_t reserved[1];
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -127,8 +129,9 @@ typedef struct mihevc_cost_params {
     int32_t intra_nxn;                /* 1: try part_mode NxN (four 4x4 PUs, DST-VII) for 8x8 intra CUs */
     int32_t intra_in_p;               /* 1: mihevc_k_inter_frame also runs the intra second pass of P pictures */
     int32_t pre_search;               /* 1: without explicit centres, mihevc_k_inter_frame derives them from the 1/4-size pictures */
+    int32_t rdo_zero;                 /* 1: RD zero-out of inter TUs */
 } mihevc_cost_params;
-void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, intra_nxn 0, intra_in_p 0, pre_search 0 */
+void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, every analysis knob 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every
  * column >= 256 and every row >= 64 luma samples (A.4.1), uniform spacing; 1x1 when cfg->intra_tiles == 0. */
 int  mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows);

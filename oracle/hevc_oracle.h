@@ -71,6 +71,7 @@ typedef struct {
     int intra_nxn;            /* 1: every 8x8 intra CU is also tried as four 4x4 PUs (part_mode NxN, DST-VII luma TUs) */
     int intra_in_p;           /* 1: P pictures get a second pass that re-codes badly predicted CTUs as intra (see orc_analyze_inter_frame) */
     int pre_search;           /* 1: when no search centres are given, take them from a +-14 full search on the 1/4-size pictures (+-56 samples) */
+    int rdo_zero;             /* 1: an inter TU whose levels cost more (lambda * bits) than the distortion they remove is coded as all-zero */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */

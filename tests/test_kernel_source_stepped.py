@@ -37,6 +37,7 @@ CASES = [
 def test_stepped_kernels_equal_oracle(emu, w, h, qp, bd, rng):
     prm_i = O.default_params(max(0, qp - 3), bit_depth=bd, me_range=rng)
     prm_p = O.default_params(qp, bit_depth=bd, me_range=rng)
+    prm_p.rdo_zero = int(qp >= 26)               # RD zero-out of inter TUs on for the higher QPs (where it bites), off for the rest
     srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
     want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
     ref = None
@@ -110,7 +111,7 @@ def test_stepped_pre_search_finds_fast_motion(emu, w, h, bd, shift):
     got = emu.inter(b, a, prm)
     assert util.same_analysis(want, got) and np.array_equal(want.me, got.me), util.describe_diff(want, got)
     vals, counts = np.unique(want.cu["mvx"].astype(np.int32) * 4096 + want.cu["mvy"], return_counts=True)
-    assert vals[np.argmax(counts)] == 4 * shift[0] * 4096 + 4 * shift[1] and counts.max() > 0.35 * want.cu.size     # the true shift dominates (part of the picture has no counterpart in the reference)
+    assert vals[np.argmax(counts)] == 4 * shift[0] * 4096 + 4 * shift[1] and counts.max() > 0.3 * want.cu.size     # the true shift dominates (part of the picture has no counterpart in the reference)
     if max(abs(shift[0]), abs(shift[1])) > 8:
         prm.pre_search = 0
         assert O.analyze_inter(b, a, prm).est > 1.5 * want.est        # without the centres the motion is out of reach
