@@ -114,7 +114,9 @@ struct SaoShared {
     uint16_t tile_c[2][18 * 20];
     // 16 private copies of the statistics (copy = lane & 15, odd stride -> distinct banks): neighbouring samples mostly
     // fall in the same category/band, and 64 lanes hitting one LDS word serialise (SQ_LDS_BANK_CONFLICT, r01 profiles)
-    int priv[3][16][105];            // per copy: eo_n[4][5] | eo_s[4][5] | bo_n[32] | bo_s[32]
+    // count and difference sum share one word, (1 << 20) + (d + bias) per sample: half the LDS atomics.  A copy sees at most
+    // 64 samples of a plane, so the biased sum (< 64 * 2048) never reaches the count field.
+    unsigned priv[3][16][53];        // per copy: eo[4][5] | bo[32], packed
     unsigned long long band_key[3];  // min over the 29 band positions of ((cost + bias) << 8 | position)
 };
 
@@ -159,7 +161,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
     ex.phase([&](int tid) {
         int *z = &s.eo_n[0][0][0];
         for (int i = tid; i < 3 * (20 + 20 + 32 + 32); i += NT) z[i] = 0;
-        for (int i = tid; i < 3 * 16 * 105; i += NT) (&s.priv[0][0][0])[i] = 0;
+        for (int i = tid; i < 3 * 16 * 53; i += NT) (&s.priv[0][0][0])[i] = 0;
         for (int i = tid; i < 34 * 34 + 2 * 18 * 18; i += NT) {
             int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), k = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
             int tx = k % dim, ty = k / dim, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
@@ -179,28 +181,26 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             int r = tp[ti];
             int d = (int)a.src[pl].p[(ptrdiff_t)gy * a.src[pl].stride + gx] - r;
             int b = r >> (bd - 5);
-            int *pv = s.priv[pl][tid & 15];
-            ex.atomic_add(&pv[40 + b], 1);
-            ex.atomic_add(&pv[72 + b], d);
+            unsigned *pv = s.priv[pl][tid & 15];
+            const unsigned one = (1u << 20) + (unsigned)(d + (1 << bd));      // count 1, sum d + bias
+            ex.atomic_add(&pv[20 + b], one);
             for (int c = 0; c < 4; c++) {
                 int xa = gx + kEoDx[c][0], ya = gy + kEoDy[c][0], xb = gx + kEoDx[c][1], yb = gy + kEoDy[c][1], k = 0;
                 if (!(xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph)) {
                     int e = 2 + sgn3(r - tp[ti + kEoDy[c][0] * ts + kEoDx[c][0]]) + sgn3(r - tp[ti + kEoDy[c][1] * ts + kEoDx[c][1]]);
                     k = e == 2 ? 0 : e < 2 ? e + 1 : e;
                 }
-                ex.atomic_add(&pv[c * 5 + k], 1);
-                ex.atomic_add(&pv[20 + c * 5 + k], d);
+                ex.atomic_add(&pv[c * 5 + k], one);
             }
         }
     });
     ex.phase([&](int tid) {          // fold the private copies
-        for (int i = tid; i < 3 * 104; i += NT) {
-            int pl = i / 104, e = i % 104, sum = 0;
-            for (int c = 0; c < 16; c++) sum += s.priv[pl][c][e];
-            if (e < 20) s.eo_n[pl][e / 5][e % 5] = sum;
-            else if (e < 40) s.eo_s[pl][(e - 20) / 5][(e - 20) % 5] = sum;
-            else if (e < 72) s.bo_n[pl][e - 40] = sum;
-            else s.bo_s[pl][e - 72] = sum;
+        for (int i = tid; i < 3 * 52; i += NT) {
+            int pl = i / 52, e = i % 52, n = 0, sum = 0;
+            for (int c = 0; c < 16; c++) { const unsigned v = s.priv[pl][c][e]; n += (int)(v >> 20); sum += (int)(v & 0xfffffu); }
+            sum -= n << bd;                      // take the per-sample bias back out
+            if (e < 20) { s.eo_n[pl][e / 5][e % 5] = n; s.eo_s[pl][e / 5][e % 5] = sum; }
+            else { s.bo_n[pl][e - 20] = n; s.bo_s[pl][e - 20] = sum; }
         }
     });
     ex.phase([&](int tid) {
