@@ -347,3 +347,21 @@ def test_flush_without_frames_and_reuse_after_flush(lib):
         enc.flush()
         assert list(enc.packets()) == []
         assert enc.stats().frames_out == 0
+
+
+@pytest.mark.parametrize("w,h,keyint,lanes,n", [(96, 80, 4, 2, 19), (256, 64, 5, 3, 47)])
+def test_several_chunks_with_rate_control(lib, w, h, keyint, lanes, n):
+    """More pictures than one lock-step chunk (lanes x keyint): the session runs chunk after chunk, the rate controller carries its
+    learned ratios across them, buffers are reused; every picture still decodes to the encoder's reconstruction."""
+    from hevc_amd import _lib
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.me_range = w, h, keyint, 2, lanes, 8
+    cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = 20, -1, 150, 180
+    frames = [util.synth_frame(h, w, seed=13, shift=(2 * i, i), bit_depth=8) for i in range(n)]
+    stream, recs, st, _ = _encode(cfg, frames)
+    assert st.frames_out == n
+    dec, info = O.decode(stream)
+    assert len(dec) == n
+    for i in range(n):
+        assert dec[i].same(O.Frame(*recs[i])), f"frame {i}"
+    assert info["pps.tile_cols"] in (None, 1) or w >= 256
