@@ -154,8 +154,88 @@ class Encoder:
         return 99.0 if mse <= 0 else float(10 * np.log10(peak * peak / mse))
 
 
+class ShardedEncoder:
+    """One clip over several MI355X: closed GOPs are independent, so consecutive chunks of `gops_in_flight x keyint` pictures go
+    round-robin to one session per device (SURVEY.md §8e "GOP g -> device g mod n"); nothing is exchanged between the devices
+    (no RCCL) and the packets come back in presentation order.  `devices` may name a device twice (two sessions on one GPU)."""
+
+    def __init__(self, cfg: _lib.Config, devices):
+        import queue
+        self.cfg, self.devices = cfg, list(devices)
+        lanes = cfg.gops_in_flight if cfg.gops_in_flight > 0 else 4
+        self.chunk = max(1, lanes * cfg.keyint)
+        self._encs = [Encoder(cfg, device=d) for d in self.devices]
+        self._q = [queue.Queue(maxsize=2 * self.chunk) for _ in self.devices]
+        self._out = {}                      # pts -> (data, key)
+        self._lock = threading.Lock()
+        self._err = []
+        self._threads = [threading.Thread(target=self._worker, args=(k,), daemon=True) for k in range(len(self.devices))]
+        for t in self._threads:
+            t.start()
+        self._n_in, self._next_out = 0, 0
+
+    def _worker(self, k):
+        enc, q = self._encs[k], self._q[k]
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                y, u, v, pts = item
+                enc.send(y, u, v, pts=pts)          # ctypes releases the GIL: the sessions run concurrently
+                self._collect(enc)
+            enc.flush()
+            self._collect(enc)
+        except Exception as exc:                    # surfaced by send()/finish() on the caller's thread
+            self._err.append(exc)
+
+    def _collect(self, enc):
+        got = list(enc.packets())
+        if got:
+            with self._lock:
+                for data, pts, key in got:
+                    self._out[pts] = (data, key)
+
+    def send(self, y, u, v):
+        if self._err:
+            raise self._err[0]
+        k = (self._n_in // self.chunk) % len(self.devices)
+        self._q[k].put((y, u, v, self._n_in))
+        self._n_in += 1
+
+    def ready(self):
+        """Packets that are next in presentation order: (data, pts, key)."""
+        out = []
+        with self._lock:
+            while self._next_out in self._out:
+                data, key = self._out.pop(self._next_out)
+                out.append((data, self._next_out, key))
+                self._next_out += 1
+        return out
+
+    def finish(self):
+        for q in self._q:
+            q.put(None)
+        for t in self._threads:
+            t.join()
+        if self._err:
+            raise self._err[0]
+        return self.ready()
+
+    def headers(self) -> bytes:
+        return self._encs[0].headers()
+
+    def stats(self):
+        return [e.stats() for e in self._encs]
+
+    def close(self):
+        for e in self._encs:
+            e.close()
+
+
 def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callback: Optional[Callable[[str, int, int], None]] = None,
-                total_frames: int = 1, stop_event: Optional[threading.Event] = None, device: Optional[int] = None, debug: bool = False) -> int:
+                total_frames: int = 1, stop_event: Optional[threading.Event] = None, device: Optional[int] = None, debug: bool = False,
+                devices=None) -> int:
     """Encode `file_path` to `out_path` (MP4/hvc1) on an MI355X.  Returns 0 on success, 1 on failure/cancel —
     the same (returncode) shape `run_ffmpeg` gives `convert_video` (core/transcoder.py:497-535)."""
     from . import mp4, yuvio
@@ -168,6 +248,31 @@ def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callb
     try:
         total = clip.n_frames or total_frames
         mux = mp4.Mp4Writer(Path(out_path), cfg)
+        if devices and len(devices) > 1:            # one clip over several GPUs, GOP chunks round-robin
+            sh = ShardedEncoder(cfg, devices)
+            n_out = 0
+            try:
+                def drain(pkts):
+                    nonlocal n_out
+                    for data, pts, key in pkts:
+                        mux.add_sample(data, pts, key)
+                        n_out += 1
+                    if pkts and progress_callback:
+                        try:
+                            progress_callback(Path(file_path).name, n_out, total)
+                        except Exception:
+                            logger.debug("progress_callback raised", exc_info=True)
+                for y, u, v in clip.frames():
+                    if stop_event is not None and stop_event.is_set():
+                        mux.abort()
+                        return 1
+                    sh.send(y, u, v)
+                    drain(sh.ready())
+                drain(sh.finish())
+                mux.finish(sh.headers())
+            finally:
+                sh.close()
+            return 0 if n_out > 0 else 1
         with Encoder(cfg, device=device or 0) as enc:
             n_out = 0
             for i, (y, u, v) in enumerate(clip.frames()):

@@ -365,3 +365,39 @@ def test_several_chunks_with_rate_control(lib, w, h, keyint, lanes, n):
     for i in range(n):
         assert dec[i].same(O.Frame(*recs[i])), f"frame {i}"
     assert info["pps.tile_cols"] in (None, 1) or w >= 256
+
+
+def test_one_clip_sharded_by_gop_chunks_over_two_sessions(lib):
+    """SURVEY §8e finer unit: chunks of gops_in_flight x keyint pictures round-robin over devices, no exchange.  With a fixed QP the
+    merged stream is the single-session stream picture for picture (here both sessions share GPU 0; on a node they are different GPUs)."""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder, ShardedEncoder
+    w, h, n, bd = 96, 80, 37, 8
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.me_range, cfg.qp = w, h, 3, 2, 2, 8, 28      # chunk = 6 pictures
+    frames = [util.planes(util.synth_frame(h, w, seed=17, shift=(i, i // 2), bit_depth=bd), bd) for i in range(n)]
+    with Encoder(cfg, device=0) as enc:
+        single = {}
+        for i, (y, u, v) in enumerate(frames):
+            enc.send(y, u, v, pts=i)
+        enc.flush()
+        for data, pts, key in enc.packets():
+            single[pts] = (data, key)
+        headers = enc.headers()
+    sh = ShardedEncoder(cfg, [0, 0])
+    try:
+        got = []
+        for y, u, v in frames:
+            sh.send(y, u, v)
+            got += sh.ready()
+        got += sh.finish()
+    finally:
+        sh.close()
+    assert [p for _, p, _ in got] == list(range(n))                        # presentation order, nothing missing
+    for data, pts, key in got:
+        want, wkey = single[pts]
+        assert key == wkey
+        assert data == want or (key and data.endswith(want[-64:]))        # a session's first IDR carries the parameter sets in-band
+    stream = b"".join(d for d, _, _ in got)
+    dec, _ = O.decode(stream if stream.startswith(headers[:8]) else headers + stream)
+    assert len(dec) == n
