@@ -16,14 +16,14 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (b & 7) * chunk + (b >> 3);
 }
 
-template <typename T> __global__ __launch_bounds__(NT, (sizeof(T) == 1 ? 3 : 2)) void k_me_search(const InterArgs<T> *args, int n_ctu)
+template <typename T> __global__ __launch_bounds__(NT, 3) void k_me_search(const InterArgs<T> *args, int n_ctu)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ctu = xcd_remap(blockIdx.x, n_ctu);
     if (ctu >= n_ctu) return;
     const InterArgs<T> &a = args[blockIdx.y];
     MeShared<T> &s = *reinterpret_cast<MeShared<T> *>(smem);
-    T *win = reinterpret_cast<T *>(smem + round16(sizeof(MeShared<T>)));
+    uint8_t *win = smem + round16(sizeof(MeShared<T>));
     GpuExec ex;
     me_search_program<T>(ex, s, win, a, ctu);
 }
@@ -189,7 +189,7 @@ template <typename K> static hipError_t ensure_smem(K kernel, size_t bytes)
 
 template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
 {
-    size_t smem = round16(sizeof(MeShared<T>)) + round16((size_t)me_win_elems(R) * sizeof(T));
+    size_t smem = round16(sizeof(MeShared<T>)) + round16((size_t)me_win_elems(R));      // the window holds 8-bit samples for every T
     hipError_t e = ensure_smem(k_me_search<T>, smem);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);

@@ -129,11 +129,13 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
 }
 
 // ------------------------------------------------------------------------------------------ integer search
+// source tile and search window are held as the 8 most significant bits of every sample (8-bit input: the samples themselves), so
+// Main10 searches with the packed quad-SAD too; SADs are scaled back by the dropped bits (oracle: sad_msb8)
 template <typename T> struct MeShared {
-    T src[32 * 32];
+    uint8_t src[32 * 32];
     unsigned long long best[21];
     uint8_t valid[21];
-    // followed in LDS by the search window: T win[(32 + 2R) * wstride]
+    // followed in LDS by the search window: uint8_t win[(32 + 2R) * wstride]
 };
 HDI int me_spanx(int R) { return ((2 * R + 1) + 3) & ~3; }   // horizontal positions, rounded up to whole quads
 HDI int me_win_w(int R) { return 32 + me_spanx(R); }           // columns a quad's 8-byte windows can touch
@@ -167,47 +169,40 @@ DEV void quad_block_row(const uint8_t *src, const uint8_t *ref, int ws, unsigned
 #pragma unroll
         for (int j = 0; j < 4; j++) out[b][j] = (unsigned)((acc[b] >> (16 * j)) & 0xffff);
 }
-DEV void quad_block_row(const uint16_t *src, const uint16_t *ref, int ws, unsigned (&out)[4][4])
+// window rows of a 16-bit plane reduced to their 8 most significant bits, four samples per LDS dword (same clamping as copy_window)
+DEV void copy_window_msb(uint8_t *lds, int ls, const uint16_t *plane, int pstride, int ox, int oy, int w, int h, int lo_x, int hi_x, int lo_y, int hi_y, int sh, int tid)
 {
-    // 16-bit samples: no quad-SAD instruction; v_sad_u16 on sample pairs, odd positions realigned with v_alignbyte.  Two 8x8
-    // blocks at a time: a whole block row kept 50 dwords live per lane and spilled (256 VGPRs + 56 spills at 2 workgroups per CU)
-#pragma unroll
-    for (int bp = 0; bp < 2; bp++) {
-        unsigned acc[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int r = 0; r < 8; r++) {
-            uint32_t rr[10], cc[8];
-#pragma unroll
-            for (int d = 0; d < 10; d++) rr[d] = load_u32_aligned(ref + r * ws + 16 * bp + 2 * d);
-#pragma unroll
-            for (int d = 0; d < 8; d++) cc[d] = load_u32_aligned(src + r * 32 + 16 * bp + 2 * d);
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-#pragma unroll
-                for (int d = 0; d < 8; d++) {
-                    const int k = d + (j >> 1);
-                    uint32_t v = (j & 1) ? align_bytes(rr[k + 1], rr[k], 2) : rr[k];
-                    acc[d >> 2][j] = sad_packed_u16(v, cc[d], acc[d >> 2][j]);
-                }
+    const int dpr = w / 4, col = tid & 31, rg = tid >> 5;
+    for (int r = rg; r < h; r += NT / 32) {
+        const int y = clip3(lo_y, hi_y, oy + r);
+        const uint16_t *srow = plane + (ptrdiff_t)y * pstride;
+        for (int d = col; d < dpr; d += 32) {
+            const int x = clip3(lo_x, hi_x - 3, ox + d * 4);
+            const uint32_t a = load_u32(srow + x), b = load_u32(srow + x + 2);
+            const uint32_t v = ((a & 0xffffu) >> sh) | (((a >> 16) >> sh) << 8) | (((b & 0xffffu) >> sh) << 16) | (((b >> 16) >> sh) << 24);
+            store_u32_aligned(lds + r * ls + d * 4, v);
         }
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) out[2 * bp + b][j] = acc[b][j];
     }
+}
+DEV void copy_window_msb(uint8_t *lds, int ls, const uint8_t *plane, int pstride, int ox, int oy, int w, int h, int lo_x, int hi_x, int lo_y, int hi_y, int, int tid)
+{
+    copy_window<uint8_t>(lds, ls, plane, pstride, ox, oy, w, h, lo_x, hi_x, lo_y, hi_y, tid);
 }
 
 template <typename T, class Ex>
-DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a, int ctu)
+DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs<T> &a, int ctu)
 {
+    const int msb = a.prm.bit_depth - 8;       // bits dropped from every sample for the search
+
     const int R = a.prm.me_range, spany = 2 * R + 1, spanx = me_spanx(R), quads = spanx >> 2, ws = me_win_stride(R), ww = me_win_w(R), wh = 32 + 2 * R;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
     const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
     ex.phase([&](int tid) {
         for (int i = tid; i < 1024; i += NT) {
             int x = x0 + (i & 31), y = y0 + (i >> 5);
-            s.src[i] = (x < a.w && y < a.h) ? a.src[0].p[(size_t)y * a.src[0].stride + x] : (T)0;
+            s.src[i] = (x < a.w && y < a.h) ? (uint8_t)(a.src[0].p[(size_t)y * a.src[0].stride + x] >> msb) : (uint8_t)0;
         }
-        copy_window<T>(win, ws, a.ref[0].p, a.ref[0].stride, x0 + sx - R, y0 + sy - R, ww, wh, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, tid);
+        copy_window_msb(win, ws, a.ref[0].p, a.ref[0].stride, x0 + sx - R, y0 + sy - R, ww, wh, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, msb, tid);
         if (tid < 21) {
             int nx, ny, nl;
             node_geom(tid, nx, ny, nl);
@@ -225,7 +220,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
         for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
             const int q = item % quads, dyi = item / quads;
             const int by = mvd_bits(4 * (dyi - R));
-            const T *srcp = s.src + opaque_zero();      // keep the 1 KiB source tile in LDS (hoisted into 256 VGPRs otherwise)
+            const uint8_t *srcp = s.src + opaque_zero();      // keep the 1 KiB source tile in LDS (hoisted into 256 VGPRs otherwise)
             unsigned bits[4], pos[4], s32[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -240,6 +235,10 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, T *win, const InterArgs<T> &a
                     const int br = half * 2 + r2;
                     unsigned o[4][4];
                     quad_block_row(srcp + br * 8 * 32, win + (br * 8 + dyi) * ws + 4 * q, ws, o);
+#pragma unroll
+                    for (int b = 0; b < 4; b++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) o[b][j] <<= msb;
 #pragma unroll
                     for (int b = 0; b < 4; b++) {
                         const int node = 5 + (half * 2 + (b >> 1)) * 4 + r2 * 2 + (b & 1);

@@ -71,7 +71,7 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
         for (int c = 0; c < n_ctu; c++) { PreShared ps; pre_search_program<T>(ex, ps, pa, c); }
         a.centers = cen.data();
     }
-    std::vector<T> win((size_t)me_win_elems(R) + 8);
+    std::vector<uint8_t> win((size_t)me_win_elems(R) + 8);
     std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16), wu((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16), wv(wu.size());
     for (int c = 0; c < n_ctu; c++) {
         MeShared<T> *ms = new MeShared<T>();
