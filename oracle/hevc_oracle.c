@@ -854,8 +854,6 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
     free(sad8);
     if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers);
     free(own_centers);
-    return;
-    if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers);
 }
 
 /* ================================================================================================
