@@ -35,7 +35,7 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     cfg = _lib.default_config()
     cfg.width, cfg.height = width, height
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and NxN trial the device path runs
-    prm_i.intra_nxn = cfg.intra_nxn
+    prm_i.intra_nxn, prm_i.chroma_modes = cfg.intra_nxn, cfg.chroma_modes
     prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero
     t0 = time.perf_counter()
     ref = None

@@ -54,6 +54,7 @@ struct CostParams {
     int intra_in_p;               // 1: P pictures run the intra second pass (kernels/intra.h intra_p_eligible)
     int pre_search;               // 1: search centres come from a +-PRE_RANGE full search on the 1/4-size pictures (kernels/inter.h)
     int rdo_zero;                 // 1: inter TUs whose levels cost more than the distortion they remove are zeroed (inter_ctu_program)
+    int chroma_modes;             // 1: 2Nx2N intra CUs choose among DM / planar / 26 / 10 / DC for chroma (intra_cu)
 };
 constexpr int PRE_RANGE = 14;     // low-resolution samples: centres reach +-56 luma samples, window reads stay inside the 80-sample border
 // per-CTU hand-over from the inter pass of a P picture to its intra second pass

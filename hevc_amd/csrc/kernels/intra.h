@@ -87,6 +87,8 @@ template <typename T> struct IntraShared {
     unsigned nx_sse;
     int nx_bits, nx_keep;
     unsigned nx_cbf_c;           // CU_CBF_CB / CU_CBF_CR of the NxN trial
+    unsigned csatd[5];           // chroma mode candidates (0 = DM, 1..4 = planar / 26 / 10 / DC): SATD over Cb + Cr
+    int cmode, cmode_k;          // chosen chroma prediction mode and its candidate index
     int16_t nx_mat[2][16];       // 4x4 DST-VII and DCT matrices [k * 4 + n]
     int16_t tab_angle[35], tab_inv[35];   // Tables 8-4 / 8-5 by mode, LDS copies: a global read per use sat on the serial chain
     int16_t tab_qs[6], tab_ls[6];
@@ -137,7 +139,8 @@ DEV int mode_inv_angle(int mode) { return (mode >= 11 && mode <= 25) ? g_tab.inv
 // intra_sample, with everything that depends only on the mode / row hoisted out of the sample loop (the SATD mode
 // search runs 35 x (N/8)^2 of these per CU and dominated k_intra_diag: profiles/r01_a_first)
 template <typename T>
-DEV void intra_tile_diff(const T *L, int log2n, int mode, int angle, int inv, int tx, int ty, int bit_depth, int dc, const T *src, int src_stride, int (&m)[8][8])
+DEV void intra_tile_diff(const T *L, int log2n, int mode, int angle, int inv, int tx, int ty, int bit_depth, int dc, const T *src, int src_stride, int (&m)[8][8],
+                         bool luma = true)      // chroma blocks get no DC / mode 10 / mode 26 edge smoothing (8.4.4.2.5, 8.4.4.2.6)
 {
     const int n = 1 << log2n;
     if (mode == 0) {
@@ -157,7 +160,7 @@ DEV void intra_tile_diff(const T *L, int log2n, int mode, int angle, int inv, in
         return;
     }
     if (mode == 1) {
-        const bool edge = n < 32;
+        const bool edge = luma && n < 32;
 #pragma unroll
         for (int j = 0; j < 8; j++)
 #pragma unroll
@@ -190,7 +193,7 @@ DEV void intra_tile_diff(const T *L, int log2n, int mode, int angle, int inv, in
 #pragma unroll
         for (int bi = 0; bi < 8; bi++) {
             int v = f ? ((32 - f) * r[bi] + f * r[bi + 1] + 16) >> 5 : r[bi];
-            if (angle == 0 && n < 32 && b0 + bi == 0) {
+            if (luma && angle == 0 && n < 32 && b0 + bi == 0) {
                 const int corner = L[2 * n];
                 v = vertical ? ref_top(L, n, 0) + ((ref_left(L, n, a) - corner) >> 1) : ref_left(L, n, 0) + ((ref_top(L, n, a) - corner) >> 1);
                 v = clip3(0, maxv, v);
@@ -366,10 +369,63 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             s.rs.tu_intra[t] = 1;
         }
         if (tid >= 80 && tid < 83) s.rs.cbf[tid - 80] = 0;
+        if (tid >= 96 && tid < 101) s.csatd[tid - 96] = 0;
+        if (tid == 101) { s.cmode_k = 0; }
     });
-    // prediction of the chosen mode (luma) and DM chroma, residual
+    // intra_chroma_pred_mode (oracle intra_cu): DM or planar / 26 / 10 / DC (a candidate equal to the luma mode stands for 34), by SATD
+    // over Cb + Cr + lambda * (1 bit DM, 3 bits otherwise); DM wins ties
+    if (a.prm.chroma_modes) {
+        ex.phase([&](int tid) {
+            const int mode = (int)(s.mode_key & 63), l2c = log2n - 1, nc = n >> 1, ct = nc >= 8 ? nc >> 3 : 1, ntc = ct * ct;
+            for (int u = tid; u < 5 * 2 * ntc; u += NT) {
+                const int k = u / (2 * ntc), pl = 1 + (u / ntc) % 2, t = u % ntc;
+                const int base = k == 1 ? 0 : k == 2 ? 26 : k == 3 ? 10 : 1, m = k == 0 ? mode : (base == mode ? 34 : base);
+                const T *L = s.ref[pl];
+                const int sbase = 1024 + (pl - 1) * 256 + (cy >> 1) * 16 + (cx >> 1);
+                int satd;
+                if (nc == 4) {
+                    int d[16];
+                    const int ang = s.tab_angle[m], inv = s.tab_inv[m];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) d[i] = (int)s.src[sbase + (i >> 2) * 16 + (i & 3)] - intra_sample<T>(L, 2, m, ang, inv, i & 3, i >> 2, pl, bd, s.dc_val[pl]);
+#pragma unroll
+                    for (int y = 0; y < 4; y++) {
+                        int p0 = d[y * 4] + d[y * 4 + 1], p1 = d[y * 4] - d[y * 4 + 1], p2 = d[y * 4 + 2] + d[y * 4 + 3], p3 = d[y * 4 + 2] - d[y * 4 + 3];
+                        d[y * 4] = p0 + p2; d[y * 4 + 1] = p1 + p3; d[y * 4 + 2] = p0 - p2; d[y * 4 + 3] = p1 - p3;
+                    }
+                    int sum = 0;
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        int p0 = d[x] + d[4 + x], p1 = d[x] - d[4 + x], p2 = d[8 + x] + d[12 + x], p3 = d[8 + x] - d[12 + x];
+                        sum += iabs(p0 + p2) + iabs(p1 + p3) + iabs(p0 - p2) + iabs(p1 - p3);
+                    }
+                    satd = (sum + 1) >> 1;
+                } else {
+                    int mm[8][8];
+                    const int tx = (t % ct) * 8, ty = (t / ct) * 8;
+                    intra_tile_diff<T>(L, l2c, m, s.tab_angle[m], s.tab_inv[m], tx, ty, bd, s.dc_val[pl], s.src + sbase + ty * 16 + tx, 16, mm, false);
+                    satd = hadamard8_satd(mm);
+                }
+                ex.atomic_add(&s.csatd[k], (unsigned)satd);
+            }
+        });
+        ex.phase([&](int tid) {
+            if (tid != 0) return;
+            const int mode = (int)(s.mode_key & 63);
+            unsigned long long best = ~0ull;
+            for (int k = 0; k < 5; k++) {
+                const unsigned long long key = ((unsigned long long)((s.csatd[k] << 4) + (unsigned)(a.prm.lambda_sad_q4 * (k == 0 ? 1 : 3))) << 3) | (unsigned)k;
+                best = key < best ? key : best;
+            }
+            const int k = (int)(best & 7), base = k == 1 ? 0 : k == 2 ? 26 : k == 3 ? 10 : 1;
+            s.cmode_k = k;
+            s.cmode = k == 0 ? mode : (base == mode ? 34 : base);
+        });
+    }
+    // prediction of the chosen mode (luma) and the chosen chroma mode (DM unless prm.chroma_modes), residual
     ex.phase([&](int tid) {
-        const int mode = (int)(s.mode_key & 63);
+        const int mode = (int)(s.mode_key & 63), cmode = s.cmode_k ? s.cmode : mode;
+        const int cang = s.tab_angle[cmode], cinv = s.tab_inv[cmode];
         const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
         const int ang = s.tab_angle[mode], inv = s.tab_inv[mode];
         for (int k = tid; k < rcnt; k += NT) {
@@ -379,7 +435,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             if (!l.log2n) continue;
             int v;
             if (l.plane == 0) v = intra_sample<T>(L, log2n, mode, ang, inv, l.x - cx, l.y - cy, 0, bd, s.dc_val[0]);
-            else v = intra_sample<T>(s.ref[l.plane], log2n - 1, mode, ang, inv, l.x - (cx >> 1), l.y - (cy >> 1), l.plane, bd, s.dc_val[l.plane]);
+            else v = intra_sample<T>(s.ref[l.plane], log2n - 1, cmode, cang, cinv, l.x - (cx >> 1), l.y - (cy >> 1), l.plane, bd, s.dc_val[l.plane]);
             s.pred[i] = (T)v;
             s.rs.res[i] = (int16_t)((int)s.src[i] - v);
         }
@@ -417,14 +473,14 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             mihevc_cu_rec r;
             r.log2_size = (uint8_t)log2n;
             r.flags = (uint8_t)(((s.rs.cbf[0] >> t0) & 1 ? CU_CBF_Y : 0) | ((s.rs.cbf[1] >> t0) & 1 ? CU_CBF_CB : 0) | ((s.rs.cbf[2] >> t0) & 1 ? CU_CBF_CR : 0));
-            r.chroma_mode = (uint8_t)mode; r.qp = (uint8_t)a.prm.qp;
+            r.chroma_mode = (uint8_t)(s.cmode_k ? s.cmode : mode); r.qp = (uint8_t)a.prm.qp;
             r.intra_mode[0] = r.intra_mode[1] = r.intra_mode[2] = r.intra_mode[3] = (uint8_t)mode;
             r.mvx = r.mvy = 0; r.cbf_y4 = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
             s.cu_acc[tid] = r;
         }
         if (tid == 0) {
             int mb = mode == s.cand[0] ? 2 : (mode == s.cand[1] || mode == s.cand[2]) ? 3 : 6;
-            int bits = 16 * mb + 16 + 24;
+            int bits = 16 * mb + 16 + 24 + (s.cmode_k ? 32 : 0);
             for (int p = 0; p < 3; p++) bits += s.bits[p] ? s.bits[p] + 16 : 0;
             s.j_cu = ((unsigned long long)s.sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)bits) >> 4);
         }

@@ -74,7 +74,8 @@ typedef struct mihevc_config {
                                        * integer search follows motion up to +-56 samples; 0: centres at zero */
     int32_t rdo_zero;                 /* 1 (default): inter TUs whose levels cost more (lambda x bits) than the distortion they remove are
                                        * coded as all-zero (-2.5 % bits at -0.01 dB on the bench clip's P pictures) */
-    int32_t reserved[1];
+    int32_t chroma_modes;             /* 1 (default): 2Nx2N intra CUs choose intra_chroma_pred_mode among DM / planar / vertical / horizontal /
+                                       * DC by SATD over Cb + Cr; 0: always DM */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -130,6 +131,7 @@ typedef struct mihevc_cost_params {
     int32_t intra_in_p;               /* 1: mihevc_k_inter_frame also runs the intra second pass of P pictures */
     int32_t pre_search;               /* 1: without explicit centres, mihevc_k_inter_frame derives them from the 1/4-size pictures */
     int32_t rdo_zero;                 /* 1: RD zero-out of inter TUs */
+    int32_t chroma_modes;             /* 1: chroma intra mode decision (else DM) */
 } mihevc_cost_params;
 void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, every analysis knob 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every

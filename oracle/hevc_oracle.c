@@ -925,10 +925,33 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
     if (code_tu(s, c->sstride[0], pred, n, c->rec[0] + y * c->rstride[0] + x, c->rstride[0],
                 c->coef[0] + y * c->w + x, c->w, log2n, prm->qp, bd, 1, 0, &sse, &bits)) flags |= ORC_F_CBF_Y;
     sse_total += sse; bits_total += bits;
+    /* intra_chroma_pred_mode (7.4.9.6 / Table 8-2): DM (= the luma mode) or planar / vertical / horizontal / DC, where a candidate equal
+     * to the luma mode stands for mode 34.  Chosen by SATD over Cb + Cr plus lambda * (1 bit for DM, 3 for the others); DM wins ties. */
+    int cmode = mode;
+    if (prm->chroma_modes) {
+        static const int base[4] = {0, 26, 10, 1};
+        int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
+        pix refc[2][129];
+        for (int ci = 1; ci < 3; ci++)
+            orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, refc[ci - 1]);
+        uint64_t bestc = ~0ull;
+        for (int k = 0; k < 5; k++) {
+            int m = k == 0 ? mode : (base[k - 1] == mode ? 34 : base[k - 1]);
+            uint32_t satd = 0;
+            for (int ci = 1; ci < 3; ci++) {
+                orc_intra_pred(refc[ci - 1], pred, nc, l2, m, ci, bd);
+                satd += (uint32_t)orc_satd(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc, nc, nc);
+            }
+            uint64_t key = ((uint64_t)((satd << 4) + (uint32_t)(prm->lambda_sad_q4 * (k == 0 ? 1 : 3))) << 3) | (uint32_t)k;
+            if (key < bestc) bestc = key;
+        }
+        int k = (int)(bestc & 7);
+        if (k) { cmode = base[k - 1] == mode ? 34 : base[k - 1]; bits_total += 32; }
+    }
     for (int ci = 1; ci < 3; ci++) {
         int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
         orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
-        orc_intra_pred(ref, pred, nc, l2, mode, ci, bd);
+        orc_intra_pred(ref, pred, nc, l2, cmode, ci, bd);
         if (code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc,
                     c->rec[ci] + yc * c->rstride[ci] + xc, c->rstride[ci], c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1,
                     l2, prm->qp_c, bd, 1, 0, &sse, &bits)) flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
@@ -940,7 +963,7 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
             memset(r, 0, sizeof *r);
             r->log2_size = (uint8_t)log2n; r->flags = (uint8_t)flags; r->qp = (uint8_t)prm->qp;
             r->intra_mode[0] = r->intra_mode[1] = r->intra_mode[2] = r->intra_mode[3] = (uint8_t)mode;
-            r->chroma_mode = (uint8_t)mode;
+            r->chroma_mode = (uint8_t)cmode;
         }
     return ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);
 }

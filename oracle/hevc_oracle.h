@@ -72,6 +72,7 @@ typedef struct {
     int intra_in_p;           /* 1: P pictures get a second pass that re-codes badly predicted CTUs as intra (see orc_analyze_inter_frame) */
     int pre_search;           /* 1: when no search centres are given, take them from a +-14 full search on the 1/4-size pictures (+-56 samples) */
     int rdo_zero;             /* 1: an inter TU whose levels cost more (lambda * bits) than the distortion they remove is coded as all-zero */
+    int chroma_modes;         /* 1: 2Nx2N intra CUs choose intra_chroma_pred_mode among planar / vertical / horizontal / DC / DM by SATD */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */

@@ -28,7 +28,7 @@ def build(force: bool = False) -> Path:
 
 class Params(C.Structure):
     _fields_ = [("qp", C.c_int), ("qp_c", C.c_int), ("bit_depth", C.c_int), ("lambda_sad_q4", C.c_int),
-                ("lambda_q4", C.c_int), ("me_range", C.c_int), ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("intra_nxn", C.c_int), ("intra_in_p", C.c_int), ("pre_search", C.c_int), ("rdo_zero", C.c_int)]
+                ("lambda_q4", C.c_int), ("me_range", C.c_int), ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("intra_nxn", C.c_int), ("intra_in_p", C.c_int), ("pre_search", C.c_int), ("rdo_zero", C.c_int), ("chroma_modes", C.c_int)]
 
 
 CU_DTYPE = np.dtype([("log2_size", "u1"), ("flags", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("intra_mode", "u1", (4,)),
@@ -59,7 +59,7 @@ def _p(a):
 def default_params(qp: int, bit_depth: int = 8, me_range: int = 16) -> Params:
     """Same integer cost parameters the product derives (mihevc_cost_params): lambda = 0.57 * 2^((qp-12)/3)."""
     lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
-    return Params(qp, int(lib().orc_chroma_qp(qp)), bit_depth, int(round(16 * lam ** 0.5)), int(round(16 * lam)), me_range, 1, 1, 0, 0, 0, 0)
+    return Params(qp, int(lib().orc_chroma_qp(qp)), bit_depth, int(round(16 * lam ** 0.5)), int(round(16 * lam)), me_range, 1, 1, 0, 0, 0, 0, 0)
 
 
 # ---------------------------------------------------------------- primitives

@@ -69,6 +69,7 @@ def test_stage_parity_i_p_p(lib, api, w, h, qp, bd, rng):
     prm_i, cp_i = lib_params(lib, max(0, qp - 3), bd, rng)
     prm_p, cp_p = lib_params(lib, qp, bd, rng)
     prm_p.rdo_zero = cp_p.rdo_zero = int(qp >= 24)       # RD zero-out of inter TUs on for the higher QPs, off for the rest
+    prm_i.chroma_modes = cp_i.chroma_modes = int(qp < 35)  # chroma intra mode decision
     srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
     want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
     ref = None
@@ -91,6 +92,7 @@ def test_intra_tile_grid_parity(lib, api, w, h, grid, qp, bd):
     prm, cp = lib_params(lib, qp, bd, 8)
     prm.tile_cols, prm.tile_rows = grid
     cp.tile_cols, cp.tile_rows = grid
+    prm.chroma_modes = cp.chroma_modes = 1
     src = util.synth_frame(h, w, seed=9, bit_depth=bd)
     want, got = O.analyze_intra(src, prm), api.intra(src, cp)
     assert util.same_analysis(want, got), util.describe_diff(want, got)
@@ -206,6 +208,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_p, _ = lib_params(lib, qp_p, bd, 8)
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
     prm_i.intra_nxn = prm_p.intra_nxn = cfg.intra_nxn            # NxN trial when the session asks for it
+    prm_i.chroma_modes = prm_p.chroma_modes = cfg.chroma_modes   # default 1
     prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero   # session defaults: pre-search and RD zero-out on
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     ref = None
@@ -263,6 +266,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
         prm.intra_nxn, prm.intra_in_p, prm.pre_search, prm.rdo_zero = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero
+        prm.chroma_modes = cfg.chroma_modes
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"

@@ -38,6 +38,7 @@ def test_stepped_kernels_equal_oracle(emu, w, h, qp, bd, rng):
     prm_i = O.default_params(max(0, qp - 3), bit_depth=bd, me_range=rng)
     prm_p = O.default_params(qp, bit_depth=bd, me_range=rng)
     prm_p.rdo_zero = int(qp >= 26)               # RD zero-out of inter TUs on for the higher QPs (where it bites), off for the rest
+    prm_i.chroma_modes = int(qp < 35)            # chroma intra mode decision on for most cases (4x4, 8x8 and 16x16 chroma blocks)
     srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
     want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
     ref = None
@@ -75,6 +76,7 @@ def test_stepped_intra_nxn(emu, w, h, grid, qp, bd):
     prm = O.default_params(qp, bit_depth=bd)
     prm.tile_cols, prm.tile_rows = grid
     prm.intra_nxn = 1
+    prm.chroma_modes = int(bd == 8)
     src = util.synth_frame(h, w, seed=31, bit_depth=bd)
     want, got = O.analyze_intra(src, prm), emu.intra(src, prm)
     assert (want.cu["flags"] & 16).any(), "content must make NxN win somewhere"
@@ -86,7 +88,7 @@ def test_stepped_intra_second_pass_of_p_pictures(emu, w, h, qp, bd, nxn):
     """P pictures: CTUs the reference cannot predict are re-coded as intra in two independent-set rounds, exactly as the oracle."""
     from tests.test_bitstream_cpu import occluded_clip
     prm = O.default_params(qp, bit_depth=bd, me_range=8)
-    prm.intra_in_p, prm.intra_nxn = 1, nxn
+    prm.intra_in_p, prm.intra_nxn, prm.chroma_modes = 1, nxn, 1
     srcs = occluded_clip(w, h, bd)
     ref = O.sao(srcs[0], O.deblock(*(lambda a: (a.rec, a.cu))(O.analyze_intra(srcs[0], prm)), bd), prm)[0]
     for i in (1, 2):
