@@ -52,8 +52,12 @@ void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_
     int qpi = qp < -12 ? -12 : qp > 57 ? 57 : qp;
     out->qp_c = qpi < 30 ? qpi : qpi > 43 ? qpi - 6 : tab[qpi - 30];   // Table 8-10, cb/cr offsets 0
     out->bit_depth = bit_depth;
-    out->lambda_sad_q4 = (int)std::lround(16.0 * std::sqrt(lam));
-    out->lambda_q4 = (int)std::lround(16.0 * lam);
+    // distortions are measured on the samples as they are, so at 10 bit an SSE is 16x and a SAD/SATD 4x its 8-bit value: scale the
+    // multipliers instead of shifting every distortion (HM shifts the distortion; same trade-off).  Without this Main10 decisions ran
+    // with a 16x too small lambda: SAO parameters alone cost 72 bits per CTU on the 2160p bench clip.
+    const int sh = bit_depth - 8;
+    out->lambda_sad_q4 = (int)std::lround(16.0 * std::sqrt(lam)) << sh;
+    out->lambda_q4 = (int)std::lround(16.0 * lam) << (2 * sh);
     out->me_range = me_range > 0 ? me_range : 15;
     out->tile_cols = out->tile_rows = 1;
     out->intra_nxn = 0;

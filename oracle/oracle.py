@@ -59,7 +59,8 @@ def _p(a):
 def default_params(qp: int, bit_depth: int = 8, me_range: int = 16) -> Params:
     """Same integer cost parameters the product derives (mihevc_cost_params): lambda = 0.57 * 2^((qp-12)/3)."""
     lam = 0.57 * 2.0 ** ((qp - 12) / 3.0)
-    return Params(qp, int(lib().orc_chroma_qp(qp)), bit_depth, int(round(16 * lam ** 0.5)), int(round(16 * lam)), me_range, 1, 1, 0, 0, 0, 0, 0)
+    sh = bit_depth - 8          # distortions grow 4x (SAD) / 16x (SSE) from 8 to 10 bit: the multipliers follow
+    return Params(qp, int(lib().orc_chroma_qp(qp)), bit_depth, int(round(16 * lam ** 0.5)) << sh, int(round(16 * lam)) << (2 * sh), me_range, 1, 1, 0, 0, 0, 0, 0)
 
 
 # ---------------------------------------------------------------- primitives
