@@ -30,7 +30,9 @@ using namespace mihevc;
 
 namespace {
 
-constexpr int kRing = 8;      // symbol slots per lane: 0..2 hold the IDR picture's QP variants, 3..7 rotate over the P steps
+constexpr int kRing = 12;     // symbol slots per lane (capacity): 0..2 hold the IDR picture's QP variants, the rest rotate over the P steps.
+                              // A session uses s->ring of them: 8 up to 1080p-class levels, 12 from level 5 (2160p+), where the CABAC of one
+                              // picture (12 ms at 2160p, 45 ms at 4320p) outlasts five device steps when few GOP lanes are busy
 constexpr int kVariants = 3;  // IDR pictures under rate control are analysed at QP, QP+5, QP+10 in ONE set of launches
 constexpr int kVariantStep = 5;
 
@@ -175,6 +177,7 @@ struct mihevc_session {
     std::mutex m;
     std::condition_variable cv;
     int jobs_open[kRing] = {0};
+    int ring = 8;                 // slots in use (<= kRing)
     std::map<int64_t, Packet> packets;     // by output index
     int64_t next_out = 0, frames_in = 0, frames_done = 0;
     std::vector<uint8_t> headers, cur_packet;
@@ -237,7 +240,7 @@ int ensure_lanes(mihevc_session *s, int n)
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lsrc));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lref));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, (void **)&L.centers));
-        for (int k = 0; k < kRing; k++) {
+        for (int k = 0; k < s->ring; k++) {
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, true, (void **)&L.sym_host[k]));
         }
@@ -326,7 +329,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
     if (int e = ensure_lanes(s, gops)) return e;
     SymLayout sl(s->w, s->h);
     const int steps = std::min(n, s->keyint);
-    auto slot_of = [](int t) { return t == 0 ? 0 : kVariants + (t - 1) % (kRing - kVariants); };      // IDR variant v lives in slot v
+    const int ring = s->ring;
+    auto slot_of = [ring](int t) { return t == 0 ? 0 : kVariants + (t - 1) % (ring - kVariants); };      // IDR variant v lives in slot v
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
     const size_t need = (size_t)steps * lay.total;
@@ -410,7 +414,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         budget[g] = s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
     }
     const double w_i = 8.0;                   // an IDR picture is budgeted like 8 P pictures
-    const int p_slots = kRing - kVariants;    // a P step's CABAC job is complete once its slot has been handed out again
+    const int p_slots = s->ring - kVariants;  // a P step's CABAC job is complete once its slot has been handed out again
     // P-picture QP of lane g at step t.  Every input is deterministic: CABAC sizes only of pictures whose ring slot has been
     // reused (steps <= t - p_slots), device estimates of steps <= t - 2 (the step loop waits for that copy), a model for the
     // picture in flight.  The controller solves for the constant QP that spends the rest of the GOP budget and walks towards
@@ -711,6 +715,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->w = cs.w; s->h = cs.h;
     s->ctus_w = (s->w + CTU - 1) / CTU; s->ctus_h = (s->h + CTU - 1) / CTU; s->n_ctu = s->ctus_w * s->ctus_h;
     s->tiles = tile_grid(s->cfg);
+    s->ring = cfg->level_idc >= 150 ? kRing : 8;
     s->is16 = cfg->bit_depth > 8;
     s->keyint = cfg->keyint;
     s->lanes = cfg->gops_in_flight > 0 ? std::min(cfg->gops_in_flight, 16) : 4;
@@ -881,7 +886,7 @@ void mihevc_close(mihevc_session *s)
         bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lsrc);
         bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lref);
         bc.release(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, L.centers);
-        for (int k = 0; k < kRing; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
+        for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     if (s->d_args) (void)hipFree(s->d_args);
     if (s->h_args) (void)hipHostFree(s->h_args);

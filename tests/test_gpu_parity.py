@@ -190,6 +190,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud, cfg.intra_nxn, cfg.intra_in_p = 27, 8, 2, 1, nxn, ipass
     if bd == 10:
         cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers, cfg.hrd = 1, 9, 16, 9, 0, 1, 1
+        cfg.level_idc = 150                  # level 5: the session uses the deeper (12-slot) symbol ring
     frames = [util.synth_frame(h, w, seed=9, shift=(i, i // 2), bit_depth=bd) for i in range(n)]
     if ipass:          # paste an unrelated patch into every second picture so the intra second pass has work
         for i in range(1, n, 2):
