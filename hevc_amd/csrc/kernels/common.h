@@ -56,6 +56,11 @@ struct CostParams {
     int rdo_zero;                 // 1: inter TUs whose levels cost more than the distortion they remove are zeroed (inter_ctu_program)
     int chroma_modes;             // 1: 2Nx2N intra CUs choose among DM / planar / 26 / 10 / DC for chroma (intra_cu)
 };
+// rate model in 1/16 bit (oracle/hevc_oracle.c ORC_R_*, fitted to the host CABAC): a level, a 4x4 sub-block with a level, a TU with a level,
+// an inter CU, an intra CU
+DEV int rate_level(int a) { return a == 1 ? 33 : a == 2 ? 50 : 53 + 27 * (31 - __builtin_clz((unsigned)(a - 1) | 1)); }
+constexpr int R_SB = 143, R_TU = 30;
+constexpr unsigned R_INTER_CU = 80, R_INTRA_CU = 128;
 constexpr int PRE_RANGE = 14;     // low-resolution samples: centres reach +-56 luma samples, window reads stay inside the 80-sample border
 // per-CTU hand-over from the inter pass of a P picture to its intra second pass
 struct IpInfo {

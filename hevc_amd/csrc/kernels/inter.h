@@ -735,7 +735,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             const int pl = tid >> 4, t = tid & 15;
             if (!((s.rs.cbf[pl] >> t) & 1) || !s.tu_bits[pl][t]) return;      // only a TU's first tile carries its cbf bit and sums
             const unsigned long long jz = (unsigned long long)s.tu_dz[pl][t] << 4;
-            const unsigned long long jc = ((unsigned long long)s.tu_dc[pl][t] << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)(s.tu_bits[pl][t] + 16)) >> 4);
+            const unsigned long long jc = ((unsigned long long)s.tu_dc[pl][t] << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)(s.tu_bits[pl][t] + R_TU)) >> 4);
             if (jz <= jc) ex.atomic_or(&s.tu_zero[pl], 1u << t);
         });
         ex.phase([&](int tid) {
@@ -775,7 +775,8 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             if (tid < 16 && s.rs.tu_log2[tid]) {
                 int nx, ny, nl;
                 node_geom(s.tile_node[tid], nx, ny, nl);
-                if ((ny >> 3) * 4 + (nx >> 3) == tid) e += 16u * (unsigned)(6 + mvd_bits(s.tile_mvx[tid] - 4 * sx) + mvd_bits(s.tile_mvy[tid] - 4 * sy));
+                if ((ny >> 3) * 4 + (nx >> 3) == tid)
+                    e += R_INTER_CU + (unsigned)(R_TU * (int)(((s.rs.cbf[0] >> tid) & 1) + ((s.rs.cbf[1] >> tid) & 1) + ((s.rs.cbf[2] >> tid) & 1)));
             }
             if (e) ex.atomic_add(&s.est, e);
         }

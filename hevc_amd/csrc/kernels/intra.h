@@ -481,7 +481,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         if (tid == 0) {
             int mb = mode == s.cand[0] ? 2 : (mode == s.cand[1] || mode == s.cand[2]) ? 3 : 6;
             int bits = 16 * mb + 16 + 24 + (s.cmode_k ? 32 : 0);
-            for (int p = 0; p < 3; p++) bits += s.bits[p] ? s.bits[p] + 16 : 0;
+            for (int p = 0; p < 3; p++) bits += s.bits[p] ? s.bits[p] + R_TU : 0;
             s.j_cu = ((unsigned long long)s.sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)bits) >> 4);
         }
     });
@@ -653,9 +653,9 @@ DEV void intra_cu_nxn(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, 
             if (luma) s.rec_y[(by + y + 1) * RY_STRIDE + bx + x + 1] = (T)v; else s.rec_c[pl - 1][(by + y + 1) * RC_STRIDE + bx + x + 1] = (T)v;
             s.coef_acc[sidx] = w.lvl[g][i];
             const int d = (int)s.src[sidx] - v, al = iabs((int)w.lvl[g][i]);
-            int bits = al ? (al == 1 ? 40 : al == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(al - 1))) : 0;
+            int bits = al ? rate_level(al) : 0;
             if (i == 0) {
-                if (nz) bits += 24 + 16;
+                if (nz) bits += R_SB + R_TU;
                 if (luma) {
                     const int mode = (int)(s.mode_key & 63);
                     int cand[3];
@@ -818,7 +818,11 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             if (tid < 16) {
                 int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
                 const mihevc_cu_rec &r = s.cu_acc[tid];
-                if (x0 + tx < a.w && y0 + ty < a.h && !(tx & ((1 << r.log2_size) - 1)) && !(ty & ((1 << r.log2_size) - 1))) e += 16u * 8u;
+                if (x0 + tx < a.w && y0 + ty < a.h && !(tx & ((1 << r.log2_size) - 1)) && !(ty & ((1 << r.log2_size) - 1))) {
+                    int ncbf = ((r.flags & CU_CBF_CB) != 0) + ((r.flags & CU_CBF_CR) != 0);
+                    if (r.flags & CU_NXN) { for (int k = 0; k < 4; k++) ncbf += (r.cbf_y4 >> k) & 1; } else ncbf += (r.flags & CU_CBF_Y) != 0;
+                    e += R_INTRA_CU + (unsigned)(R_TU * ncbf);
+                }
             }
             if (e) ex.atomic_add(&s.est, e);
         }

@@ -186,9 +186,9 @@ DEV int subblock_bits_q4(const int16_t *lv, int stride)
             int a = iabs(lv[y * stride + x]);
             if (!a) continue;
             any = 1;
-            bits += a == 1 ? 40 : a == 2 ? 60 : 64 + 32 * ilog2u((unsigned)(a - 1));
+            bits += rate_level(a);
         }
-    return any ? bits + 24 : 0;
+    return any ? bits + R_SB : 0;
 }
 
 }  // namespace mihevc
