@@ -186,7 +186,7 @@ struct mihevc_session {
     // rate control (VBV-capped constant quality, one controller per GOP lane): see DESIGN.md §Rate control
     bool rc_on = false;
     double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
-    double rho_pi = 1.0 / 12.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
+    double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
     std::atomic<long long> entropy_ns{0};
