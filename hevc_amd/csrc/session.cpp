@@ -631,6 +631,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             int st = t == 0 ? 2 : 1, qp = qp_step[g];
             bool first = index == 0;
             s->pool->submit([s, slot, g, index, pts, st, t, qp, first, ev] {
+                (void)hipSetDevice(s->device);          // worker threads start on device 0: wait on the event in its own device's context
                 (void)hipEventSynchronize(ev);
                 entropy_job(s, slot, g, index, pts, st, t, qp, first);
             });
