@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -186,6 +187,7 @@ struct mihevc_session {
     // rate control (VBV-capped constant quality, one controller per GOP lane): see DESIGN.md §Rate control
     bool rc_on = false;
     double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
+    bool rho_measured = false;                // the session's first chunk measures rho with a trial analysis of the GOPs' first P picture
     double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
@@ -333,7 +335,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto slot_of = [ring](int t) { return t == 0 ? 0 : kVariants + (t - 1) % (ring - kVariants); };      // IDR variant v lives in slot v
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
-    const size_t need = (size_t)steps * lay.total;
+    const size_t need = (size_t)(steps + 1) * lay.total;      // + one block for the rho trial (below)
     if (need > s->args_cap) {
         if (s->d_args) (void)hipFree(s->d_args);
         if (s->h_args) (void)hipHostFree(s->h_args);
@@ -533,27 +535,78 @@ template <typename T> int encode_chunk(mihevc_session *s)
             STAGE(0, nv * B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, nv * B, s->tiles.cols, s->tiles.rows));
             if (nv > 1) {
                 HIPCK(s, hipStreamSynchronize(s->st_compute));
-                for (int g = 0; g < B; g++) {
-                    const double alloc = budget[g] * w_i / (w_i + gop_len[g] - 1);
-                    unsigned long long e[kVariants] = {0};
+                // estimates of every variant, then the pick: the variant whose predicted steady P QP sits closest to IDR QP + 3 (the usual
+                // I/P offset).  P size at the IDR's QP is modelled as rho x IDR size, the rest of the budget is shared by the GOP's P pictures.
+                std::vector<std::array<unsigned long long, kVariants>> ev((size_t)B);
+                for (int g = 0; g < B; g++)
+                    for (int v = 0; v < nv; v++) HIPCK(s, hipMemcpy(&ev[(size_t)g][(size_t)v], s->lane[g].sym_dev[v] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                const std::vector<int> qp_base(qp_step);
+                auto pick_for = [&](int g, double rho) {
                     int pick = nv - 1;
-                    for (int v = 0; v < nv; v++) HIPCK(s, hipMemcpy(&e[v], s->lane[g].sym_dev[v] + sl.est, sizeof e[v], hipMemcpyDeviceToHost));
-                    // pick the variant whose predicted steady P QP sits closest to IDR QP + 3 (the usual I/P offset): P size at the
-                    // IDR's QP is modelled as rho_pi x IDR size, the rest of the budget is shared by the GOP's P pictures
-                    (void)alloc;
                     double best_d = 1e30;
                     for (int v = 0; v < nv; v++) {
-                        const double ib = std::max(1.0, (double)e[v] / 16.0 * s->ratio_i), rest = budget[g] - ib;
-                        const int qi = std::min(51, qp_step[g] + kVariantStep * v);
+                        const double ib = std::max(1.0, (double)ev[(size_t)g][(size_t)v] / 16.0 * s->ratio_i), rest = budget[g] - ib;
+                        const int qi = std::min(51, qp_base[g] + kVariantStep * v);
                         double d;
                         if (gop_len[g] < 2) d = ib <= budget[g] ? -1e9 + v : 1e9 + ib;     // IDR-only GOP: finest that fits
                         else if (rest <= 0) d = 1e9 + ib;
                         else {
-                            const double q_ss = std::max((double)s->qp_p, qi + 6.0 * std::log2(ib * s->rho_pi / (rest / (gop_len[g] - 1))));
+                            const double q_ss = std::max((double)s->qp_p, qi + 6.0 * std::log2(ib * rho / (rest / (gop_len[g] - 1))));
                             d = std::fabs(q_ss - (qi + 3));
                         }
                         if (d < best_d) { best_d = d; pick = v; }
                     }
+                    return pick;
+                };
+                std::vector<int> picks((size_t)B);
+                for (int g = 0; g < B; g++) picks[(size_t)g] = pick_for(g, s->rho_pi);
+                (void)w_i;
+                if (!s->rho_measured && steps > 1 && batch[1] > 0) {
+                    // First chunk of a session: rho is only a prior (1/16).  Measure it: analyse every GOP's first P picture once against
+                    // the UNFILTERED reconstruction of the provisional pick (copied + padded into the reference buffer the real step 0
+                    // overwrites afterwards) at QP pick + 3, read the estimate, and pick again.  Costs one P step per session.
+                    const int B1 = batch[1], tb = steps;                 // trial block index
+                    memcpy(ha + (size_t)tb * lay.total, ha + (size_t)1 * lay.total, lay.total);
+                    StepView<T> tv(ha, lay, tb), dtv(da, lay, tb), h1(ha, lay, 1);
+                    std::vector<int> qp_trial((size_t)B1);
+                    for (int g = 0; g < B1; g++) {
+                        mihevc_session::Lane &L = s->lane[g];
+                        const int pk = picks[(size_t)g];
+                        qp_trial[(size_t)g] = std::min(51, qp_base[g] + kVariantStep * pk + 3);
+                        tv.sao[g] = hv.sao[g];
+                        for (int i = 0; i < 3; i++) tv.sao[g].dbk[i] = pk ? mkc<T>(L.var_p[pk - 1][i], L.work_stride[i]) : mkc<T>(L.work_p[i], L.work_stride[i]);
+                        tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr;
+                        tv.inter[g] = h1.inter[g];
+                        for (int i = 0; i < 3; i++) tv.inter[g].rec[i] = mk<T>(L.rec_p[1][i], L.rec_stride[i]);
+                        tv.inter[g].prm = prm_for(qp_trial[(size_t)g]);
+                        tv.inter[g].ip = nullptr;
+                        tv.pre[g] = h1.pre[g];
+                        HIPCK(s, hipMemsetAsync(L.sym_dev[slot_of(1)] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
+                    }
+                    HIPCK(s, hipMemcpyAsync(da + (size_t)tb * lay.total, ha + (size_t)tb * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
+                    HIPCK(s, launch_sao<T>(s->st_compute, dtv.sao, s->w, s->h, B1, false));
+                    HIPCK(s, launch_pad<T>(s->st_compute, dtv.sao, s->w, s->h, B1));
+                    if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dtv.pre, s->w, s->h, s->n_ctu, B1));
+                    HIPCK(s, launch_me_search<T>(s->st_compute, dtv.inter, s->n_ctu, B1, s->me_range));
+                    HIPCK(s, launch_inter_ctu<T>(s->st_compute, dtv.inter, s->n_ctu, B1, s->me_range));
+                    HIPCK(s, hipStreamSynchronize(s->st_compute));
+                    double lg = 0;
+                    int nl = 0;
+                    for (int g = 0; g < B1; g++) {
+                        unsigned long long ep = 0;
+                        HIPCK(s, hipMemcpy(&ep, s->lane[g].sym_dev[slot_of(1)] + sl.est, sizeof ep, hipMemcpyDeviceToHost));
+                        const unsigned long long ei = ev[(size_t)g][(size_t)picks[(size_t)g]];
+                        if (!ep || !ei) continue;
+                        lg += std::log2((double)ep / (double)ei) + 3.0 / 6.0;      // P estimate brought from QP + 3 to the IDR's QP
+                        nl++;
+                    }
+                    if (nl) s->rho_pi = std::min(1.0, std::max(1.0 / 256, std::exp2(lg / nl)));
+                    s->rho_measured = true;
+                    for (int g = 0; g < B; g++) picks[(size_t)g] = pick_for(g, s->rho_pi);
+                }
+                for (int g = 0; g < B; g++) {
+                    const int pick = picks[(size_t)g];
+                    const unsigned long long *e = ev[(size_t)g].data();
                     lane_slot[g] = pick;
                     qp_step[g] = std::min(51, qp_step[g] + kVariantStep * pick);
                     patch_qp(t, g, qp_step[g]);
