@@ -9,53 +9,68 @@ from hevc_amd.encoder import Encoder                 # noqa: E402
 from oracle import oracle as O                       # noqa: E402
 from tests import util                               # noqa: E402
 
-iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-fails = 0
-for it in range(iters):
-    w, h = int(rng.integers(8, 200)) * 2, int(rng.integers(8, 120)) * 2
-    if rng.random() < 0.25:
-        w = int(rng.integers(128, 330)) * 2          # wide enough for IDR tiles
-    bd = 10 if rng.random() < 0.3 else 8
-    keyint, lanes, n = int(rng.integers(1, 8)), int(rng.integers(1, 5)), int(rng.integers(1, 16))
-    cfg = _lib.default_config()
-    cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight = w, h, bd, keyint, 1, lanes
-    cfg.me_range = int(rng.choice([4, 8, 15, 24]))
-    cfg.level_idc = int(rng.choice([93, 120, 150, 180]))
-    for name in ("intra_nxn", "intra_in_p", "chroma_modes", "rdo_zero", "pre_search", "intra_tiles", "sao", "aud", "hrd", "repeat_headers"):
-        setattr(cfg, name, int(rng.random() < 0.5))
-    if rng.random() < 0.5:
-        cfg.qp = int(rng.integers(10, 45))
-    else:
-        cfg.crf, cfg.qp = int(rng.integers(14, 30)), -1
-        cfg.vbv_maxrate_kbps = int(rng.integers(50, 4000)); cfg.vbv_bufsize_kbits = int(cfg.vbv_maxrate_kbps * 1.2)
-    cw, ch = (w + 7) & ~7, (h + 7) & ~7
-    detail = min(cw, ch) >= 64
-    frames = []
-    for i in range(n):
-        f = util.synth_frame(ch, cw, seed=int(rng.integers(0, 1000)) if rng.random() < 0.15 else 7, shift=(int(rng.integers(-3, 4)) * i, i), bit_depth=bd, detail=detail)
-        frames.append((f.y[:h, :w].copy(), f.u[:h // 2, :w // 2].copy(), f.v[:h // 2, :w // 2].copy()))
-    desc = f"#{it} {w}x{h} bd{bd} keyint{keyint} lanes{lanes} n{n} qp{cfg.qp} crf{cfg.crf} vbv{cfg.vbv_maxrate_kbps} R{cfg.me_range} lvl{cfg.level_idc} " \
-           f"nxn{cfg.intra_nxn} ip{cfg.intra_in_p} cm{cfg.chroma_modes} rz{cfg.rdo_zero} ps{cfg.pre_search} tiles{cfg.intra_tiles} sao{cfg.sao} aud{cfg.aud} hrd{cfg.hrd}"
-    try:
-        stream = b""
-        with Encoder(cfg, device=0, keep_recon=True) as enc:
-            for y, u, v in frames:
-                enc.send(y, u, v)
-            enc.flush()
-            for data, pts, key in enc.packets():
-                stream += data
-            recs = [O.Frame(*enc.recon(i)) for i in range(n)]
-            out = enc.stats().frames_out
-        dec, info = O.decode(stream)
-        ok = out == n and len(dec) == n and all(d.same(r) for d, r in zip(dec, recs)) and (info["conf_width"], info["conf_height"]) == (w, h)
-    except Exception as exc:            # noqa: BLE001
-        ok = False
-        desc += f" EXC {type(exc).__name__}: {exc}"
-    if not ok:
-        fails += 1
-        print("FAIL", desc, flush=True)
-    elif it % 10 == 0:
-        print("ok  ", desc, flush=True)
-print(f"{iters - fails}/{iters} passed")
-sys.exit(1 if fails else 0)
+
+
+def run(iters, seed, verbose=True):
+    """returns the descriptions of the failing cases"""
+    rng = np.random.default_rng(seed)
+    failed = []
+    for it in range(iters):
+        desc, ok = one_case(rng, it)
+        if not ok:
+            failed.append(desc)
+            print("FAIL", desc, flush=True)
+        elif verbose and it % 10 == 0:
+            print("ok  ", desc, flush=True)
+    return failed
+
+
+def one_case(rng, it):
+    if True:
+        w, h = int(rng.integers(8, 200)) * 2, int(rng.integers(8, 120)) * 2
+        if rng.random() < 0.25:
+            w = int(rng.integers(128, 330)) * 2          # wide enough for IDR tiles
+        bd = 10 if rng.random() < 0.3 else 8
+        keyint, lanes, n = int(rng.integers(1, 8)), int(rng.integers(1, 5)), int(rng.integers(1, 16))
+        cfg = _lib.default_config()
+        cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight = w, h, bd, keyint, 1, lanes
+        cfg.me_range = int(rng.choice([4, 8, 15, 24]))
+        cfg.level_idc = int(rng.choice([93, 120, 150, 180]))
+        for name in ("intra_nxn", "intra_in_p", "chroma_modes", "rdo_zero", "pre_search", "intra_tiles", "sao", "aud", "hrd", "repeat_headers"):
+            setattr(cfg, name, int(rng.random() < 0.5))
+        if rng.random() < 0.5:
+            cfg.qp = int(rng.integers(10, 45))
+        else:
+            cfg.crf, cfg.qp = int(rng.integers(14, 30)), -1
+            cfg.vbv_maxrate_kbps = int(rng.integers(50, 4000)); cfg.vbv_bufsize_kbits = int(cfg.vbv_maxrate_kbps * 1.2)
+        cw, ch = (w + 7) & ~7, (h + 7) & ~7
+        detail = min(cw, ch) >= 64
+        frames = []
+        for i in range(n):
+            f = util.synth_frame(ch, cw, seed=int(rng.integers(0, 1000)) if rng.random() < 0.15 else 7, shift=(int(rng.integers(-3, 4)) * i, i), bit_depth=bd, detail=detail)
+            frames.append((f.y[:h, :w].copy(), f.u[:h // 2, :w // 2].copy(), f.v[:h // 2, :w // 2].copy()))
+        desc = f"#{it} {w}x{h} bd{bd} keyint{keyint} lanes{lanes} n{n} qp{cfg.qp} crf{cfg.crf} vbv{cfg.vbv_maxrate_kbps} R{cfg.me_range} lvl{cfg.level_idc} " \
+               f"nxn{cfg.intra_nxn} ip{cfg.intra_in_p} cm{cfg.chroma_modes} rz{cfg.rdo_zero} ps{cfg.pre_search} tiles{cfg.intra_tiles} sao{cfg.sao} aud{cfg.aud} hrd{cfg.hrd}"
+        try:
+            stream = b""
+            with Encoder(cfg, device=0, keep_recon=True) as enc:
+                for y, u, v in frames:
+                    enc.send(y, u, v)
+                enc.flush()
+                for data, pts, key in enc.packets():
+                    stream += data
+                recs = [O.Frame(*enc.recon(i)) for i in range(n)]
+                out = enc.stats().frames_out
+            dec, info = O.decode(stream)
+            ok = out == n and len(dec) == n and all(d.same(r) for d, r in zip(dec, recs)) and (info["conf_width"], info["conf_height"]) == (w, h)
+        except Exception as exc:            # noqa: BLE001
+            ok = False
+            desc += f" EXC {type(exc).__name__}: {exc}"
+    return desc, ok
+
+
+if __name__ == "__main__":
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    bad = run(iters, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    print(f"{iters - len(bad)}/{iters} passed")
+    sys.exit(1 if bad else 0)

@@ -406,3 +406,9 @@ def test_one_clip_sharded_by_gop_chunks_over_two_sessions(lib):
     stream = b"".join(d for d, _, _ in got)
     dec, _ = O.decode(stream if stream.startswith(headers[:8]) else headers + stream)
     assert len(dec) == n
+
+
+def test_random_sessions_decode_to_their_reconstruction(lib):
+    """24 random geometry / GOP / knob / rate-control combinations (tests/fuzz_sessions.py runs the same generator for longer)"""
+    from tests import fuzz_sessions
+    assert fuzz_sessions.run(24, seed=3, verbose=False) == []
