@@ -443,14 +443,25 @@ struct GpuExec {
 };
 #endif
 struct SeqExec {      // sequential stepping of a phase program (tests/emu)
-    template <class F> void phase(F &&f)
+    // order 0: threads 0..NT-1; 1: NT-1..0; 2: a fresh pseudo-random permutation per phase.  A program without races inside a phase
+    // gives the same result in every order (tests/test_kernel_source_stepped.py).
+    int order = 0;
+    unsigned long long rnd = 0x2545F4914F6CDD1Dull;
+    template <class F> void run(F &&f)
     {
-        for (int t = 0; t < NT; t++) f(t);
+        if (order == 0) { for (int t = 0; t < NT; t++) f(t); return; }
+        if (order == 1) { for (int t = NT - 1; t >= 0; t--) f(t); return; }
+        int perm[NT];
+        for (int i = 0; i < NT; i++) perm[i] = i;
+        for (int i = NT - 1; i > 0; i--) {
+            rnd ^= rnd << 13; rnd ^= rnd >> 7; rnd ^= rnd << 17;
+            int j = (int)((rnd >> 33) % (unsigned)(i + 1)), tmp = perm[i];
+            perm[i] = perm[j]; perm[j] = tmp;
+        }
+        for (int i = 0; i < NT; i++) f(perm[i]);
     }
-    template <class F> void wave_step(F &&f)
-    {
-        for (int t = 0; t < NT; t++) f(t);
-    }
+    template <class F> void phase(F &&f) { run(f); }
+    template <class F> void wave_step(F &&f) { run(f); }
     void atomic_add(int *p, int v) { *p += v; }
     void atomic_add(unsigned *p, unsigned v) { *p += v; }
     void atomic_add(unsigned long long *p, unsigned long long v) { *p += v; }

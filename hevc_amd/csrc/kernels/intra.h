@@ -86,6 +86,7 @@ template <typename T> struct IntraShared {
     unsigned long long nx_j2n;
     unsigned nx_sse;
     int nx_bits, nx_keep;
+    int nx_try;                  // set by intra_cu: the 2Nx2N CU left a luma residual (the NxN trial's condition)
     unsigned nx_cbf_c;           // CU_CBF_CB / CU_CBF_CR of the NxN trial
     unsigned csatd[5];           // chroma mode candidates (0 = DM, 1..4 = planar / 26 / 10 / DC): SATD over Cb + Cr
     int cmode, cmode_k;          // chosen chroma prediction mode and its candidate index
@@ -483,6 +484,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             int bits = 16 * mb + 16 + 24 + (s.cmode_k ? 32 : 0);
             for (int p = 0; p < 3; p++) bits += s.bits[p] ? s.bits[p] + R_TU : 0;
             s.j_cu = ((unsigned long long)s.sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)bits) >> 4);
+            s.nx_try = (int)((s.rs.cbf[0] >> t0) & 1);
         }
     });
 }
@@ -766,8 +768,10 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             const int bx = qx + (b & 1) * 8, by = qy + (b >> 1) * 8;
             if (x0 + bx >= a.w || y0 + by >= a.h) continue;
             intra_cu(ex, s, a, x0, y0, bx, by, 3);
-            // NxN trial only when the 2Nx2N CU left a luma residual (uniform over the workgroup: read after intra_cu's last barrier)
-            if (a.prm.intra_nxn && (s.cu_acc[(by >> 3) * 4 + (bx >> 3)].flags & CU_CBF_Y)) intra_cu_nxn(ex, s, a, x0, y0, bx, by);
+            // NxN trial only when the 2Nx2N CU left a luma residual.  The condition must be uniform over the workgroup, so it is read from
+            // a word nobody writes before the next intra_cu ends — NOT from cu_acc[].flags, which the trial's first phase rewrites while
+            // slower waves may still be evaluating this line (that race made waves skip the trial and its barriers on loaded devices)
+            if (a.prm.intra_nxn && s.nx_try) intra_cu_nxn(ex, s, a, x0, y0, bx, by);
             jsplit += s.j_cu;
         }
         const bool fits = x0 + qx + 16 <= a.w && y0 + qy + 16 <= a.h;

@@ -1,5 +1,6 @@
 """Randomised end-to-end check on a GPU box: random geometry / bit depth / GOP structure / analysis knobs / rate control, every stream must
 decode (oracle decoder) to the encoder's own reconstruction.  Usage: python tests/fuzz_sessions.py [iterations] [seed]"""
+import os
 import sys
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
@@ -11,8 +12,14 @@ from tests import util                               # noqa: E402
 
 
 
-def run(iters, seed, verbose=True):
+LARGE = False     # third argument "large": pictures up to 2160p, longer clips (several chunks)
+
+
+def run(iters, seed, verbose=True, large=None):
     """returns the descriptions of the failing cases"""
+    global LARGE
+    if large is not None:
+        LARGE = large
     rng = np.random.default_rng(seed)
     failed = []
     for it in range(iters):
@@ -20,7 +27,7 @@ def run(iters, seed, verbose=True):
         if not ok:
             failed.append(desc)
             print("FAIL", desc, flush=True)
-        elif verbose and it % 10 == 0:
+        elif verbose and (LARGE or it % 10 == 0):
             print("ok  ", desc, flush=True)
     return failed
 
@@ -30,8 +37,14 @@ def one_case(rng, it):
         w, h = int(rng.integers(8, 200)) * 2, int(rng.integers(8, 120)) * 2
         if rng.random() < 0.25:
             w = int(rng.integers(128, 330)) * 2          # wide enough for IDR tiles
+        if LARGE:
+            w, h = int(rng.integers(150, 1000)) * 2, int(rng.integers(100, 560)) * 2
+            if rng.random() < 0.15:
+                w, h = 3840, 2160
         bd = 10 if rng.random() < 0.3 else 8
         keyint, lanes, n = int(rng.integers(1, 8)), int(rng.integers(1, 5)), int(rng.integers(1, 16))
+        if LARGE:
+            n = int(rng.integers(1, 40)) if w < 3000 else int(rng.integers(1, 8))
         cfg = _lib.default_config()
         cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight = w, h, bd, keyint, 1, lanes
         cfg.me_range = int(rng.choice([4, 8, 15, 24]))
@@ -51,6 +64,11 @@ def one_case(rng, it):
             frames.append((f.y[:h, :w].copy(), f.u[:h // 2, :w // 2].copy(), f.v[:h // 2, :w // 2].copy()))
         desc = f"#{it} {w}x{h} bd{bd} keyint{keyint} lanes{lanes} n{n} qp{cfg.qp} crf{cfg.crf} vbv{cfg.vbv_maxrate_kbps} R{cfg.me_range} lvl{cfg.level_idc} " \
                f"nxn{cfg.intra_nxn} ip{cfg.intra_in_p} cm{cfg.chroma_modes} rz{cfg.rdo_zero} ps{cfg.pre_search} tiles{cfg.intra_tiles} sao{cfg.sao} aud{cfg.aud} hrd{cfg.hrd}"
+        only = os.environ.get("FUZZ_ONLY")               # "23,27": run just these cases (the generator still draws every case)
+        if only and it not in [int(x) for x in only.split(",")]:
+            return desc, True
+        for kv in filter(None, os.environ.get("FUZZ_SET", "").split(",")):      # "pre_search=0,intra_nxn=1": override knobs
+            setattr(cfg, kv.split("=")[0], int(kv.split("=")[1]))
         try:
             stream = b""
             with Encoder(cfg, device=0, keep_recon=True) as enc:
@@ -63,6 +81,12 @@ def one_case(rng, it):
                 out = enc.stats().frames_out
             dec, info = O.decode(stream)
             ok = out == n and len(dec) == n and all(d.same(r) for d, r in zip(dec, recs)) and (info["conf_width"], info["conf_height"]) == (w, h)
+            if not ok:
+                bad = [i for i, (d, r) in enumerate(zip(dec, recs)) if not d.same(r)]
+                desc += f" out={out} decoded={len(dec)} differing pictures {bad[:8]}"
+                if bad:
+                    ys, xs = np.nonzero(dec[bad[0]].y != recs[bad[0]].y)
+                    desc += f" luma diffs {len(ys)} first (x={xs[0]}, y={ys[0]})" if len(ys) else " chroma only"
         except Exception as exc:            # noqa: BLE001
             ok = False
             desc += f" EXC {type(exc).__name__}: {exc}"
@@ -71,6 +95,7 @@ def one_case(rng, it):
 
 if __name__ == "__main__":
     iters = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"
     bad = run(iters, int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     print(f"{iters - len(bad)}/{iters} passed")
     sys.exit(1 if bad else 0)

@@ -411,4 +411,12 @@ def test_one_clip_sharded_by_gop_chunks_over_two_sessions(lib):
 def test_random_sessions_decode_to_their_reconstruction(lib):
     """24 random geometry / GOP / knob / rate-control combinations (tests/fuzz_sessions.py runs the same generator for longer)"""
     from tests import fuzz_sessions
-    assert fuzz_sessions.run(24, seed=3, verbose=False) == []
+    assert fuzz_sessions.run(24, seed=3, verbose=False, large=False) == []
+
+
+def test_random_sessions_on_large_pictures_with_nxn(lib, monkeypatch):
+    """Pictures up to 2160p, several lanes and IDR QP variants per launch, the NxN trial forced on: the load under which a race on the
+    trial's condition (waves skipping its barriers) used to corrupt streams; small pictures never showed it."""
+    from tests import fuzz_sessions
+    monkeypatch.setenv("FUZZ_SET", "intra_nxn=1")
+    assert fuzz_sessions.run(8, seed=5, verbose=False, large=True) == []
