@@ -129,3 +129,20 @@ def test_search_centres_are_honoured(emu):
     got = emu.inter(b, a, prm, centers=cen)
     assert util.same_analysis(want, got) and np.array_equal(want.me, got.me)
     assert np.median(want.cu["mvx"]) == 44 and np.median(want.cu["mvy"]) == -24
+
+
+@pytest.mark.parametrize("order,fill", [("1", None), ("2", "11")])
+def test_phase_programs_do_not_depend_on_thread_order_or_initial_lds(emu, monkeypatch, order, fill):
+    """Inside a phase the threads run in any order on the device, and LDS starts with whatever the previous workgroup left: stepping the
+    kernels with reversed / shuffled thread order and pseudo-random initial shared state must still reproduce the oracle."""
+    monkeypatch.setenv("EMU_ORDER", order)
+    if fill:
+        monkeypatch.setenv("EMU_SHARED_FILL", fill)
+    prm = O.default_params(24, bit_depth=8, me_range=8)
+    prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search = 1, 1, 1, 1
+    srcs = [util.synth_frame(104, 136, seed=31, shift=(3 * i, i), bit_depth=8) for i in range(2)]
+    want, got = O.analyze_intra(srcs[0], prm), emu.intra(srcs[0], prm)
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+    ref = O.sao(srcs[0], O.deblock(want.rec, want.cu, 8), prm)[0]
+    want, got = O.analyze_inter(srcs[1], ref, prm, dump_me=True), emu.inter(srcs[1], ref, prm)
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
