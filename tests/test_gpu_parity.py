@@ -420,3 +420,28 @@ def test_random_sessions_on_large_pictures_with_nxn(lib, monkeypatch):
     from tests import fuzz_sessions
     monkeypatch.setenv("FUZZ_SET", "intra_nxn=1")
     assert fuzz_sessions.run(8, seed=5, verbose=False, large=True) == []
+
+
+def test_concurrent_sessions_from_several_threads(lib):
+    """The reference runs one convert_video per QThread (gui/mainwindow.py:289-301): sessions opened, fed and closed from four threads at
+    once on one device must not disturb each other (shared buffer cache, per-session streams, host pools)."""
+    import threading
+    import numpy as np
+    from tests import fuzz_sessions
+    fuzz_sessions.LARGE = False
+    failed, lock = [], threading.Lock()
+
+    def worker(seed):
+        rng = np.random.default_rng(seed)
+        for it in range(6):
+            desc, ok = fuzz_sessions.one_case(rng, it)
+            if not ok:
+                with lock:
+                    failed.append(f"thread {seed}: {desc}")
+
+    threads = [threading.Thread(target=worker, args=(100 + i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert failed == []
