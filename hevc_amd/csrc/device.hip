@@ -127,13 +127,13 @@ template <typename T> __global__ __launch_bounds__(256) void k_sao_apply(const S
 template <typename T> __global__ __launch_bounds__(256) void k_pad(const SaoArgs<T> *args)
 {
     const SaoArgs<T> &a = args[blockIdx.y];
-    const int ny = (a.w + 2 * PAD_Y) * (a.h + 2 * PAD_Y), ncp = ((a.w >> 1) + 2 * PAD_C) * ((a.h >> 1) + 2 * PAD_C);
+    const int ny = pad_border_count(a.w, a.h, PAD_Y), ncp = pad_border_count(a.w >> 1, a.h >> 1, PAD_C);      // border samples only
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < ny) { pad_sample<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
+    if (i < ny) { pad_border_sample<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
     i -= ny;
-    if (i < ncp) { pad_sample<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
+    if (i < ncp) { pad_border_sample<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
     i -= ncp;
-    if (i < ncp) pad_sample<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
+    if (i < ncp) pad_border_sample<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
 }
 
 // fill the coded-size margin of a source plane (columns sw..pw-1, rows sh..ph-1) by edge replication
@@ -155,13 +155,20 @@ template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p
 template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const SaoArgs<T> *args)
 {
     const SaoArgs<T> &a = args[blockIdx.y];
-    const int nl = a.w * a.h, nc = nl >> 2, n = nl + 2 * nc;
+    // four samples of a row per lane and iteration (coded widths are multiples of 8, chroma of 4): dword / qword loads, one division per quad
+    const int ql = (a.w * a.h) >> 2, qc = ql >> 2, nq = ql + 2 * qc;
     unsigned long long acc[3] = {0, 0, 0};
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        int pl = i < nl ? 0 : i < nl + nc ? 1 : 2, k = pl == 0 ? i : pl == 1 ? i - nl : i - nl - nc, pw = pl ? a.w >> 1 : a.w;
-        int x = k % pw, y = k / pw;
-        int d = (int)a.src[pl].p[(ptrdiff_t)y * a.src[pl].stride + x] - (int)a.out[pl].p[(ptrdiff_t)y * a.out[pl].stride + x];
-        acc[pl] += (unsigned long long)(d * d);
+#pragma unroll 4
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+        const int pl = i < ql ? 0 : i < ql + qc ? 1 : 2, k = pl == 0 ? i : pl == 1 ? i - ql : i - ql - qc, qw = (pl ? a.w >> 1 : a.w) >> 2;
+        const int x = (k % qw) * 4, y = k / qw;
+        T s4[4], o4[4];
+        __builtin_memcpy(s4, a.src[pl].p + (ptrdiff_t)y * a.src[pl].stride + x, sizeof s4);
+        __builtin_memcpy(o4, a.out[pl].p + (ptrdiff_t)y * a.out[pl].stride + x, sizeof o4);
+        unsigned e = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int d = (int)s4[j] - (int)o4[j]; e += (unsigned)(d * d); }
+        acc[pl] += e;
     }
     __shared__ unsigned long long red[3];
     if (threadIdx.x < 3) red[threadIdx.x] = 0;
@@ -178,7 +185,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const S
 // ------------------------------------------------------------------------------------------ launchers
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch)
 {
-    hipLaunchKernelGGL(k_frame_sse<T>, dim3(1024, (unsigned)batch), dim3(256), 0, st, d_args);
+    hipLaunchKernelGGL(k_frame_sse<T>, dim3(256, (unsigned)batch), dim3(256), 0, st, d_args);      // 3 same-address atomics per block: few, fat blocks
     return hipGetLastError();
 }
 template <typename K> static hipError_t ensure_smem(K kernel, size_t bytes)
@@ -260,7 +267,7 @@ template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_
 
 template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch)
 {
-    int n = (w + 2 * PAD_Y) * (h + 2 * PAD_Y) + 2 * ((w >> 1) + 2 * PAD_C) * ((h >> 1) + 2 * PAD_C);
+    int n = pad_border_count(w, h, PAD_Y) + 2 * pad_border_count(w >> 1, h >> 1, PAD_C);
     hipLaunchKernelGGL(k_pad<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
     return hipGetLastError();
 }

@@ -286,4 +286,20 @@ template <typename T> DEV void pad_sample(Plane<T> p, int w, int h, int pad, int
     p.p[(ptrdiff_t)y * p.stride + x] = p.p[(ptrdiff_t)clip3(0, h - 1, y) * p.stride + clip3(0, w - 1, x)];
 }
 
+// the same, indexed over the border samples only: pad rows above, pad rows below, then 2 x pad columns beside each picture row
+HDI int pad_border_count(int w, int h, int pad) { return 2 * pad * (w + 2 * pad) + 2 * pad * h; }
+template <typename T> DEV void pad_border_sample(Plane<T> p, int w, int h, int pad, int j)
+{
+    const int pw = w + 2 * pad, band = pad * pw;
+    int idx;
+    if (j < band) idx = j;
+    else if (j < 2 * band) idx = (pad + h) * pw + (j - band);
+    else {
+        const int k = j - 2 * band, y = k / (2 * pad), c = k % (2 * pad);
+        if (y >= h) return;
+        idx = (pad + y) * pw + (c < pad ? c : w + c);
+    }
+    pad_sample<T>(p, w, h, pad, idx);
+}
+
 }  // namespace mihevc

@@ -42,7 +42,7 @@ template <typename T> struct Padded {
     void load(const T *src, int w, int h)
     {
         for (int y = 0; y < h; y++) memcpy(plane.p + (ptrdiff_t)y * stride, src + (size_t)y * w, w * sizeof(T));
-        for (int i = 0; i < (w + 2 * pad) * (h + 2 * pad); i++) pad_sample<T>(plane, w, h, pad, i);
+        for (int i = 0; i < pad_border_count(w, h, pad); i++) pad_border_sample<T>(plane, w, h, pad, i);
     }
     void store(T *dst, int w, int h) const
     {
