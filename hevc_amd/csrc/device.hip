@@ -111,17 +111,17 @@ template <typename T> __global__ __launch_bounds__(NT, 4) void k_sao_decide(cons
     sao_ctu_program<T>(ex, s, a, ctu);
 }
 
-// one thread per sample; rows of a plane are walked by consecutive lanes (coalesced)
+// one thread per four samples of a row; rows of a plane are walked by consecutive lanes (coalesced dword / qword accesses)
 template <typename T> __global__ __launch_bounds__(256) void k_sao_apply(const SaoArgs<T> *args)
 {
     const SaoArgs<T> &a = args[blockIdx.y];
-    const int nl = a.w * a.h, nc = nl >> 2;
+    const int ql = (a.w * a.h) >> 2, qc = ql >> 2, qwl = a.w >> 2, qwc = a.w >> 3;
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nl) { sao_apply_sample<T>(a, 0, i % a.w, i / a.w); return; }
-    i -= nl;
-    if (i < nc) { sao_apply_sample<T>(a, 1, i % (a.w >> 1), i / (a.w >> 1)); return; }
-    i -= nc;
-    if (i < nc) sao_apply_sample<T>(a, 2, i % (a.w >> 1), i / (a.w >> 1));
+    if (i < ql) { sao_apply_quad<T>(a, 0, (i % qwl) * 4, i / qwl); return; }
+    i -= ql;
+    if (i < qc) { sao_apply_quad<T>(a, 1, (i % qwc) * 4, i / qwc); return; }
+    i -= qc;
+    if (i < qc) sao_apply_quad<T>(a, 2, (i % qwc) * 4, i / qwc);
 }
 
 template <typename T> __global__ __launch_bounds__(256) void k_pad(const SaoArgs<T> *args)
@@ -260,7 +260,7 @@ template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_
 {
     int n_ctu = ((w + CTU - 1) / CTU) * ((h + CTU - 1) / CTU);
     if (decide) hipLaunchKernelGGL(k_sao_decide<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), 0, st, d_args, n_ctu);
-    int n = w * h + (w * h >> 1);
+    int n = (w * h + (w * h >> 1)) >> 2;
     hipLaunchKernelGGL(k_sao_apply<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
     return hipGetLastError();
 }

@@ -256,24 +256,41 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
     });
 }
 
-// apply (8.7.3): one thread per sample of a plane-row segment; also usable with sao == nullptr (plain copy)
-template <typename T> DEV void sao_apply_sample(const SaoArgs<T> &a, int pl, int gx, int gy)
+// apply (8.7.3) to one sample value v at (gx, gy) of plane pl
+template <typename T> DEV int sao_sample_value(const SaoArgs<T> &a, const mihevc_sao_ctu &o, int pl, int gx, int gy, int v)
 {
     const int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h, bd = a.prm.bit_depth, maxv = (1 << bd) - 1;
+    const int type = o.type[pl ? 1 : 0];
+    if (type == 2) {
+        int k = eo_category<T>(a.dbk[pl], gx, gy, pw, ph, o.eo_class[pl ? 1 : 0]);
+        if (k) v = clip3(0, maxv, v + o.offset[pl][k - 1]);
+    } else if (type == 1) {
+        int k = ((v >> (bd - 5)) - o.band_pos[pl]) & 31;
+        if (k < 4) v = clip3(0, maxv, v + o.offset[pl][k]);
+    }
+    return v;
+}
+// one thread per sample of a plane-row segment; also usable with sao == nullptr (plain copy)
+template <typename T> DEV void sao_apply_sample(const SaoArgs<T> &a, int pl, int gx, int gy)
+{
     int v = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+    if (a.sao) v = sao_sample_value<T>(a, a.sao[(gy >> (pl ? 4 : 5)) * a.ctus_w + (gx >> (pl ? 4 : 5))], pl, gx, gy, v);
+    a.out[pl].p[(ptrdiff_t)gy * a.out[pl].stride + gx] = (T)v;
+}
+// one thread per four samples of a row (gx a multiple of 4: the quad lies in one CTU; plane widths are multiples of 4): one load and one
+// store per quad, the CTU's parameters fetched once, and CTUs without SAO are a plain copy
+template <typename T> DEV void sao_apply_quad(const SaoArgs<T> &a, int pl, int gx, int gy)
+{
+    T q[4];
+    __builtin_memcpy(q, a.dbk[pl].p + (ptrdiff_t)gy * a.dbk[pl].stride + gx, sizeof q);
     if (a.sao) {
-        const int csh = pl ? 4 : 5;
-        const mihevc_sao_ctu &o = a.sao[(gy >> csh) * a.ctus_w + (gx >> csh)];
-        int type = o.type[pl ? 1 : 0];
-        if (type == 2) {
-            int k = eo_category<T>(a.dbk[pl], gx, gy, pw, ph, o.eo_class[pl ? 1 : 0]);
-            if (k) v = clip3(0, maxv, v + o.offset[pl][k - 1]);
-        } else if (type == 1) {
-            int k = ((v >> (bd - 5)) - o.band_pos[pl]) & 31;
-            if (k < 4) v = clip3(0, maxv, v + o.offset[pl][k]);
+        const mihevc_sao_ctu &o = a.sao[(gy >> (pl ? 4 : 5)) * a.ctus_w + (gx >> (pl ? 4 : 5))];
+        if (o.type[pl ? 1 : 0]) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) q[j] = (T)sao_sample_value<T>(a, o, pl, gx + j, gy, (int)q[j]);
         }
     }
-    a.out[pl].p[(ptrdiff_t)gy * a.out[pl].stride + gx] = (T)v;
+    store4(a.out[pl].p + (ptrdiff_t)gy * a.out[pl].stride + gx, q[0], q[1], q[2], q[3]);
 }
 
 // border extension of a padded plane: thread per border sample

@@ -171,7 +171,7 @@ static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, 
     for (int c = 0; c < n_ctu; c++) { SaoShared s; sao_ctu_program<T>(ex, s, a, c); }
     for (int pl = 0; pl < 3; pl++)
         for (int yy = 0; yy < (pl ? h / 2 : h); yy++)
-            for (int xx = 0; xx < (pl ? w / 2 : w); xx++) sao_apply_sample<T>(a, pl, xx, yy);
+            for (int xx = 0; xx < (pl ? w / 2 : w); xx += 4) sao_apply_quad<T>(a, pl, xx, yy);
     return 0;
 }
 
