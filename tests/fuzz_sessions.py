@@ -12,6 +12,11 @@ from tests import util                               # noqa: E402
 
 
 
+try:                       # the device-frame cases hold their planes in torch tensors: bring torch's HIP runtime up before libmihevc's
+    import torch
+    torch.cuda.init()
+except Exception:          # noqa: BLE001
+    torch = None
 LARGE = False     # third argument "large": pictures up to 2160p, longer clips (several chunks)
 
 
@@ -62,7 +67,8 @@ def one_case(rng, it):
         for i in range(n):
             f = util.synth_frame(ch, cw, seed=int(rng.integers(0, 1000)) if rng.random() < 0.15 else 7, shift=(int(rng.integers(-3, 4)) * i, i), bit_depth=bd, detail=detail)
             frames.append((f.y[:h, :w].copy(), f.u[:h // 2, :w // 2].copy(), f.v[:h // 2, :w // 2].copy()))
-        desc = f"#{it} {w}x{h} bd{bd} keyint{keyint} lanes{lanes} n{n} qp{cfg.qp} crf{cfg.crf} vbv{cfg.vbv_maxrate_kbps} R{cfg.me_range} lvl{cfg.level_idc} " \
+        dev_path, extra_y, extra_c = bool(rng.random() < 0.3) and torch is not None, int(rng.integers(0, 9)), int(rng.integers(0, 5))
+        desc = f"#{it} {'dev ' if dev_path else ''}{w}x{h} bd{bd} keyint{keyint} lanes{lanes} n{n} qp{cfg.qp} crf{cfg.crf} vbv{cfg.vbv_maxrate_kbps} R{cfg.me_range} lvl{cfg.level_idc} " \
                f"nxn{cfg.intra_nxn} ip{cfg.intra_in_p} cm{cfg.chroma_modes} rz{cfg.rdo_zero} ps{cfg.pre_search} tiles{cfg.intra_tiles} sao{cfg.sao} aud{cfg.aud} hrd{cfg.hrd}"
         only = os.environ.get("FUZZ_ONLY")               # "23,27": run just these cases (the generator still draws every case)
         if only and it not in [int(x) for x in only.split(",")]:
@@ -72,8 +78,21 @@ def one_case(rng, it):
         try:
             stream = b""
             with Encoder(cfg, device=0, keep_recon=True) as enc:
-                for y, u, v in frames:
-                    enc.send(y, u, v)
+                if dev_path:        # frames already in HBM, rows padded to an arbitrary pitch (in samples)
+                    keep = []
+                    for y, u, v in frames:
+                        t = []
+                        for pl, ex in ((y, extra_y), (u, extra_c), (v, extra_c)):
+                            host = np.zeros((pl.shape[0], pl.shape[1] + ex), pl.dtype)
+                            host[:, :pl.shape[1]] = pl
+                            t.append(torch.from_numpy(host).cuda())
+                        keep.append(t)
+                    torch.cuda.synchronize()
+                    for i, t in enumerate(keep):
+                        enc.send_device(t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), w + extra_y, w // 2 + extra_c, pts=i)
+                else:
+                    for y, u, v in frames:
+                        enc.send(y, u, v)
                 enc.flush()
                 for data, pts, key in enc.packets():
                     stream += data
