@@ -182,7 +182,18 @@ template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const S
     if (threadIdx.x < 3 && red[threadIdx.x]) atomicAdd(a.sse + threadIdx.x, red[threadIdx.x]);
 }
 
+// zero the per-picture accumulators (SSE per plane + the rate estimate behind them: four 64-bit words at a.sse) of every lane in one launch
+template <typename T> __global__ __launch_bounds__(64) void k_zero_acc(const SaoArgs<T> *args)
+{
+    if (threadIdx.x < 4) args[blockIdx.x].sse[threadIdx.x] = 0;
+}
+
 // ------------------------------------------------------------------------------------------ launchers
+template <typename T> hipError_t launch_zero_acc(hipStream_t st, const SaoArgs<T> *d_args, int batch)
+{
+    hipLaunchKernelGGL(k_zero_acc<T>, dim3((unsigned)batch), dim3(64), 0, st, d_args);
+    return hipGetLastError();
+}
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch)
 {
     hipLaunchKernelGGL(k_frame_sse<T>, dim3(256, (unsigned)batch), dim3(256), 0, st, d_args);      // 3 same-address atomics per block: few, fat blocks
@@ -309,6 +320,7 @@ int gfx950_device_count()
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
     template hipError_t launch_frame_sse<T>(hipStream_t, const SaoArgs<T> *, int);                                       \
+    template hipError_t launch_zero_acc<T>(hipStream_t, const SaoArgs<T> *, int);                                        \
     template hipError_t launch_extend_margin<T>(hipStream_t, Plane<T>, int, int, int, int);                             \
     template hipError_t alloc_plane<T>(DevPlane<T> &, int, int, int);                                                   \
     template void free_plane<T>(DevPlane<T> &);

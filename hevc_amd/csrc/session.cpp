@@ -632,8 +632,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             }
         } else {
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
-            for (int g = 0; g < B; g++)      // zero the slot's SSE + estimate accumulators
-                HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[slot0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
+            HIPCK(s, launch_zero_acc<T>(s->st_compute, dv.sao, B));      // the slot's SSE + estimate accumulators of every lane, one launch
             // stage 1 = search centres from the 1/4-size pictures (k_lowres, k_pre_search) + the integer search around them
             if (int e_ = mark(1, B, true)) return e_;
             if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dv.pre, s->w, s->h, s->n_ctu, B));
