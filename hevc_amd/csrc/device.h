@@ -35,7 +35,9 @@ template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_
 template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch);
 // per-picture sum of squared error into args.sse[0..2] (u64, accumulated with atomics: zero the targets first)
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch);
-template <typename T> hipError_t launch_zero_acc(hipStream_t st, const SaoArgs<T> *d_args, int batch);     // four u64 at SaoArgs::sse of every lane
+constexpr int MAX_LANES = 16;
+struct StepParams { CostParams prm[MAX_LANES]; };      // one P step's cost parameters per lane, passed by value
+template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch);
 
 template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p, int sw, int sh, int pw, int ph);
 

@@ -182,16 +182,26 @@ template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const S
     if (threadIdx.x < 3 && red[threadIdx.x]) atomicAdd(a.sse + threadIdx.x, red[threadIdx.x]);
 }
 
-// zero the per-picture accumulators (SSE per plane + the rate estimate behind them: four 64-bit words at a.sse) of every lane in one launch
-template <typename T> __global__ __launch_bounds__(64) void k_zero_acc(const SaoArgs<T> *args)
+// Start of a P step, one tiny launch for every lane: the step's cost parameters (QP from the rate controller, by value in the kernel
+// arguments) go into the lane's argument blocks — the rest of the blocks was uploaded with the chunk — and the per-picture accumulators
+// (SSE per plane + the rate estimate behind them: four 64-bit words at SaoArgs::sse) are zeroed.
+template <typename T> __global__ __launch_bounds__(64) void k_begin_p_step(IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, StepParams p)
 {
-    if (threadIdx.x < 4) args[blockIdx.x].sse[threadIdx.x] = 0;
+    const int g = (int)blockIdx.x;
+    if (threadIdx.x == 0) {
+        CostParams c = p.prm[g];
+        ea[g].prm = c; sa[g].prm = c;
+        c.tile_cols = c.tile_rows = 1;      // P pictures use PPS 0 (one tile)
+        ia[g].prm = c;
+    }
+    if (threadIdx.x < 4) sa[g].sse[threadIdx.x] = 0;
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-template <typename T> hipError_t launch_zero_acc(hipStream_t st, const SaoArgs<T> *d_args, int batch)
+template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch)
 {
-    hipLaunchKernelGGL(k_zero_acc<T>, dim3((unsigned)batch), dim3(64), 0, st, d_args);
+    if (batch > MAX_LANES) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_begin_p_step<T>, dim3((unsigned)batch), dim3(64), 0, st, ia, ea, sa, p);
     return hipGetLastError();
 }
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch)
@@ -320,7 +330,7 @@ int gfx950_device_count()
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
     template hipError_t launch_frame_sse<T>(hipStream_t, const SaoArgs<T> *, int);                                       \
-    template hipError_t launch_zero_acc<T>(hipStream_t, const SaoArgs<T> *, int);                                        \
+    template hipError_t launch_begin_p_step<T>(hipStream_t, IntraArgs<T> *, InterArgs<T> *, SaoArgs<T> *, const StepParams &, int); \
     template hipError_t launch_extend_margin<T>(hipStream_t, Plane<T>, int, int, int, int);                             \
     template hipError_t alloc_plane<T>(DevPlane<T> &, int, int, int);                                                   \
     template void free_plane<T>(DevPlane<T> &);

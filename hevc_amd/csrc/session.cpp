@@ -631,8 +631,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
             }
         } else {
-            HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
-            HIPCK(s, launch_zero_acc<T>(s->st_compute, dv.sao, B));      // the slot's SSE + estimate accumulators of every lane, one launch
+            {   // the step's QPs reach the device inside one tiny launch that also zeroes the slot's SSE + estimate accumulators; everything
+                // else in the step's argument block went up with the chunk
+                StepParams sp{};
+                for (int g = 0; g < B; g++) sp.prm[g] = hv.inter[g].prm;
+                HIPCK(s, launch_begin_p_step<T>(s->st_compute, dv.intra, dv.inter, dv.sao, sp, B));
+            }
             // stage 1 = search centres from the 1/4-size pictures (k_lowres, k_pre_search) + the integer search around them
             if (int e_ = mark(1, B, true)) return e_;
             if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dv.pre, s->w, s->h, s->n_ctu, B));
@@ -771,7 +775,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->ring = cfg->level_idc >= 150 ? kRing : 8;
     s->is16 = cfg->bit_depth > 8;
     s->keyint = cfg->keyint;
-    s->lanes = cfg->gops_in_flight > 0 ? std::min(cfg->gops_in_flight, 16) : 4;
+    s->lanes = cfg->gops_in_flight > 0 ? std::min(cfg->gops_in_flight, MAX_LANES) : 4;
     s->me_range = cfg->me_range > 0 ? std::min(cfg->me_range, MAX_RANGE) : 15;   // 8 quads x 31 rows = 248 items: one pass of the 256-thread search
     // constant-quality operating point: P pictures at crf + 2, IDR pictures 3 below (x265's ipratio 1.4 ~ 3 QP)
     s->qp_p = cfg->qp >= 0 ? cfg->qp : std::min(51, std::max(0, cfg->crf + 2));
