@@ -2,8 +2,12 @@
 // CPU with the sequential executor (one "thread" at a time, barrier = end of loop), so the kernel SOURCE can be
 // checked against the oracle on machines without a GPU.  It proves the kernels' logic, not the GPU execution:
 // the -m gpu tests run the real gfx950 binaries through the C ABI.  hevc_amd/ never loads this library.
+#include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../hevc_amd/csrc/kernels/common.h"
@@ -55,6 +59,66 @@ static CostParams to_prm(const mihevc_cost_params *p)
     return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search, p->rdo_zero, p->chroma_modes};
 }
 
+// ---- EMU_WAVES=<seed>: the four waves of a workgroup as four host threads -------------------------------------------------------------
+// The sequential executor runs the code BETWEEN two phases once, so it cannot see a wave that reads shared state for a uniform branch
+// after another wave has already entered the next phase and rewritten it (the NxN race of round 1).  Here every wave runs the whole CTU
+// program on its own thread, phases end in a real barrier, and a random wave is delayed after each barrier to provoke such skew.  A wave
+// that takes a different branch misses a barrier: the barrier times out and the frame call reports -2.
+struct WaveBarrier {
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0, generation = 0;
+    bool broken = false;
+    bool wait()
+    {
+        std::unique_lock<std::mutex> l(m);
+        if (broken) return false;
+        const int gen = generation;
+        if (++waiting == NT / 64) { waiting = 0; generation++; cv.notify_all(); return true; }
+        if (!cv.wait_for(l, std::chrono::seconds(3), [&] { return generation != gen || broken; })) { broken = true; cv.notify_all(); }
+        return !broken;
+    }
+};
+struct WaveAbort {};
+struct WaveExec {
+    int wave;
+    WaveBarrier *bar;
+    unsigned long long rnd;
+    template <class F> void lanes(F &&f) { for (int l = 0; l < 64; l++) f(wave * 64 + l); }
+    template <class F> void phase(F &&f)
+    {
+        lanes(f);
+        if (!bar->wait()) throw WaveAbort{};
+        rnd ^= rnd << 13; rnd ^= rnd >> 7; rnd ^= rnd << 17;
+        if ((rnd >> 40) % 16 == 0) std::this_thread::sleep_for(std::chrono::microseconds(30));      // this wave falls behind
+    }
+    template <class F> void wave_step(F &&f) { lanes(f); }
+    void atomic_add(int *p, int v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+    void atomic_add(unsigned *p, unsigned v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+    void atomic_add(unsigned long long *p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+    void atomic_or(unsigned *p, unsigned v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+    void atomic_and(unsigned *p, unsigned v) { __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+    void atomic_min(unsigned long long *p, unsigned long long v)
+    {
+        unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+        while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    }
+    void atomic_add_global(unsigned long long *p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+};
+// run one workgroup program on four wave threads; false when a barrier broke
+template <class Program> static bool run_waves(unsigned long long seed, Program &&program)
+{
+    WaveBarrier bar;
+    std::vector<std::thread> th;
+    for (int wv = 0; wv < NT / 64; wv++)
+        th.emplace_back([&, wv] {
+            WaveExec ex{wv, &bar, (seed + 1) * 0x9E3779B97F4A7C15ull + (unsigned long long)wv * 0xD1B54A32D192ED03ull};
+            try { program(ex); } catch (const WaveAbort &) {}
+        });
+    for (auto &t : th) t.join();
+    return !bar.broken;
+}
+
 template <typename T>
 static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const T *ru, const T *rv, int w, int h,
                        const mihevc_cost_params *prm, const int16_t *centers, T *oy, T *ou, T *ov, mihevc_cu_rec *cu,
@@ -86,18 +150,25 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
         for (int c = 0; c < n_ctu; c++) { PreShared ps; pre_search_program<T>(ex, ps, pa, c); }
         a.centers = cen.data();
     }
+    const char *waves = getenv("EMU_WAVES");
     std::vector<uint8_t> win((size_t)me_win_elems(R) + 8);
     std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16), wu((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16), wv(wu.size());
     for (int c = 0; c < n_ctu; c++) {
         MeShared<T> *ms = fresh_shared<MeShared<T>>();
-        me_search_program<T>(ex, *ms, win.data(), a, c);
+        bool ok = true;
+        if (waves) ok = run_waves((unsigned long long)atoll(waves) + (unsigned)c, [&](WaveExec &wx) { me_search_program<T>(wx, *ms, win.data(), a, c); });
+        else me_search_program<T>(ex, *ms, win.data(), a, c);
         free(ms);
+        if (!ok) return -2;
     }
     if (me_dump) memcpy(me_dump, me.data(), me.size() * sizeof(int32_t));
     for (int c = 0; c < n_ctu; c++) {
         InterShared<T> *is = fresh_shared<InterShared<T>>();
-        inter_ctu_program<T>(ex, *is, wy.data(), wu.data(), wv.data(), a, c);
+        bool ok = true;
+        if (waves) ok = run_waves((unsigned long long)atoll(waves) + 7919u * (unsigned)c, [&](WaveExec &wx) { inter_ctu_program<T>(wx, *is, wy.data(), wu.data(), wv.data(), a, c); });
+        else inter_ctu_program<T>(ex, *is, wy.data(), wu.data(), wv.data(), a, c);
         free(is);
+        if (!ok) return -2;
     }
     if (a.ip) {       // intra second pass, two rounds like the device's two launches
         IntraArgs<T> ia;
@@ -109,8 +180,11 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
             for (int c = 0; c < n_ctu; c++) {
                 if (!ip_eligible(ia.ip, ia.ctus_w, ia.ctus_h, c % ia.ctus_w, c / ia.ctus_w, round)) continue;
                 IntraShared<T> *is = fresh_shared<IntraShared<T>>();
-                intra_ctu_program<T>(ex, *is, ia, c % ia.ctus_w, c / ia.ctus_w);
+                bool ok = true;
+                if (waves) ok = run_waves((unsigned long long)atoll(waves) + 104729u * (unsigned)c, [&](WaveExec &wx) { intra_ctu_program<T>(wx, *is, ia, c % ia.ctus_w, c / ia.ctus_w); });
+                else intra_ctu_program<T>(ex, *is, ia, c % ia.ctus_w, c / ia.ctus_w);
                 free(is);
+                if (!ok) return -2;
             }
     }
     return 0;
@@ -138,8 +212,11 @@ static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, cons
             const int cyi = cy0 + r, cxi = cx0 + d - 2 * r;
             if (cyi >= cy1 || cxi < cx0 || cxi >= cx1) continue;
             IntraShared<T> *is = fresh_shared<IntraShared<T>>();
-            intra_ctu_program<T>(ex, *is, a, cxi, cyi);
+            bool ok = true;
+            if (const char *e = getenv("EMU_WAVES")) ok = run_waves((unsigned long long)atoll(e) + (unsigned)(cyi * 4096 + cxi), [&](WaveExec &wx) { intra_ctu_program<T>(wx, *is, a, cxi, cyi); });
+            else intra_ctu_program<T>(ex, *is, a, cxi, cyi);
             free(is);
+            if (!ok) return -2;
         }
     }
     return 0;

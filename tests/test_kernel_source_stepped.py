@@ -19,7 +19,7 @@ def emu():
     so = EMU_DIR / "libkernel_emu.so"
     srcs = [EMU_DIR / "emu.cpp"] + list((EMU_DIR.parents[1] / "hevc_amd" / "csrc" / "kernels").glob("*.h"))
     if not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
-        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w", "-o", str(so), str(EMU_DIR / "emu.cpp")], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-w", "-pthread", "-o", str(so), str(EMU_DIR / "emu.cpp")], check=True)
     return util.StageApi(C.CDLL(str(so)), "emu_")
 
 
@@ -145,4 +145,23 @@ def test_phase_programs_do_not_depend_on_thread_order_or_initial_lds(emu, monkey
     assert util.same_analysis(want, got), util.describe_diff(want, got)
     ref = O.sao(srcs[0], O.deblock(want.rec, want.cu, 8), prm)[0]
     want, got = O.analyze_inter(srcs[1], ref, prm, dump_me=True), emu.inter(srcs[1], ref, prm)
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+
+
+def test_waves_as_threads_with_real_barriers(emu, monkeypatch):
+    """EMU_WAVES: the four waves of every workgroup run as four host threads, phases end in a real barrier and random waves are delayed
+    after it.  Code between two phases (uniform branches on shared state) then runs once per wave, as on the device: a wave that reads a
+    word another wave has already rewritten takes the other branch, misses a barrier and the call fails (this is how the NxN race of
+    round 1 shows on a CPU).  NxN, chroma modes, RD zero-out, pre-search and the intra second pass are all on."""
+    from tests.test_bitstream_cpu import occluded_clip
+    monkeypatch.setenv("EMU_WAVES", "5")
+    prm = O.default_params(24, bit_depth=8, me_range=8)
+    prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search, prm.intra_in_p = 1, 1, 1, 1, 1
+    srcs = occluded_clip(136, 104, 8)
+    want, got = O.analyze_intra(srcs[0], prm), emu.intra(srcs[0], prm)
+    assert (want.cu["flags"] & 16).any()
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+    ref = O.sao(srcs[0], O.deblock(want.rec, want.cu, 8), prm)[0]
+    want, got = O.analyze_inter(srcs[1], ref, prm, dump_me=True), emu.inter(srcs[1], ref, prm)
+    assert ((want.cu["flags"] & 1) == 0).any()
     assert util.same_analysis(want, got), util.describe_diff(want, got)
