@@ -3,10 +3,9 @@
 // checked against the oracle on machines without a GPU.  It proves the kernels' logic, not the GPU execution:
 // the -m gpu tests run the real gfx950 binaries through the C ABI.  hevc_amd/ never loads this library.
 #include <chrono>
-#include <condition_variable>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -64,19 +63,25 @@ static CostParams to_prm(const mihevc_cost_params *p)
 // after another wave has already entered the next phase and rewritten it (the NxN race of round 1).  Here every wave runs the whole CTU
 // program on its own thread, phases end in a real barrier, and a random wave is delayed after each barrier to provoke such skew.  A wave
 // that takes a different branch misses a barrier: the barrier times out and the frame call reports -2.
-struct WaveBarrier {
-    std::mutex m;
-    std::condition_variable cv;
-    int waiting = 0, generation = 0;
-    bool broken = false;
+struct WaveBarrier {       // spinning barrier on C++ atomics (sanitizers follow their acquire / release edges)
+    std::atomic<int> waiting{0}, generation{0};
+    std::atomic<bool> broken{false};
     bool wait()
     {
-        std::unique_lock<std::mutex> l(m);
-        if (broken) return false;
-        const int gen = generation;
-        if (++waiting == NT / 64) { waiting = 0; generation++; cv.notify_all(); return true; }
-        if (!cv.wait_for(l, std::chrono::seconds(3), [&] { return generation != gen || broken; })) { broken = true; cv.notify_all(); }
-        return !broken;
+        if (broken.load()) return false;
+        const int gen = generation.load(std::memory_order_acquire);
+        if (waiting.fetch_add(1, std::memory_order_acq_rel) + 1 == NT / 64) {
+            waiting.store(0, std::memory_order_relaxed);
+            generation.fetch_add(1, std::memory_order_release);
+            return true;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (generation.load(std::memory_order_acquire) == gen) {
+            if (broken.load()) return false;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(3)) { broken.store(true); return false; }
+            std::this_thread::yield();
+        }
+        return true;
     }
 };
 struct WaveAbort {};
@@ -108,7 +113,8 @@ struct WaveExec {
 // run one workgroup program on four wave threads; false when a barrier broke
 template <class Program> static bool run_waves(unsigned long long seed, Program &&program)
 {
-    WaveBarrier bar;
+    static WaveBarrier bar;        // one long-lived object (workgroups run one after the other): sanitizers track a mutex by its address
+    bar.waiting.store(0); bar.broken.store(false);
     std::vector<std::thread> th;
     for (int wv = 0; wv < NT / 64; wv++)
         th.emplace_back([&, wv] {
@@ -116,7 +122,7 @@ template <class Program> static bool run_waves(unsigned long long seed, Program 
             try { program(ex); } catch (const WaveAbort &) {}
         });
     for (auto &t : th) t.join();
-    return !bar.broken;
+    return !bar.broken.load();
 }
 
 template <typename T>
