@@ -153,7 +153,11 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
         ls.assign((size_t)(w / 4) * (h / 4), 0); lr = ls; cen.assign((size_t)n_ctu * 2, 0);
         pa.src = a.src[0]; pa.ref = a.ref[0]; pa.lsrc = ls.data(); pa.lref = lr.data(); pa.w = w; pa.h = h; pa.bit_depth = a.prm.bit_depth; pa.centers = cen.data();
         for (int i = 0; i < 2 * (w / 4) * (h / 4); i++) lowres_sample<T>(pa, i);
-        for (int c = 0; c < n_ctu; c++) { PreShared ps; pre_search_program<T>(ex, ps, pa, c); }
+        for (int c = 0; c < n_ctu; c++) {
+            PreShared ps;
+            if (const char *e = getenv("EMU_WAVES")) { if (!run_waves((unsigned long long)atoll(e) + 31u * (unsigned)c, [&](WaveExec &wx) { pre_search_program<T>(wx, ps, pa, c); })) return -2; }
+            else pre_search_program<T>(ex, ps, pa, c);
+        }
         a.centers = cen.data();
     }
     const char *waves = getenv("EMU_WAVES");
@@ -251,7 +255,11 @@ static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, 
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.prm = to_prm(prm); a.sao = out; a.sse = nullptr;
     SeqExec ex; ex.order = emu_order();
     int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU);
-    for (int c = 0; c < n_ctu; c++) { SaoShared s; sao_ctu_program<T>(ex, s, a, c); }
+    for (int c = 0; c < n_ctu; c++) {
+        SaoShared s;
+        if (const char *e = getenv("EMU_WAVES")) { if (!run_waves((unsigned long long)atoll(e) + 131u * (unsigned)c, [&](WaveExec &wx) { sao_ctu_program<T>(wx, s, a, c); })) return -2; }
+        else sao_ctu_program<T>(ex, s, a, c);
+    }
     for (int pl = 0; pl < 3; pl++)
         for (int yy = 0; yy < (pl ? h / 2 : h); yy++)
             for (int xx = 0; xx < (pl ? w / 2 : w); xx += 4) sao_apply_quad<T>(a, pl, xx, yy);

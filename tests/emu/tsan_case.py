@@ -9,6 +9,9 @@ prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search, prm.intra_in_p = 
 srcs = occluded_clip(72, 40, 8)
 want, got = O.analyze_intra(srcs[0], prm), emu.intra(srcs[0], prm)
 print("intra same", util.same_analysis(want, got))
-ref = O.sao(srcs[0], O.deblock(want.rec, want.cu, 8), prm)[0]
+dbk = O.deblock(want.rec, want.cu, 8)
+ref, sp = O.sao(srcs[0], dbk, prm)
+gref, gsp = emu.sao(srcs[0], dbk, prm)
+print("sao same", ref.same(gref), bool((sp == gsp).all()) if hasattr(sp, "all") else sp == gsp)
 want, got = O.analyze_inter(srcs[1], ref, prm, dump_me=True), emu.inter(srcs[1], ref, prm)
 print("inter same", util.same_analysis(want, got))

@@ -161,7 +161,9 @@ def test_waves_as_threads_with_real_barriers(emu, monkeypatch):
     want, got = O.analyze_intra(srcs[0], prm), emu.intra(srcs[0], prm)
     assert (want.cu["flags"] & 16).any()
     assert util.same_analysis(want, got), util.describe_diff(want, got)
-    ref = O.sao(srcs[0], O.deblock(want.rec, want.cu, 8), prm)[0]
+    dbk = O.deblock(want.rec, want.cu, 8)
+    (ref, sp), (gref, gsp) = O.sao(srcs[0], dbk, prm), emu.sao(srcs[0], dbk, prm)
+    assert ref.same(gref) and np.array_equal(sp, gsp)
     want, got = O.analyze_inter(srcs[1], ref, prm, dump_me=True), emu.inter(srcs[1], ref, prm)
     assert ((want.cu["flags"] & 1) == 0).any()
     assert util.same_analysis(want, got), util.describe_diff(want, got)
