@@ -1,18 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — encoded 1080p30 frames/s on MI355X (BASELINE.json metric), one process per GPU.
+"""bench.py — encoded 1080p30 frames/s on MI355X (BASELINE.json metric), one process per GPU, no collective on the data path.
 
 A step = one complete encode of the workload clip: BASELINE configs[1], "1080p30 SDR 8-bit Main profile, CQ mode":
 300 frames (10 s) of the synthetic `motion` clip, seed = rank, already resident in HBM when the
 timed region starts.  Timed: every device stage + D2H of the symbols + host CABAC until the last NAL byte exists.
-N > 1 shards one clip per GPU with no data-path collective (BASELINE configs[3]); scaling is weak.
+
+N > 1 (BASELINE configs[3], one clip per GPU): either the driver starts the ranks (`python -m torch.distributed.run ... bench.py --gpus N`,
+RANK / LOCAL_RANK / WORLD_SIZE in the environment) or `python bench.py --gpus N` spawns N child processes itself BEFORE any GPU call.
+Every rank binds device LOCAL_RANK and encodes its own clip; barrier and MAX-over-ranks time go over gloo (host TCP on 127.0.0.1) —
+nothing is exchanged between GPUs, so there is no RCCL anywhere (north_star).  Scaling is weak.
+
+Outside the timed region rank 0 adds: `stream_ok` (the last step's stream decoded by the oracle decoder: picture count and per-plane SSE
+against the source must equal the encoder's own statistics), `value_pcie_inclusive` (the same clip handed over as host buffers), a
+`configs` block with the 2160p30 Main10 HDR10 run (BASELINE configs[2]), `cpu_baseline` (the oracle on one host core) and `libx265`
+(the reference's own ffmpeg command when ffmpeg + libx265 exist on the host; probed, never assumed).
 """
 import argparse
-import ctypes as C
 import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 
 import numpy as np
@@ -21,8 +34,10 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+METRIC = "encoded 1080p30 frames/sec/GPU; PSNR-Y parity vs libx265 at matched bitrate"
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
 def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     """The oracle (scalar C port of the same path) on ONE host core, on the first frames of the same clip:
     1 I + (budget_frames-1) P pictures through analysis + deblock + SAO.  Reported baseline, not the target."""
@@ -47,26 +62,226 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     dt = time.perf_counter() - t0
     return {"value": round(budget_frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"oracle/hevc_oracle.c, first {budget_frames} pictures (1 I + {budget_frames - 1} P) of the same {width}x{height} clip, "
-                      f"analysis+deblock+SAO, no CABAC, {dt:.1f} s; libx265 itself is unavailable (no ffmpeg on this host)"}
+                      f"analysis+deblock+SAO, no CABAC, {dt:.1f} s; for libx265 itself see the `libx265` block"}
+
+
+# ------------------------------------------------------------------------------------------------ libx265 (the reference's own command)
+def libx265_probe():
+    """(available, reason): ffmpeg on PATH and libx265 among its encoders — probed at run time."""
+    exe = shutil.which("ffmpeg")
+    if exe is None:
+        return False, "unavailable: shutil.which('ffmpeg') found no ffmpeg on this host"
+    try:
+        txt = subprocess.run([exe, "-hide_banner", "-encoders"], capture_output=True, text=True, timeout=30).stdout
+    except Exception as exc:      # noqa: BLE001 — a broken ffmpeg is reported, not raised
+        return False, f"unavailable: `ffmpeg -encoders` failed ({exc})"
+    if "libx265" not in txt:
+        return False, "unavailable: ffmpeg is present but lists no libx265 encoder"
+    return True, exe
+
+
+def libx265_baseline(info, frames, bit_depth, budget_s=120.0):
+    """The reference's CPU command (core/transcoder.py:398-411,460-493 via hevc_amd.transcoder.build_ffmpeg_command) on a raw-video
+    wrapper of the same synthetic pictures, timed on this host's cores; PSNR-Y of its output (decoded by the same ffmpeg) by numpy."""
+    ok, why = libx265_probe()
+    if not ok:
+        return {"available": False, "reason": why}
+    from hevc_amd.transcoder import build_ffmpeg_command, build_ffmpeg_params
+    W, H, n = info.width, info.height, len(frames)
+    pix = "yuv420p10le" if bit_depth > 8 else "yuv420p"
+    with tempfile.TemporaryDirectory(prefix="mihevc_x265_") as td:
+        raw, out = Path(td) / "clip.yuv", Path(td) / "clip.mp4"
+        with open(raw, "wb") as f:
+            for y, u, v in frames:
+                f.write(y.tobytes()); f.write(u.tobytes()); f.write(v.tobytes())
+        ff = build_ffmpeg_params(info, False, "unknown")
+        cmd = build_ffmpeg_command(raw, out, ff, 0, "eng")
+        i = cmd.index("-i")
+        cmd[i:i] = ["-f", "rawvideo", "-pix_fmt", pix, "-s", f"{W}x{H}", "-r", "30"]      # the lossless wrapper of the same YUV
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s * 10)
+        except subprocess.TimeoutExpired:
+            return {"available": True, "error": "libx265 run exceeded its time budget"}
+        dt = time.perf_counter() - t0
+        if p.returncode != 0 or not out.exists():
+            return {"available": True, "error": "ffmpeg/libx265 failed: " + (p.stderr or "")[-400:]}
+        kbps = out.stat().st_size * 8 / (n / 30.0) / 1e3
+        dec = subprocess.run(["ffmpeg", "-v", "error", "-i", str(out), "-f", "rawvideo", "-pix_fmt", pix, "-"], capture_output=True)
+        psnr = None
+        fb = W * H * 3 // 2 * (2 if bit_depth > 8 else 1)
+        if dec.returncode == 0 and len(dec.stdout) >= n * fb:
+            dt_ = np.dtype("<u2") if bit_depth > 8 else np.uint8
+            se = 0.0
+            for k, (y, _, _) in enumerate(frames):
+                d = np.frombuffer(dec.stdout, dt_, W * H, k * fb).reshape(H, W).astype(np.float64) - y
+                se += float((d * d).sum())
+            mse = se / (n * W * H)
+            psnr = 99.0 if mse == 0 else 10 * np.log10(((1 << bit_depth) - 1) ** 2 / mse)
+        return {"available": True, "fps": round(n / dt, 3), "frames": n, "bitrate_kbps": round(kbps, 1), "psnr_y_db": None if psnr is None else round(float(psnr), 3),
+                "cores": os.cpu_count(), "cmd": " ".join(cmd[:cmd.index(str(out))][-12:]), "note": "x265 sizes its own pool (-threads 0)"}
+
+
+# ------------------------------------------------------------------------------------------------ committed profile data
+def newest_profile(name):
+    files = sorted(glob.glob(str(ROOT / "profiles" / "r*" / name)))
+    return files[-1] if files else None
 
 
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/r*/traffic.json, written by
     tools/profile_bench.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  PMC passes cannot
     run inside the timed bench, so the figure is only reported for the default workload it was collected on."""
-    if workload != (1920, 1080, 300, 15):
-        return None, None
-    here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, "profiles", "r*", "traffic.json")))
-    if not files:
+    f = newest_profile("traffic.json")
+    if workload != (1920, 1080, 300, 15) or not f:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        k = json.load(open(f))["kernels"].get(kernel)
     except (OSError, ValueError, KeyError):
         return None, None
-    return (k["hbm_bytes_per_launch"], os.path.relpath(files[-1], here)) if k else (None, None)
+    return (k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)) if k else (None, None)
 
 
+def measured_valu(kernel):
+    """VALU issue share of `kernel` from the newest committed SQ counter pass (profiles/r*/pmc.json, tools/pmc_kernels.sh):
+    SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles over the same sampled waves) = share of a wave's resident time in which it
+    issues vector ALU work; times the resident waves per SIMD (from the kernel's launch bounds) = share of a SIMD's issue slots."""
+    f = newest_profile("pmc.json")
+    if not f:
+        return None
+    try:
+        k = json.load(open(f))["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None
+    if not k:
+        return None
+    return {"valu_issue_frac": k["valu_issue_frac"], "valu_active_per_wave": k["valu_active_per_wave"], "waves_per_simd": k["waves_per_simd"],
+            "source": os.path.relpath(f, ROOT)}
+
+
+# ------------------------------------------------------------------------------------------------ stream check (oracle decoder)
+def verify_stream(packets, headers, cfg, clip, stats, limit=None):
+    """Decode the stream with the oracle decoder (one thread per closed GOP; ctypes releases the GIL) and compare with the source:
+    the number of pictures and the per-plane SSE must equal what the encoder itself reported (its k_frame_sse sums), i.e. the decoder
+    reconstructs exactly the pictures the encoder reconstructed.  limit = only the first `limit` pictures (then counts only)."""
+    from oracle import oracle as O
+    gops, cur = [], []
+    for data, _pts, key in packets:
+        if key and cur:
+            gops.append(cur)
+            cur = []
+        cur.append(data)
+    if cur:
+        gops.append(cur)
+    if limit is not None:
+        gops, packets = [gops[0][:limit]], packets[:limit]
+    W, H = cfg.width, cfg.height
+    cw, ch = (W + 7) & ~7, (H + 7) & ~7
+    starts = np.cumsum([0] + [len(g) for g in gops])
+
+    def one(k):
+        stream = b"".join(gops[k])
+        if k > 0 and not cfg.repeat_headers:
+            stream = headers + stream            # only the session's first IDR carries the parameter sets unless repeat_headers
+        dec, info = O.decode(stream)
+        sse = np.zeros(3)
+        for j, f in enumerate(dec):
+            y, u, v = clip.frame(int(starts[k]) + j)
+            src = (np.pad(y, ((0, ch - H), (0, cw - W)), mode="edge"), np.pad(u, ((0, (ch - H) // 2), (0, (cw - W) // 2)), mode="edge"),
+                   np.pad(v, ((0, (ch - H) // 2), (0, (cw - W) // 2)), mode="edge"))
+            for p, (a, b) in enumerate(zip(src, (f.y, f.u, f.v))):
+                d = a.astype(np.int64) - b.astype(np.int64)
+                sse[p] += float((d * d).sum())
+        return len(dec), sse
+
+    try:
+        with ThreadPoolExecutor(max_workers=min(8, len(gops))) as ex:
+            res = list(ex.map(one, range(len(gops))))
+    except Exception as exc:      # noqa: BLE001 — a stream the decoder rejects is a failed check, with the reason
+        return {"stream_ok": False, "error": str(exc)[:200]}
+    n = sum(r[0] for r in res)
+    sse = sum(r[1] for r in res)
+    out = {"pictures_decoded": n, "decoder": "oracle/hevc_dec.c (own decoder; no third-party decoder exists on this pool)"}
+    if limit is None:
+        same = [float(sse[0]) == float(stats.sse_y), float(sse[1]) == float(stats.sse_u), float(sse[2]) == float(stats.sse_v)]
+        out["stream_ok"] = bool(n == len(packets) and all(same))
+        out["sse_equal_to_encoder_stats"] = same
+    else:
+        out["stream_ok"] = bool(n == len(packets))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ rank launcher
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: N children, one per GPU, started before this process touches a GPU."""
+    if args.stub:
+        n_dev = args.gpus
+    else:
+        import torch
+        n_dev = torch.cuda.device_count()          # counts devices without initialising the GPU runtime in this process
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} MI355X visible on this host — one process per GPU needs {args.gpus} devices "
+                         "(there is no CPU fallback and ranks never share a device)")
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0:
+                    rc = rc or r
+                    for q in procs:             # a failed rank leaves the others waiting at the barrier: stop them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    sys.exit(rc)
+
+
+class Ranks:
+    """barrier / max / gather over gloo (host TCP): timing plumbing only, nothing from the data path goes through it"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.dist = rank, world, None
+        if world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def gather(self, value):
+        if self.dist is None:
+            return [value]
+        import torch
+        t = [torch.zeros(1, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(t, torch.tensor([value], dtype=torch.float64))
+        return [float(x.item()) for x in t]
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ one rank
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,26 +292,46 @@ def main():
     ap.add_argument("--frames", type=int, default=300)
     ap.add_argument("--me-range", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (stream check, PCIe-inclusive run, 2160p config, libx265 probe run)")
     ap.add_argument("--host-threads", type=int, default=0, help="CABAC worker threads (0 = library default)")
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
-    ap.add_argument("--intra-nxn", type=int, default=None, help="experiments only: override cfg.intra_nxn (4x4 PUs + DST in IDR pictures)")
-    ap.add_argument("--intra-tiles", type=int, default=None, help="experiments only: override cfg.intra_tiles (IDR tile grid)")
-    ap.add_argument("--pre-search", type=int, default=None, help="experiments only: override cfg.pre_search")
-    ap.add_argument("--rdo-zero", type=int, default=None, help="experiments only: override cfg.rdo_zero")
-    ap.add_argument("--intra-in-p", type=int, default=None, help="experiments only: override cfg.intra_in_p")
+    ap.add_argument("--stub", action="store_true", help="tests only: no GPU, no encoder — exercises the rank spawn / rendezvous / JSON path (tests/test_bench_ranks.py)")
+    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes"):
+        ap.add_argument("--" + name, type=int, default=None, help="experiments only: override cfg." + name.replace("-", "_"))
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args)                        # never returns
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    W, H, N = args.width, args.height, args.frames
+
+    if args.stub:
+        ranks = Ranks(rank, world)
+        ranks.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.01 * (1 + rank))
+        own = ranks.gather(time.perf_counter() - t0)         # every rank's own K steps
+        ranks.barrier()
+        dts = ranks.gather(time.perf_counter() - t0)         # barrier to barrier; the job takes the MAX over ranks
+        if rank == 0:
+            dt = max(dts)
+            print(json.dumps({"metric": METRIC, "value": round(world * args.steps * N / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                              "dtype": "u8", "data": "stub", "config": {"workload": "stub"}, "per_rank_fps": [round(args.steps * N / d, 2) for d in own], "stub": True}))
+        ranks.close()
+        return
+
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
+    if local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    ranks = Ranks(rank, world)
 
     from hevc_amd import _lib
     from hevc_amd.encoder import Encoder, config_for
@@ -104,59 +339,68 @@ def main():
     from hevc_amd.transcoder import calculate_apple_hevc_level, calculate_dynamic_values
     from hevc_amd.yuvio import SyntheticClip
 
-    W, H, N = args.width, args.height, args.frames
-    info = VideoInfo(W, H, 30.0, "bt709", "bt709", "bt709", "yuv420p", "", "", 0, False, "eng", N, N / 30.0)
-    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
-    level, tier = calculate_apple_hevc_level(info)
-    cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
+    def operating_point(w, h, n, hdr):
+        if hdr:
+            info = VideoInfo(w, h, 30.0, "bt2020", "smpte2084", "bt2020nc", "yuv420p10le", "", "", 0, True, "eng", n, n / 30.0)
+        else:
+            info = VideoInfo(w, h, 30.0, "bt709", "bt709", "bt709", "yuv420p", "", "", 0, False, "eng", n, n / 30.0)
+        crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
+        level, tier = calculate_apple_hevc_level(info)
+        return info, config_for(info, crf, maxrate, bufsize, gop, level, tier), (crf, maxrate, bufsize, gop)
+
+    info, cfg, (crf, maxrate, bufsize, gop) = operating_point(W, H, N, False)
     cfg.me_range, cfg.profile_stages = args.me_range, 1
     cfg.qp = args.qp
     cfg.host_threads = args.host_threads
-    if args.intra_nxn is not None:
-        cfg.intra_nxn = args.intra_nxn
-    if args.intra_tiles is not None:
-        cfg.intra_tiles = args.intra_tiles
-    for name in ("pre_search", "rdo_zero", "intra_in_p"):
+    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes"):
         if getattr(args, name) is not None:
             setattr(cfg, name, getattr(args, name))
 
     # synthetic clip -> HBM (untimed).  torch is plumbing for device memory only.
     clip = SyntheticClip("motion", rank, W, H, N)
-    ys, us, vs = [], [], []
-    for y, u, v in clip.frames():
-        ys.append(torch.from_numpy(y).cuda(non_blocking=False))
-        us.append(torch.from_numpy(u).cuda())
-        vs.append(torch.from_numpy(v).cuda())
+    clip.frame(0)                                    # builds the texture once, before the threads
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        host_frames = list(ex.map(clip.frame, range(N)))
+    ys = [torch.from_numpy(f[0]).cuda() for f in host_frames]
+    us = [torch.from_numpy(f[1]).cuda() for f in host_frames]
+    vs = [torch.from_numpy(f[2]).cuda() for f in host_frames]
     torch.cuda.synchronize()
 
     phase_s = np.zeros(4)       # open, send, flush+drain, close
 
-    def step():
+    def step(keep=None, host=False, c=cfg, frames=None, n=N):
         t0 = time.perf_counter()
-        enc = Encoder(cfg, device=local)
+        enc = Encoder(c, device=local)
         t1 = time.perf_counter()
         try:
             nbytes = 0
-            for i in range(N):
-                enc.send_device(ys[i].data_ptr(), us[i].data_ptr(), vs[i].data_ptr(), W, W // 2, pts=i)
-                for data, _pts, _key in enc.packets():
-                    nbytes += len(data)
+            for i in range(n):
+                if host:
+                    enc.send(*frames[i], pts=i)
+                else:
+                    enc.send_device(ys[i].data_ptr(), us[i].data_ptr(), vs[i].data_ptr(), W, W // 2, pts=i)
+                for pk in enc.packets():
+                    nbytes += len(pk[0])
+                    if keep is not None:
+                        keep.append(pk)
             t2 = time.perf_counter()
             enc.flush()
-            for data, _pts, _key in enc.packets():
-                nbytes += len(data)
+            for pk in enc.packets():
+                nbytes += len(pk[0])
+                if keep is not None:
+                    keep.append(pk)
             t3 = time.perf_counter()
             st = enc.stats()
             psnr = enc.psnr_y()
+            hdrs = enc.headers()
         finally:
             enc.close()
         t4 = time.perf_counter()
         phase_s[:] += (t1 - t0, t2 - t1, t3 - t2, t4 - t3)
-        return st, nbytes, psnr
+        return st, nbytes, psnr, hdrs
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
+        ranks.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -164,25 +408,28 @@ def main():
     phase_s[:] = 0
     barrier()
     t0 = time.perf_counter()
-    stage_ms = np.zeros(8)
-    stage_launch = np.zeros(8)
-    stage_pics = np.zeros(8)
-    last = None
-    for _ in range(args.steps):
-        st, nbytes, psnr = step()
+    stage_ms, stage_launch, stage_pics = np.zeros(8), np.zeros(8), np.zeros(8)
+    last, kept = None, []
+    for k in range(args.steps):
+        st, nbytes, psnr, hdrs = step(keep=kept if k == args.steps - 1 else None)
         stage_ms += np.array(st.stage_ms[:])
         stage_launch += np.array(st.stage_launches[:])
         stage_pics += np.array(st.stage_pictures[:])
-        last = (st, nbytes, psnr)
+        last = (st, nbytes, psnr, hdrs)
+    own = time.perf_counter() - t0                   # this rank's own K steps (every step ends with the last NAL byte on the host)
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dts = ranks.gather(time.perf_counter() - t0)     # barrier to barrier; the job takes the MAX over ranks
+    dt = max(dts)
+    own = ranks.gather(own)
+    st, nbytes, psnr, hdrs = last
+
+    # ---- untimed legs ----
+    check = {"stream_ok": None}
+    if not args.no_extras:
+        check = verify_stream(kept, hdrs, cfg, clip, st)            # every rank checks its own stream
+    oks = ranks.gather(1.0 if check.get("stream_ok") else 0.0)
 
     if rank == 0:
-        st, nbytes, psnr = last
         fps = world * args.steps * N / dt
         # roofline of the dominant kernel: algorithmic bytes per launch / mean launch time (HIP events on the session's
         # compute stream).  Per picture: inter_ctu reads source + reference and writes the reconstruction = 3*S;
@@ -194,17 +441,23 @@ def main():
         avg_ms = stage_ms[dom] / launches
         bytes_per_launch = per_pic[dom] * stage_pics[dom] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        traffic, traffic_src = measured_traffic("k_" + _lib.STAGE_NAMES[dom] if dom else "k_intra_diag", (W, H, N, args.me_range))
+        kname = "k_" + _lib.STAGE_NAMES[dom] if dom else "k_intra_diag"
+        traffic, traffic_src = measured_traffic(kname, (W, H, N, args.me_range))
+        valu = measured_valu(kname)
+        ok265, why265 = libx265_probe()
         out = {
-            "metric": "encoded 1080p30 frames/sec/GPU; PSNR-Y parity vs libx265 at matched bitrate",
+            "metric": METRIC,
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H}@30 SDR 8-bit Main, crf {crf} capped by VBV maxrate {maxrate} kbps / bufsize {bufsize} kbit "
                                    f"(the reference's libx265 operating point), {N}-frame synthetic 'motion' clip per GPU, "
-                                   f"keyint {gop}, IPPP, full-search +-{args.me_range}, one clip per GPU"},
-            "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1),
-                        "libx265_parity": "unavailable: no ffmpeg/libx265 on this host"},
+                                   f"keyint {gop}, IPPP, full-search +-{args.me_range}, one clip per GPU, input resident in HBM"},
+            "per_rank_fps": [round(args.steps * N / d, 2) for d in own],
+            "stream_ok": bool(all(o == 1.0 for o in oks)) if not args.no_extras else None,
+            "stream_check": check,
+            "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1), "vbv_maxrate_kbps": maxrate,
+                        "libx265_parity": "see `libx265`" if ok265 else why265},
             "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(stage_ms[i] / max(1.0, stage_pics[i]), 4) for i in range(8)},
             "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count(),
                      "step_phases_ms": dict(zip(("open", "send", "flush_drain", "close"), [round(x / args.steps * 1e3, 2) for x in phase_s])),
@@ -213,13 +466,47 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "avg_launch_ms": round(avg_ms, 4), "pictures_per_launch": round(stage_pics[dom] / launches, 2),
-                         "note": "integer-VALU/LDS bound path: the HBM fraction is small by construction (SURVEY.md §0.5)"},
+                         "valu_issue_frac": valu["valu_issue_frac"] if valu else None, "valu": valu,
+                         "note": "integer-VALU/LDS bound path: the HBM fraction is small by construction (SURVEY.md §0.5); valu_issue_frac is the "
+                                 "share of SIMD issue slots the kernel fills, from the committed SQ counter pass"},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_extras:
+            # the boundary hands over HOST buffers (mihevc_send_frame): the same clip, upload inside the clock
+            n_p = max(1, min(args.steps, 3))
+            step(host=True, frames=host_frames)
+            t1 = time.perf_counter()
+            for _ in range(n_p):
+                step(host=True, frames=host_frames)
+            out["value_pcie_inclusive"] = round(n_p * N / (time.perf_counter() - t1), 2)
+            out["configs"] = {"1080p30_sdr_8bit": {"fps_hbm_resident": round(fps / world, 2), "fps_pcie_inclusive": out["value_pcie_inclusive"],
+                                                    "bitrate_kbps": out["quality"]["bitrate_kbps"], "psnr_y_db": out["quality"]["psnr_y_db"]}}
+            del ys[:], us[:], vs[:]
+            out["configs"]["2160p30_hdr10_main10"] = run_2160p(local, operating_point, step, SyntheticClip, verify_stream)
+            out["libx265"] = libx265_baseline(info, host_frames, 8) if ok265 else {"available": False, "reason": why265}
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(W, H, st.last_qp, args.me_range)
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    ranks.barrier()
+    ranks.close()
+
+
+def run_2160p(local, operating_point, step, SyntheticClip, verify, n=120):
+    """BASELINE configs[2]: 3840x2160 Main10 HDR10 at the reference's operating point, host buffers in (PCIe-inclusive), 120 frames
+    (2 closed GOPs of keyint 60: half of the 4 lanes a longer clip keeps busy)."""
+    w, h = 3840, 2160
+    info, cfg, (crf, maxrate, bufsize, gop) = operating_point(w, h, n, True)
+    clip = SyntheticClip("motion", 0, w, h, n, bit_depth=10)
+    clip.frame(0)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        frames = list(ex.map(clip.frame, range(n)))
+    kept = []
+    step(host=True, frames=frames, c=cfg, n=n)
+    t0 = time.perf_counter()
+    st, nbytes, psnr, hdrs = step(keep=kept, host=True, frames=frames, c=cfg, n=n)
+    dt = time.perf_counter() - t0
+    chk = verify(kept, hdrs, cfg, clip, st, limit=4)
+    return {"fps_pcie_inclusive": round(n / dt, 2), "frames": n, "bitrate_kbps": round(nbytes * 8 / (n / 30.0) / 1e3, 1), "vbv_maxrate_kbps": maxrate,
+            "psnr_y_db": round(psnr, 3), "crf": crf, "keyint": gop, "first_pictures_decode": chk.get("stream_ok"), "pictures_decoded": chk.get("pictures_decoded")}
 
 
 if __name__ == "__main__":

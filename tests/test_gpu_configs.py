@@ -1,0 +1,172 @@
+"""GPU (-m gpu): the BASELINE.json configurations themselves, deterministically.
+
+config 2 — 1920x1080 8-bit Main at the reference's libx265 operating point (crf 19, vbv-maxrate 2940, vbv-bufsize 3528, keyint 90:
+/root/reference core/transcoder.py:398-411), and config 3 — 3840x2160 Main10 HDR10 (level 5, 10x11 IDR tile grid, 12-slot symbol ring,
+the HDR10 set of core/utils.py:58-69).  Each: per-stage HIP vs oracle on I+P(+P) of the bench clip (`SyntheticClip("motion")`) including
+the integer-search dump, then a session at the operating point whose stream must decode (oracle decoder) to the encoder's reconstruction.
+The fuzz tests draw their sizes at random and never reached these two geometries."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from hevc_amd import _lib
+    L = _lib.load()
+    assert L.mihevc_device_count() >= 1, "no gfx950 device visible: the GPU tests need an MI355X"
+    return L
+
+
+@pytest.fixture(scope="module")
+def api(lib):
+    return util.StageApi(lib, "mihevc_k_", device=0)
+
+
+def operating_point(w, h, hdr, n):
+    """mihevc_config exactly as encode_file / bench.py derive it from the reference's policy functions"""
+    from hevc_amd.encoder import config_for
+    from hevc_amd.probe import VideoInfo
+    from hevc_amd.transcoder import calculate_apple_hevc_level, calculate_dynamic_values
+    if hdr:
+        info = VideoInfo(w, h, 30.0, "bt2020", "smpte2084", "bt2020nc", "yuv420p10le", "", "", 0, True, "eng", n, n / 30.0)
+    else:
+        info = VideoInfo(w, h, 30.0, "bt709", "bt709", "bt709", "yuv420p", "", "", 0, False, "eng", n, n / 30.0)
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
+    level, tier = calculate_apple_hevc_level(info)
+    return config_for(info, crf, maxrate, bufsize, gop, level, tier), (crf, maxrate, bufsize, gop, level)
+
+
+def clip_frames(w, h, bd, n, seed=0):
+    """first n pictures of the bench clip, padded to the coded size by edge replication (what the session's ingest does)"""
+    from hevc_amd.yuvio import SyntheticClip
+    cw, ch = (w + 7) & ~7, (h + 7) & ~7
+    out = []
+    for y, u, v in SyntheticClip("motion", seed, w, h, n, bit_depth=bd).frames():
+        out.append(((y, u, v), O.Frame(np.pad(y, ((0, ch - h), (0, cw - w)), mode="edge"), np.pad(u, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"),
+                                       np.pad(v, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"))))
+    return out
+
+
+def session_params(lib, cfg, qp, idr):
+    """oracle + device cost parameters of one picture of a session opened with cfg (the knobs the session passes to its kernels)"""
+    from hevc_amd import _lib
+    cp = _lib.cost_params(qp, cfg.bit_depth, cfg.me_range if cfg.me_range > 0 else 15)
+    if idr:
+        cp.tile_cols, cp.tile_rows = _lib.tile_grid(cfg)
+    cp.intra_nxn, cp.intra_in_p, cp.pre_search, cp.rdo_zero, cp.chroma_modes = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.chroma_modes
+    prm = O.Params(cp.qp, cp.qp_c, cp.bit_depth, cp.lambda_sad_q4, cp.lambda_q4, cp.me_range, cp.tile_cols, cp.tile_rows, cp.intra_nxn, cp.intra_in_p,
+                   cp.pre_search, cp.rdo_zero, cp.chroma_modes)
+    return prm, cp
+
+
+def stage_parity(lib, api, cfg, frames, qp_p):
+    bd = cfg.bit_depth
+    ref = None
+    for i, (_, src) in enumerate(frames):
+        prm, cp = session_params(lib, cfg, max(0, qp_p - 3) if i == 0 else qp_p, i == 0)
+        want = O.analyze_intra(src, prm) if i == 0 else O.analyze_inter(src, ref, prm, dump_me=True)
+        got = api.intra(src, cp) if i == 0 else api.inter(src, ref, cp)
+        if i:
+            assert np.array_equal(want.me, got.me), f"picture {i}: integer search differs"
+            assert (want.cu["flags"] & 1).all() or cfg.intra_in_p
+        assert util.same_analysis(want, got), f"picture {i}: " + util.describe_diff(want, got)
+        d = O.deblock(want.rec, want.cu, bd)
+        assert api.deblock(want.rec, want.cu, bd).same(d), f"deblock picture {i}"
+        f, sp = O.sao(src, d, prm)
+        gf, gsp = api.sao(src, d, cp)
+        assert np.array_equal(gsp, sp), f"sao params picture {i}"
+        assert gf.same(f), f"sao picture {i}"
+        ref = f
+
+
+def run_session(cfg, frames):
+    from hevc_amd.encoder import Encoder
+    stream, sizes = b"", []
+    with Encoder(cfg, device=0, keep_recon=True) as enc:
+        for (y, u, v), _ in frames:
+            enc.send(y, u, v)
+        enc.flush()
+        for data, pts, key in enc.packets():
+            stream += data
+            sizes.append(len(data) * 8)
+        infos = [enc.frame_info(i) for i in range(len(frames))]
+        recs = [O.Frame(*enc.recon(i)) for i in range(len(frames))]
+        st = enc.stats()
+    return stream, sizes, infos, recs, st
+
+
+def replay(lib, cfg, frames, infos, recs, upto):
+    """the oracle pipeline with the session's per-picture QPs must give the session's reconstruction"""
+    ref = None
+    for i in range(upto):
+        qp, st, _ = infos[i]
+        prm, _ = session_params(lib, cfg, qp, st == 2)
+        src = frames[i][1]
+        a = O.analyze_intra(src, prm) if st == 2 else O.analyze_inter(src, ref, prm)
+        ref, _ = O.sao(src, O.deblock(a.rec, a.cu, cfg.bit_depth), prm)
+        assert recs[i].same(ref), f"picture {i} (qp {qp}): session reconstruction != oracle pipeline"
+
+
+def test_config2_1080p_stage_parity_i_p_p(lib, api):
+    cfg, (crf, maxrate, bufsize, gop, level) = operating_point(1920, 1080, False, 300)
+    assert (crf, maxrate, bufsize, gop, level) == (19, 2940, 3528, 90, "4")          # SURVEY App. A golden
+    from hevc_amd import _lib
+    assert _lib.tile_grid(cfg) == (5, 5)
+    stage_parity(lib, api, cfg, clip_frames(1920, 1080, 8, 3), crf + 2)
+
+
+def test_config2_1080p_session_at_the_reference_operating_point(lib):
+    n = 12
+    cfg, (crf, maxrate, bufsize, gop, _) = operating_point(1920, 1080, False, 300)
+    frames = clip_frames(1920, 1080, 8, n)
+    stream, sizes, infos, recs, st = run_session(cfg, frames)
+    assert st.frames_out == n
+    dec, info = O.decode(stream)
+    assert len(dec) == n and (info["width"], info["height"], info["conf_width"], info["conf_height"]) == (1920, 1080, 1920, 1080)
+    assert info["sps.profile_idc"] == 1 and info["sps.level_idc"] == 120 and (info["pps.tile_cols"], info["pps.tile_rows"]) == (5, 5)
+    for i in range(n):
+        assert dec[i].same(recs[i]), f"frame {i}: decoded picture != encoder reconstruction"
+    assert [t for _, t, _ in infos] == [2] + [1] * (n - 1)
+    assert all(q >= crf + 2 for q, _, _ in infos[1:]) and infos[0][0] >= crf - 1        # CRF is the quality ceiling; the VBV cap only raises QP
+    assert [b for _, _, b in infos] == sizes
+    replay(lib, cfg, frames, infos, recs, 3)
+    y = np.stack([f[0][0] for f in frames]).astype(np.float64)
+    r = np.stack([x.y[:1080] for x in recs]).astype(np.float64)
+    assert 10 * np.log10(255.0 ** 2 / np.mean((y - r) ** 2)) > 36.0
+
+
+def test_config3_2160p_main10_hdr10_stage_parity_i_p(lib, api):
+    cfg, (crf, maxrate, bufsize, gop, level) = operating_point(3840, 2160, True, 300)
+    assert (crf, maxrate, bufsize, gop, level) == (19, 11760, 14112, 60, "5") and cfg.bit_depth == 10 and cfg.hrd == 1
+    from hevc_amd import _lib
+    assert _lib.tile_grid(cfg) == (10, 11)
+    stage_parity(lib, api, cfg, clip_frames(3840, 2160, 10, 2), crf + 2)
+
+
+def test_config3_2160p_main10_hdr10_session(lib):
+    n = 6
+    cfg, (crf, maxrate, bufsize, gop, _) = operating_point(3840, 2160, True, 300)
+    frames = clip_frames(3840, 2160, 10, n)
+    stream, sizes, infos, recs, st = run_session(cfg, frames)
+    assert st.frames_out == n
+    dec, info = O.decode(stream)
+    assert len(dec) == n and (info["width"], info["height"], info["bit_depth"]) == (3840, 2160, 10)
+    for i in range(n):
+        assert dec[i].same(recs[i]), f"frame {i}: decoded picture != encoder reconstruction"
+    # Main10, level 5, 10x11 IDR tiles, HDR10 signalling (core/utils.py:58-69 defaults), HRD + buffering period / picture timing SEI
+    assert info["sps.profile_idc"] == 2 and info["sps.level_idc"] == 150 and (info["pps.tile_cols"], info["pps.tile_rows"]) == (10, 11)
+    assert (info["vui.colour_primaries"], info["vui.transfer"], info["vui.matrix"], info["vui.full_range"]) == (9, 16, 9, 0)
+    assert (info["sei.mdcv.gx"], info["sei.mdcv.gy"], info["sei.mdcv.bx"], info["sei.mdcv.by"], info["sei.mdcv.rx"], info["sei.mdcv.ry"]) == (13250, 34500, 7500, 3000, 34000, 16000)
+    assert (info["sei.mdcv.wpx"], info["sei.mdcv.wpy"], info["sei.mdcv.max_lum"], info["sei.mdcv.min_lum"]) == (15635, 16450, 10000000, 50)
+    assert (info["sei.cll.max_cll"], info["sei.cll.max_fall"]) == (1000, 400)
+    assert info["count.aud"] == n and info["vui.hrd_present"] == 1 and info["count.sei_bp"] == 1 and info["count.sei_pt"] == n
+    rate = (info["hrd.bit_rate_value_minus1"] + 1) << (6 + info["hrd.bit_rate_scale"])
+    cpb = (info["hrd.cpb_size_value_minus1"] + 1) << (4 + info["hrd.cpb_size_scale"])
+    assert abs(rate - maxrate * 1000) <= maxrate * 10 and abs(cpb - bufsize * 1000) <= bufsize * 10
+    assert all(q >= crf + 2 for q, _, _ in infos[1:])
+    replay(lib, cfg, frames, infos, recs, 2)

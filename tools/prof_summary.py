@@ -4,6 +4,15 @@
   python tools/prof_summary.py stats  <dir-with-*kernel_stats.csv>                 -> kernel table on stdout
   python tools/prof_summary.py pmc    <dir-with-*counter_collection.csv> [...]     -> per-kernel mean counter per dispatch
   python tools/prof_summary.py traffic <fetch-dir> <write-dir> <out.json>          -> HBM bytes per launch per kernel
+  python tools/prof_summary.py pmcjson <out.json> <dir> [...]                      -> per-kernel VALU issue share (bench.py reads it)
+
+Normalisation of the SQ counters (stated because the raw numbers cannot be read without it): every value printed by `pmc` is the MEAN
+PER DISPATCH of what rocprofv3 wrote for that kernel.  On this pool rocprofv3 reports the SQ block of a subset of the shader engines
+(SQ_WAVES comes out near 1/20 of the waves a grid launches), so absolute values are a sample; ratios of two SQ counters of the same
+pass are not affected, and only such ratios are used: valu_active_per_wave = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both quad-cycles
+summed over the same sampled waves) = share of a wave's resident time in which it issues vector ALU work; valu_issue_frac = that
+times the waves resident per SIMD (workgroups per CU from the kernel's __launch_bounds__ x 4 waves / 4 SIMDs), capped at 1 = share
+of a SIMD's issue slots the kernel fills.  wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked at s_waitcnt / barrier).
 
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md (HBM section) gfx950's
 FETCH_SIZE tallies 128-byte requests as 64 bytes, so reads are doubled; WRITE_SIZE is taken as is.
@@ -71,6 +80,32 @@ def traffic(fd, wd, outp):
     print(json.dumps(res, indent=1))
 
 
+# workgroups (= waves per SIMD: 256 threads = 4 waves over 4 SIMDs) per CU from the kernels' __launch_bounds__ in csrc/device.hip
+WAVES_PER_SIMD = {"k_inter_ctu": 4, "k_intra_diag": 3, "k_me_search": 3, "k_sao_decide": 4, "k_intra_p": 3}
+
+
+def pmcjson(outp, dirs):
+    acc = {}
+    for d in dirs:
+        for k, cs in pmc_means(d).items():
+            if "mihevc" not in k or "unsigned short" in k:
+                continue
+            name = k.split("::")[-1].split("<")[0]
+            acc.setdefault(name, {}).update({c: v[0] / max(1, v[1]) for c, v in cs.items()})
+    res = {}
+    for name, c in acc.items():
+        if not c.get("SQ_WAVE_CYCLES") or "SQ_ACTIVE_INST_VALU" not in c:
+            continue
+        per_wave = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
+        occ = WAVES_PER_SIMD.get(name, 8)
+        res[name] = {"valu_active_per_wave": round(per_wave, 4), "waves_per_simd": occ, "valu_issue_frac": round(min(1.0, per_wave * occ), 4),
+                     "wait_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in c else None,
+                     "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1) if c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c else None}
+    json.dump({"source": "rocprofv3 --pmc SQ_* passes of tests/prof_clip.py (tools/pmc_kernels.sh); ratios of counters of one pass, see tools/prof_summary.py",
+               "kernels": res}, open(outp, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
     cmd = sys.argv[1]
     if cmd == "stats":
@@ -79,3 +114,5 @@ if __name__ == "__main__":
         pmc(sys.argv[2:])
     elif cmd == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif cmd == "pmcjson":
+        pmcjson(sys.argv[2], sys.argv[3:])
