@@ -686,4 +686,17 @@ int mihevc_k_sao(int device, const void *sy, const void *su, const void *sv, con
     return MIHEVC_EINVAL;
 }
 
+#ifdef MIHEVC_PHASE_PROF
+// diagnostic build only: read (and optionally clear) the per-call-site cycle table of GpuExec::phase
+int mihevc_debug_phase_profile(unsigned long long *out, int reset)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mihevc::g_phase_prof), sizeof(unsigned long long) * 8 * 1024 * 3) != hipSuccess) return MIHEVC_EDEVICE;
+    if (reset) {
+        static unsigned long long zero[8 * 1024 * 3];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mihevc::g_phase_prof), zero, sizeof zero) != hipSuccess) return MIHEVC_EDEVICE;
+    }
+    return MIHEVC_OK;
+}
+#endif
+
 }  // extern "C"

@@ -409,6 +409,9 @@ DEV int hadamard8_ac(int (&m)[8][8])
 
 // ------------------------------------------------------------------------------------------ executors
 #if MIHEVC_GPU
+#ifdef MIHEVC_PHASE_PROF
+__device__ unsigned long long g_phase_prof[8 * 1024 * 3];
+#endif
 struct GpuExec {
     // The lane id reaches every phase through an opaque asm: without it LLVM hoists each phase's lane-index arithmetic to the
     // kernel entry and keeps it all live across the whole CTU program (k_intra_diag: 88 VGPR spill stores at entry, 92 MB of
@@ -419,11 +422,34 @@ struct GpuExec {
         asm volatile("" : "+v"(t));
         return t;
     }
+#ifdef MIHEVC_PHASE_PROF
+    // diagnostic build only (libmihevc_prof.so, tools/phase_profile.py): cycles of wave 0 per call site — its own work and the whole phase
+    // including the barrier — summed into a table indexed by the source line of the ex.phase() call
+    template <class F> DEV void phase(F &&f, int line = __builtin_LINE(), const char *file = __builtin_FILE())
+    {
+        // slot = (file id, line): the id comes from three characters of the header's name (inter.h 6, intra.h 7, residual.h 2, loopfilter.h 0, device.hip 5)
+        int len = 0;
+        while (file[len]) len++;
+        const int fid = ((int)file[len - 3] + 2 * (int)file[len - 4] + 3 * (int)file[len - 6]) & 7;
+        const int slot = (fid * 1024 + (line & 1023)) * 3;
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        f(lane_id());
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            atomicAdd(&g_phase_prof[slot], t2 - t0);
+            atomicAdd(&g_phase_prof[slot + 1], t1 - t0);
+            atomicAdd(&g_phase_prof[slot + 2], 1ull);
+        }
+    }
+#else
     template <class F> DEV void phase(F &&f)
     {
         f(lane_id());
         __syncthreads();
     }
+#endif
     // A step whose producers and consumers all sit in ONE wave (lanes tid < 64): no workgroup barrier, only wave-scope
     // ordering — LDS operations of a wave execute in issue order, the fence keeps the compiler from moving them across.
     // The caller closes the sequence of wave steps with a full phase() before other waves look at the results.

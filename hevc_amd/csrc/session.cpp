@@ -31,11 +31,15 @@ using namespace mihevc;
 
 namespace {
 
-constexpr int kRing = 12;     // symbol slots per lane (capacity): 0..2 hold the IDR picture's QP variants, the rest rotate over the P steps.
+constexpr int kRing = 12;     // symbol slots per lane (capacity): slot 0 holds the IDR picture, the rest rotate over the P steps.
                               // A session uses s->ring of them: 8 up to 1080p-class levels, 12 from level 5 (2160p+), where the CABAC of one
                               // picture (12 ms at 2160p, 45 ms at 4320p) outlasts five device steps when few GOP lanes are busy
-constexpr int kVariants = 3;  // IDR pictures under rate control are analysed at QP, QP+5, QP+10 in ONE set of launches
-constexpr int kVariantStep = 5;
+constexpr int kIdrStart = 5;  // first chunk of a session: IDR pictures under rate control are analysed at the CRF's IDR QP + 5, then re-analysed only
+                              // where the rate model asks for a QP at least kIdrRedo away (round 1 analysed every IDR at three QPs: 23 % of device time)
+constexpr int kIdrRedo = 2;
+constexpr double kBudgetShare = 0.985;   // a GOP is planned to 98.5 % of vbv-maxrate x its duration: the estimate-to-CABAC ratio is known to ~1 %
+constexpr double kCpbStart = 0.9;        // CPB fullness every closed GOP may assume at its IDR (= the buffering period SEI's initial delay)
+constexpr double kIdrCpbShare = 0.85;    // an IDR picture may take at most this share of that fullness
 
 class ThreadPool {
 public:
@@ -158,7 +162,6 @@ struct mihevc_session {
     struct Lane {
         void *rec_base[2][3], *rec_p[2][3]; int rec_stride[3];       // padded final reconstructions (ping-pong)
         void *work_base[3], *work_p[3]; int work_stride[3];           // pre-deblock / deblocked picture (unpadded)
-        void *var_base[kVariants - 1][3], *var_p[kVariants - 1][3];   // work pictures of IDR variants 1..
         int32_t *me = nullptr;
         IpInfo *ip = nullptr;      // per CTU: inter pass -> intra second pass of P pictures
         void *lsrc = nullptr, *lref = nullptr;   // 1/4-size source / reference luma of the step's picture (pre-search)
@@ -189,6 +192,7 @@ struct mihevc_session {
     double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
     bool rho_measured = false;                // the session's first chunk measures rho with a trial analysis of the GOPs' first P picture
     double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
+    int idr_qp_hint = -1;                     // mean IDR QP the last chunk settled on: where the next chunk's IDR analysis starts
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
     std::atomic<long long> entropy_ns{0};
@@ -235,8 +239,6 @@ int ensure_lanes(mihevc_session *s, int n)
         for (int k = 0; k < 2; k++)
             if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, true)) return e;
         if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, false)) return e;
-        for (int v = 0; v < kVariants - 1; v++)
-            if (int e = alloc_planes(s, L.var_base[v], L.var_p[v], L.work_stride, false)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lsrc));
@@ -258,7 +260,7 @@ template <typename T> struct StepLayout {
     {
         auto al = [](size_t v) { return (v + 63) & ~(size_t)63; };
         intra = 0;
-        inter = al(intra + (size_t)kVariants * gops * sizeof(IntraArgs<T>));
+        inter = al(intra + (size_t)2 * gops * sizeof(IntraArgs<T>));      // [gops, 2 gops): the IDR re-analysis pass, compacted
         dbk_v = al(inter + gops * sizeof(InterArgs<T>));
         dbk_h = al(dbk_v + gops * sizeof(DeblockArgs<T>));
         sao = al(dbk_h + gops * sizeof(DeblockArgs<T>));
@@ -332,7 +334,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     SymLayout sl(s->w, s->h);
     const int steps = std::min(n, s->keyint);
     const int ring = s->ring;
-    auto slot_of = [ring](int t) { return t == 0 ? 0 : kVariants + (t - 1) % (ring - kVariants); };      // IDR variant v lives in slot v
+    auto slot_of = [ring](int t) { return t == 0 ? 0 : 1 + (t - 1) % (ring - 1); };
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
     const size_t need = (size_t)(steps + 1) * lay.total;      // + one block for the rho trial (below)
@@ -408,15 +410,20 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
     HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
     // ---- per-lane rate controllers ----
+    // CPB model (x265 nal-hrd=vbr + vbv-maxrate / vbv-bufsize, reference core/transcoder.py:399-400).  The GOPs of a chunk are coded in
+    // lock-step, so a GOP cannot know the buffer level its predecessor leaves.  Every closed GOP is therefore planned to be buffer-neutral:
+    // it may assume the fullness kCpbStart x bufsize at its IDR (what the buffering period SEI announces for the first one), its IDR takes at
+    // most kIdrCpbShare of that, and its pictures together take at most kBudgetShare of what the channel delivers during the GOP — so the
+    // level at the next IDR is at least the assumed one again (tests replay the produced sizes through the Annex C arrival / removal schedule).
     const double fps = (double)s->cfg.fps_num / s->cfg.fps_den;
     std::vector<int> qp_prev(gops, s->qp_p), gop_len(gops, 0);
     std::vector<double> budget(gops, 0.0);
     for (int g = 0; g < gops; g++) {
         gop_len[g] = std::min(s->keyint, n - g * s->keyint);
-        budget[g] = s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
+        budget[g] = kBudgetShare * s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
     }
-    const double w_i = 8.0;                   // an IDR picture is budgeted like 8 P pictures
-    const int p_slots = s->ring - kVariants;  // a P step's CABAC job is complete once its slot has been handed out again
+    const double cpb_idr_cap = s->cfg.vbv_bufsize_kbits > 0 ? kIdrCpbShare * kCpbStart * s->cfg.vbv_bufsize_kbits * 1000.0 : 1e30;
+    const int p_slots = s->ring - 1;          // a P step's CABAC job is complete once its slot has been handed out again
     // P-picture QP of lane g at step t.  Every input is deterministic: CABAC sizes only of pictures whose ring slot has been
     // reused (steps <= t - p_slots), device estimates of steps <= t - 2 (the step loop waits for that copy), a model for the
     // picture in flight.  The controller solves for the constant QP that spends the rest of the GOP budget and walks towards
@@ -485,11 +492,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
     };
 #define STAGE(idx, pics, call) do { if (int e_ = mark(idx, pics, true)) return e_; HIPCK(s, call); if (int e_ = mark(idx, pics, false)) return e_; } while (0)
     for (int t = 0; t < steps; t++) {
-        const int B = batch[t], nv = (t == 0 && s->rc_on) ? kVariants : 1;
+        const int B = batch[t];
         const int slot0 = slot_of(t);
-        {   // the slots this step writes must have been drained by their previous CABAC jobs
+        {   // the slot this step writes must have been drained by its previous CABAC jobs
             std::unique_lock<std::mutex> l(s->m);
-            s->cv.wait(l, [&] { for (int v = 0; v < nv; v++) if (s->jobs_open[slot0 + v]) return false; return true; });
+            s->cv.wait(l, [&] { return s->jobs_open[slot0] == 0; });
         }
         StepView<T> dv(da, lay, t), hv(ha, lay, t);
         std::vector<int> qp_step(B), lane_slot(B, slot0);
@@ -507,74 +514,57 @@ template <typename T> int encode_chunk(mihevc_session *s)
             }
         }
         for (int g = 0; g < B; g++) {
-            qp_step[g] = t == 0 ? s->qp_i : (s->rc_on ? decide_p(g, t) : s->qp_p);
+            // IDR pictures under rate control start where the last chunk's IDR pictures ended (first chunk: kIdrStart above the CRF's IDR QP)
+            const int q_idr = !s->rc_on ? s->qp_i : std::min(51, std::max(s->qp_i, s->idr_qp_hint >= 0 ? s->idr_qp_hint : s->qp_i + kIdrStart));
+            qp_step[g] = t == 0 ? q_idr : (s->rc_on ? decide_p(g, t) : s->qp_p);
             patch_qp(t, g, qp_step[g]);
             qp_prev[g] = qp_step[g];
         }
         if (t == 0) {
-            // IDR pictures: under rate control every lane is analysed at kVariants QPs in the SAME anti-diagonal launches
-            // (the wavefront leaves most CUs idle, so the extra variants ride along almost for free); the device's rate
-            // estimates then pick, per lane, the finest variant that fits the picture's share of the GOP budget
-            for (int v = 1; v < nv; v++)
-                for (int g = 0; g < B; g++) {
-                    IntraArgs<T> &A = hv.intra[v * B + g];
-                    A = hv.intra[g];
-                    mihevc_session::Lane &L = s->lane[g];
-                    uint8_t *sym = L.sym_dev[v];
-                    for (int i = 0; i < 3; i++) A.rec[i] = mk<T>(L.var_p[v - 1][i], L.work_stride[i]);
-                    A.prm = prm_for(std::min(51, qp_step[g] + kVariantStep * v));
-                    A.cu = (mihevc_cu_rec *)(sym + sl.cu);
-                    uint8_t *symh = L.sym_host[v];
-                    A.coef[0] = (int16_t *)(symh + sl.cy); A.coef[1] = (int16_t *)(symh + sl.cu_); A.coef[2] = (int16_t *)(symh + sl.cv);
-                    A.est = (unsigned long long *)(sym + sl.est);
-                }
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
-            for (int v = 0; v < nv; v++)
-                for (int g = 0; g < B; g++)
-                    HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[v] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
-            STAGE(0, nv * B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, nv * B, s->tiles.cols, s->tiles.rows));
-            if (nv > 1) {
+            for (int g = 0; g < B; g++) HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
+            STAGE(0, B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B, s->tiles.cols, s->tiles.rows));
+            if (s->rc_on) {
+                // ONE analysis per IDR picture, then the rate model decides: IDR bits scale as 2^(-dQP/6) around the analysed point, P size
+                // at the IDR's QP is rho x IDR size, the rest of the GOP budget is shared by the P pictures; wanted is the IDR QP whose
+                // predicted steady P QP sits 3 above it (the usual I/P offset), never finer than the CRF asks, and whose picture fits the
+                // share of the CPB an IDR may take.  Only lanes whose wanted QP is kIdrRedo or more away are analysed again, at that QP.
                 HIPCK(s, hipStreamSynchronize(s->st_compute));
-                // estimates of every variant, then the pick: the variant whose predicted steady P QP sits closest to IDR QP + 3 (the usual
-                // I/P offset).  P size at the IDR's QP is modelled as rho x IDR size, the rest of the budget is shared by the GOP's P pictures.
-                std::vector<std::array<unsigned long long, kVariants>> ev((size_t)B);
-                for (int g = 0; g < B; g++)
-                    for (int v = 0; v < nv; v++) HIPCK(s, hipMemcpy(&ev[(size_t)g][(size_t)v], s->lane[g].sym_dev[v] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                const std::vector<int> qp_base(qp_step);
-                auto pick_for = [&](int g, double rho) {
-                    int pick = nv - 1;
+                std::vector<unsigned long long> ev((size_t)B);
+                std::vector<int> qa(qp_step);                       // QP each lane's current analysis was made at
+                for (int g = 0; g < B; g++) HIPCK(s, hipMemcpy(&ev[(size_t)g], s->lane[g].sym_dev[0] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                auto want_for = [&](int g, double rho) {
+                    const double ib_a = std::max(1.0, (double)ev[(size_t)g] / 16.0 * s->ratio_i);
+                    int pick = 51;
                     double best_d = 1e30;
-                    for (int v = 0; v < nv; v++) {
-                        const double ib = std::max(1.0, (double)ev[(size_t)g][(size_t)v] / 16.0 * s->ratio_i), rest = budget[g] - ib;
-                        const int qi = std::min(51, qp_base[g] + kVariantStep * v);
+                    for (int q = s->qp_i; q <= 51; q++) {
+                        const double ib = ib_a * std::exp2((qa[(size_t)g] - q) / 6.0), rest = budget[g] - ib;
                         double d;
-                        if (gop_len[g] < 2) d = ib <= budget[g] ? -1e9 + v : 1e9 + ib;     // IDR-only GOP: finest that fits
+                        if (ib > cpb_idr_cap && q < 51) continue;
+                        if (gop_len[g] < 2) d = ib <= budget[g] ? -1e9 + q : 1e9 + ib;          // IDR-only GOP: finest that fits
                         else if (rest <= 0) d = 1e9 + ib;
                         else {
-                            const double q_ss = std::max((double)s->qp_p, qi + 6.0 * std::log2(ib * rho / (rest / (gop_len[g] - 1))));
-                            d = std::fabs(q_ss - (qi + 3));
+                            const double q_ss = std::max((double)s->qp_p, q + 6.0 * std::log2(ib * rho / (rest / (gop_len[g] - 1))));
+                            d = std::fabs(q_ss - (q + 3));
                         }
-                        if (d < best_d) { best_d = d; pick = v; }
+                        if (d < best_d) { best_d = d; pick = q; }
                     }
                     return pick;
                 };
-                std::vector<int> picks((size_t)B);
-                for (int g = 0; g < B; g++) picks[(size_t)g] = pick_for(g, s->rho_pi);
-                (void)w_i;
+                std::vector<int> want((size_t)B);
+                for (int g = 0; g < B; g++) want[(size_t)g] = want_for(g, s->rho_pi);
                 if (!s->rho_measured && steps > 1 && batch[1] > 0) {
                     // First chunk of a session: rho is only a prior (1/16).  Measure it: analyse every GOP's first P picture once against
-                    // the UNFILTERED reconstruction of the provisional pick (copied + padded into the reference buffer the real step 0
-                    // overwrites afterwards) at QP pick + 3, read the estimate, and pick again.  Costs one P step per session.
+                    // the UNFILTERED reconstruction of the IDR analysis (copied + padded into the reference buffer the real step 0
+                    // overwrites afterwards) at the wanted IDR QP + 3, read the estimate, and decide again.  Costs one P step per session.
                     const int B1 = batch[1], tb = steps;                 // trial block index
                     memcpy(ha + (size_t)tb * lay.total, ha + (size_t)1 * lay.total, lay.total);
                     StepView<T> tv(ha, lay, tb), dtv(da, lay, tb), h1(ha, lay, 1);
                     std::vector<int> qp_trial((size_t)B1);
                     for (int g = 0; g < B1; g++) {
                         mihevc_session::Lane &L = s->lane[g];
-                        const int pk = picks[(size_t)g];
-                        qp_trial[(size_t)g] = std::min(51, qp_base[g] + kVariantStep * pk + 3);
+                        qp_trial[(size_t)g] = std::min(51, want[(size_t)g] + 3);
                         tv.sao[g] = hv.sao[g];
-                        for (int i = 0; i < 3; i++) tv.sao[g].dbk[i] = pk ? mkc<T>(L.var_p[pk - 1][i], L.work_stride[i]) : mkc<T>(L.work_p[i], L.work_stride[i]);
                         tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr;
                         tv.inter[g] = h1.inter[g];
                         for (int i = 0; i < 3; i++) tv.inter[g].rec[i] = mk<T>(L.rec_p[1][i], L.rec_stride[i]);
@@ -595,40 +585,42 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     for (int g = 0; g < B1; g++) {
                         unsigned long long ep = 0;
                         HIPCK(s, hipMemcpy(&ep, s->lane[g].sym_dev[slot_of(1)] + sl.est, sizeof ep, hipMemcpyDeviceToHost));
-                        const unsigned long long ei = ev[(size_t)g][(size_t)picks[(size_t)g]];
-                        if (!ep || !ei) continue;
-                        lg += std::log2((double)ep / (double)ei) + 3.0 / 6.0;      // P estimate brought from QP + 3 to the IDR's QP
+                        if (!ep || !ev[(size_t)g]) continue;
+                        // both estimates brought to one QP: the P picture from its trial QP, the IDR picture from the QP it was analysed at
+                        lg += std::log2((double)ep / (double)ev[(size_t)g]) + (qp_trial[(size_t)g] - qa[(size_t)g]) / 6.0;
                         nl++;
                     }
                     if (nl) s->rho_pi = std::min(1.0, std::max(1.0 / 256, std::exp2(lg / nl)));
                     s->rho_measured = true;
-                    for (int g = 0; g < B; g++) picks[(size_t)g] = pick_for(g, s->rho_pi);
+                    for (int g = 0; g < B; g++) want[(size_t)g] = want_for(g, s->rho_pi);
                 }
+                std::vector<int> redo;
+                for (int g = 0; g < B; g++)
+                    if (std::abs(want[(size_t)g] - qa[(size_t)g]) >= kIdrRedo) redo.push_back(g);
+                if (!redo.empty()) {
+                    // second analysis of those lanes at the wanted QP into the same buffers (every CTU, record and non-zero TU is rewritten;
+                    // levels of TUs that are zero now are never read by the entropy coder): argument blocks compacted behind the first B
+                    for (size_t k = 0; k < redo.size(); k++) {
+                        const int g = redo[k];
+                        qp_step[g] = want[(size_t)g];
+                        patch_qp(t, g, qp_step[g]);
+                        hv.intra[B + (int)k] = hv.intra[g];
+                        HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
+                    }
+                    HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
+                    STAGE(0, (int)redo.size(), launch_intra_picture<T>(s->st_compute, dv.intra + B, s->ctus_w, s->ctus_h, (int)redo.size(), s->tiles.cols, s->tiles.rows));
+                    HIPCK(s, hipStreamSynchronize(s->st_compute));
+                    for (int g : redo) HIPCK(s, hipMemcpy(&ev[(size_t)g], s->lane[g].sym_dev[0] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                }
+                int sum_q = 0;
                 for (int g = 0; g < B; g++) {
-                    const int pick = picks[(size_t)g];
-                    const unsigned long long *e = ev[(size_t)g].data();
-                    lane_slot[g] = pick;
-                    qp_step[g] = std::min(51, qp_step[g] + kVariantStep * pick);
-                    patch_qp(t, g, qp_step[g]);
                     qp_prev[g] = qp_step[g];
-                    {
-                        std::lock_guard<std::mutex> l(s->m);
-                        auto &fr = s->frames[(size_t)(first_index + g * s->keyint)];
-                        fr.est_q4 = e[pick]; fr.est_known = true;
-                    }
-                    if (pick) {       // the loop filters and the symbol copy follow the chosen variant's buffers
-                        mihevc_session::Lane &L = s->lane[g];
-                        uint8_t *sym = L.sym_dev[pick];
-                        for (int i = 0; i < 3; i++) {
-                            hv.dbk_v[g].rec[i] = hv.dbk_h[g].rec[i] = mk<T>(L.var_p[pick - 1][i], L.work_stride[i]);
-                            hv.sao[g].dbk[i] = mkc<T>(L.var_p[pick - 1][i], L.work_stride[i]);
-                        }
-                        hv.dbk_v[g].cu = hv.dbk_h[g].cu = (const mihevc_cu_rec *)(sym + sl.cu);
-                        hv.sao[g].sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
-                        hv.sao[g].sse = (unsigned long long *)(sym + sl.sse);
-                    }
+                    sum_q += qp_step[g];
+                    std::lock_guard<std::mutex> l(s->m);
+                    auto &fr = s->frames[(size_t)(first_index + g * s->keyint)];
+                    fr.est_q4 = ev[(size_t)g]; fr.est_known = true;
                 }
-                HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
+                s->idr_qp_hint = (sum_q + B / 2) / B;
             }
         } else {
             {   // the step's QPs reach the device inside one tiny launch that also zeroes the slot's SSE + estimate accumulators; everything
@@ -674,7 +666,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 for (size_t k = 0; k < dst.size(); k++) dst[k] = s->is16 ? ((uint16_t *)tmp.data())[k] : tmp[k];
             }
         }
-        for (int v = 0; v < nv; v++) HIPCK(s, hipEventRecord(s->ev_copy[slot0 + v], s->st_copy));
+        HIPCK(s, hipEventRecord(s->ev_copy[slot0], s->st_copy));
         {
             std::lock_guard<std::mutex> l(s->m);
             for (int g = 0; g < B; g++) s->jobs_open[lane_slot[g]]++;
@@ -937,7 +929,6 @@ void mihevc_close(mihevc_session *s)
     for (auto &x : s->free_src) free3(x.base, 0);
     for (auto &L : s->lane) {
         free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
-        for (int v = 0; v < kVariants - 1; v++) free3(L.var_base[v], 0);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
         bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lsrc);

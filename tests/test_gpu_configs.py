@@ -170,3 +170,57 @@ def test_config3_2160p_main10_hdr10_session(lib):
     assert abs(rate - maxrate * 1000) <= maxrate * 10 and abs(cpb - bufsize * 1000) <= bufsize * 10
     assert all(q >= crf + 2 for q, _, _ in infos[1:])
     replay(lib, cfg, frames, infos, recs, 2)
+
+
+def hrd_arrival_schedule(sizes_bits, keys, bit_rate, init_delays_90k, fps):
+    """H.265 C.2.2 (cbr_flag = 0) + C.2.3 for a stream without reordering: picture n is removed at n / fps (the picture timing SEI counts
+    clock ticks since the last buffering period), its first bit may enter the CPB no earlier than its removal time minus the initial delay
+    announced by the LAST buffering period, and never before the previous picture has fully arrived.  Returns the smallest slack
+    (removal time - final arrival time) in seconds: negative = the CPB underflows."""
+    t_af, slack, delay = 0.0, 1e9, init_delays_90k[0] / 90000.0
+    k = 0
+    for n, (bits, key) in enumerate(zip(sizes_bits, keys)):
+        if key:
+            delay = init_delays_90k[min(k, len(init_delays_90k) - 1)] / 90000.0
+            k += 1
+        t_r = init_delays_90k[0] / 90000.0 + n / fps
+        t_ai = max(t_af, t_r - delay)
+        t_af = t_ai + bits / bit_rate
+        slack = min(slack, t_r - t_af)
+    return slack
+
+
+@pytest.mark.parametrize("w,h,bd,keyint,n,maxrate,bufsize", [(640, 352, 8, 30, 150, 600, 720), (416, 240, 10, 20, 130, 400, 480)])
+def test_cpb_schedule_of_the_produced_sizes_never_underflows(lib, w, h, bd, keyint, n, maxrate, bufsize):
+    """nal-hrd=vbr:vbv-maxrate:vbv-bufsize (reference core/transcoder.py:399-400): the sizes the session produces, fed through the
+    Annex C arrival / removal schedule that its own VUI HRD parameters + buffering period / picture timing SEI describe, never
+    underflow the CPB; the average rate stays under vbv-maxrate; the QP never drops below the CRF's."""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder
+    from hevc_amd.yuvio import SyntheticClip
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.me_range = w, h, bd, keyint, 2, 8
+    cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits, cfg.hrd, cfg.aud, cfg.level_idc = 19, -1, maxrate, bufsize, 1, 1, 93
+    sizes, keys, stream = [], [], b""
+    with Encoder(cfg, device=0) as enc:
+        for y, u, v in SyntheticClip("motion", 4, w, h, n, bit_depth=bd).frames():
+            enc.send(y, u, v)
+            for data, pts, key in enc.packets():
+                sizes.append(len(data) * 8); keys.append(key); stream += data
+        enc.flush()
+        for data, pts, key in enc.packets():
+            sizes.append(len(data) * 8); keys.append(key); stream += data
+        qps = [enc.frame_info(i)[0] for i in range(n)]
+    assert len(sizes) == n and keys == [i % keyint == 0 for i in range(n)]
+    dec, info = O.decode(stream[:sum(sizes[:keyint + 2]) // 8])          # two buffering periods' worth of SEI parsed back
+    assert info["vui.hrd_present"] == 1 and info["count.sei_bp"] == 2
+    rate = (info["hrd.bit_rate_value_minus1"] + 1) << (6 + info["hrd.bit_rate_scale"])
+    cpb = (info["hrd.cpb_size_value_minus1"] + 1) << (4 + info["hrd.cpb_size_scale"])
+    assert abs(rate - maxrate * 1000) <= 64 and abs(cpb - bufsize * 1000) <= 16
+    d0 = info["sei.bp.initial_delay"]
+    assert abs(d0 - 90000 * 0.9 * cpb / rate) <= 2
+    slack = hrd_arrival_schedule(sizes, keys, rate, [d0], 30.0)
+    assert slack >= 0.0, f"CPB underflow: a picture finishes arriving {-slack * 1e3:.1f} ms after its removal time"
+    assert sum(sizes) / (n / 30.0) <= maxrate * 1000, (sum(sizes) / (n / 30.0), maxrate * 1000)
+    assert max(sizes) <= 0.9 * cpb
+    assert min(qps[1:]) >= cfg.crf + 2 and min(qps) >= cfg.crf - 1 and max(qps) > cfg.crf + 2       # the cap had to bind on this clip
