@@ -313,7 +313,7 @@ def main():
         ranks.barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            time.sleep(0.01 * (1 + rank))
+            time.sleep(0.05 * (1 + rank))
         own = ranks.gather(time.perf_counter() - t0)         # every rank's own K steps
         ranks.barrier()
         dts = ranks.gather(time.perf_counter() - t0)         # barrier to barrier; the job takes the MAX over ranks

@@ -48,13 +48,25 @@ template <typename T> __global__ __launch_bounds__(NT, (sizeof(T) == 1 ? 4 : 3))
     inter_ctu_program<T>(ex, s, wy, wu, wv, a, ctu);
 }
 
-// blockIdx.x = tile * rows_per_tile + row inside the tile: every tile row holds at most one CTU of a diagonal
-// 3 workgroups per CU: with the tile grid a diagonal launch holds ~1800 CTUs (12 pictures x 25 tiles x <= 7 rows), so the kernel
-// is throughput-bound and needs the occupancy; measured per picture 4.02 ms (1, 298 VGPRs) / 2.33 (2) / 2.02 (3) / 2.21 (4, spills)
+// stage A of the intra pictures: every CTU of every picture in flight plans its quadtree and modes on the source picture (kernels/intra.h);
+// a throughput kernel like k_inter_ctu: 3 workgroups per CU fit its 50 KB of LDS (8 bit)
 #ifndef INTRA_OCC
 #define INTRA_OCC 3
 #endif
-template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int rows_per_tile)
+template <typename T> __global__ __launch_bounds__(NT, (sizeof(T) == 1 ? INTRA_OCC : 2)) void k_intra_plan(const IntraArgs<T> *args, int n_ctu)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int ctu = xcd_remap(blockIdx.x, n_ctu);
+    if (ctu >= n_ctu) return;
+    const IntraArgs<T> &a = args[blockIdx.y];
+    IntraShared<T> &s = *reinterpret_cast<IntraShared<T> *>(smem);
+    GpuExec ex;
+    intra_plan_program<T>(ex, s, a, ctu % a.ctus_w, ctu / a.ctus_w);
+}
+
+// stage B: blockIdx.x = tile * rows_per_tile + row inside the tile: every tile row holds at most one CTU of a diagonal.  A launch holds
+// few hundred CTU programs (pictures x tiles x rows), each a chain of barrier phases: latency bound, so the planned CUs are all it runs
+template <typename T> __global__ __launch_bounds__(NT, 2) void k_intra_diag(const IntraArgs<T> *args, int diagonal, int rows_per_tile)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const IntraArgs<T> &a = args[blockIdx.y];
@@ -67,7 +79,7 @@ template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_d
     if (cy >= cy1 || cx < cx0 || cx >= cx1) return;
     IntraShared<T> &s = *reinterpret_cast<IntraShared<T> *>(smem);
     GpuExec ex;
-    intra_ctu_program<T>(ex, s, a, cx, cy);
+    intra_code_program<T>(ex, s, a, cx, cy, true);
 }
 
 template <typename T> __global__ __launch_bounds__(256) void k_lowres(const PreArgs<T> *args)
@@ -83,7 +95,7 @@ template <typename T> __global__ __launch_bounds__(NT) void k_pre_search(const P
 }
 
 // intra second pass of P pictures: one workgroup per CTU, most of them leave at once (not a candidate of this round)
-template <typename T> __global__ __launch_bounds__(NT, INTRA_OCC) void k_intra_p(const IntraArgs<T> *args, int n_ctu, int round)
+template <typename T> __global__ __launch_bounds__(NT, 2) void k_intra_p(const IntraArgs<T> *args, int n_ctu, int round)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const IntraArgs<T> &a = args[blockIdx.y];
@@ -239,11 +251,15 @@ template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArg
 template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows)
 {
     size_t smem = round16(sizeof(IntraShared<T>));
-    hipError_t e = ensure_smem(k_intra_diag<T>, smem);
+    hipError_t e = ensure_smem(k_intra_plan<T>, smem);
+    if (e != hipSuccess) return e;
+    e = ensure_smem(k_intra_diag<T>, smem);
     if (e != hipSuccess) return e;
     if (tile_cols < 1) tile_cols = 1;
     if (tile_rows < 1) tile_rows = 1;
-    // uniform spacing: the widest column / tallest row is ceil(n_ctb / n_tiles)
+    const int n_ctu = ctus_w * ctus_h;
+    hipLaunchKernelGGL(k_intra_plan<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), smem, st, d_args, n_ctu);      // stage A: every CTU at once
+    // stage B, per tile one anti-diagonal at a time; uniform spacing: the widest column / tallest row is ceil(n_ctb / n_tiles)
     const int colw = (ctus_w + tile_cols - 1) / tile_cols, rowh = (ctus_h + tile_rows - 1) / tile_rows;
     for (int d = 0; d <= (colw - 1) + 2 * (rowh - 1); d++)
         hipLaunchKernelGGL(k_intra_diag<T>, dim3((unsigned)(tile_cols * tile_rows * rowh), (unsigned)batch), dim3(NT), smem, st, d_args, d, rowh);
@@ -477,14 +493,15 @@ int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, co
     if (src.alloc(w, h, false) || rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
     if (int e = src.upload(sy, su, sv)) return e;
     const size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h;
-    DevBuf dcu, dc0, dc1, dc2, dargs, dest;
+    DevBuf dcu, dc0, dc1, dc2, dargs, dest, dplan;
     CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dc0.alloc(ny * 2)); CK(dc1.alloc(ny / 2)); CK(dc2.alloc(ny / 2)); CK(dargs.alloc(sizeof(IntraArgs<T>)));
+    CK(dplan.alloc((size_t)((w + CTU - 1) / CTU) * ((h + CTU - 1) / CTU) * sizeof(IntraPlan)));
     CK(dest.alloc(8)); CK(hipMemset(dest.p, 0, 8));
     CK(hipMemset(dcu.p, 0, n8 * sizeof(mihevc_cu_rec)));
     IntraArgs<T> a;
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.rec[i] = rec.p[i].pl; }
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
-    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0; a.ip = nullptr;
+    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0; a.ip = nullptr; a.plan = dplan.as<IntraPlan>();
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows));
     CK(hipDeviceSynchronize());
@@ -545,7 +562,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
         for (int i = 0; i < 3; i++) { ia.src[i] = a.src[i]; ia.rec[i] = a.rec[i]; ia.coef[i] = a.coef[i]; }
         ia.w = w; ia.h = h; ia.ctus_w = ctus_w; ia.ctus_h = (h + CTU - 1) / CTU;
         ia.prm = a.prm; ia.prm.tile_cols = ia.prm.tile_rows = 1;
-        ia.cu = a.cu; ia.diagonal = 0; ia.est = a.est; ia.sparse_coef = 0; ia.ip = a.ip;
+        ia.cu = a.cu; ia.diagonal = 0; ia.est = a.est; ia.sparse_coef = 0; ia.ip = a.ip; ia.plan = nullptr;
         CK(diargs.alloc(sizeof ia));
         CK(hipMemcpy(diargs.p, &ia, sizeof ia, hipMemcpyHostToDevice));
         CK(launch_intra_p<T>(0, diargs.as<IntraArgs<T>>(), n_ctu, 1));

@@ -228,15 +228,57 @@ template <typename T>
 DEV void copy_window(T *lds, int ls, const T *plane, int pstride, int ox, int oy, int w, int h, int lo_x, int hi_x, int lo_y, int hi_y, int tid)
 {
     constexpr int per = 4 / (int)sizeof(T);            // samples per dword
+    constexpr int CH = 6;                              // row groups per batch: all their loads are issued before the first LDS store, so a lane
+                                                       // waits for memory once per batch, not once per row (the load phases of the CTU kernels
+                                                       // were chains of dependent round trips: profiles/r02 phase table)
     const int dpr = w / per, col = tid & 31, rg = tid >> 5;
-    for (int r = rg; r < h; r += NT / 32) {
-        const int y = clip3(lo_y, hi_y, oy + r);
-        const T *srow = plane + (ptrdiff_t)y * pstride;
-        for (int d = col; d < dpr; d += 32) {
-            const int x = clip3(lo_x, hi_x - (per - 1), ox + d * per);
-            uint32_t v = load_u32(srow + x);
-            __builtin_memcpy(__builtin_assume_aligned(lds + r * ls + d * per, 4), &v, 4);
+    for (int d = col; d < dpr; d += 32) {
+        const int x = clip3(lo_x, hi_x - (per - 1), ox + d * per);
+        for (int r0 = rg; r0 < h; r0 += CH * (NT / 32)) {
+            uint32_t v[CH];
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int r = r0 + k * (NT / 32);
+                if (r < h) v[k] = load_u32(plane + (ptrdiff_t)clip3(lo_y, hi_y, oy + r) * pstride + x);
+            }
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                const int r = r0 + k * (NT / 32);
+                if (r < h) __builtin_memcpy(__builtin_assume_aligned(lds + r * ls + d * per, 4), &v[k], 4);
+            }
         }
+    }
+}
+
+// the workgroup's CTU source image (Y 32x32, then U, V 16x16; zero outside the picture) — dword loads for whole CTUs, all of a lane's
+// loads in flight together; sample-wise only for the partial CTUs at the right / bottom picture edge
+template <typename T>
+DEV void load_ctu_source(T *dst, const Plane<const T> (&src)[3], int x0, int y0, int w, int h, int tid)
+{
+    constexpr int per = 4 / (int)sizeof(T);
+    if (x0 + CTU <= w && y0 + CTU <= h) {
+        constexpr int ND = 1536 / per, IT = (ND + NT - 1) / NT;
+        uint32_t v[IT];
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int d = tid + k * NT;
+            if (d < ND) {
+                const int i = d * per, pl = i < 1024 ? 0 : 1 + ((i - 1024) >> 8), kk = pl ? (i - 1024) & 255 : i, x = pl ? kk & 15 : kk & 31, y = pl ? kk >> 4 : kk >> 5;
+                v[k] = load_u32(src[pl].p + (size_t)((pl ? y0 >> 1 : y0) + y) * src[pl].stride + (pl ? x0 >> 1 : x0) + x);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < IT; k++) {
+            const int d = tid + k * NT;
+            if (d < ND) __builtin_memcpy(__builtin_assume_aligned(dst + d * per, 4), &v[k], 4);
+        }
+        return;
+    }
+    for (int i = tid; i < 1536; i += NT) {
+        int pl, x, y;
+        if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
+        const int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? w >> 1 : w, ph = pl ? h >> 1 : h;
+        dst[i] = (gx < pw && gy < ph) ? src[pl].p[(size_t)gy * src[pl].stride + gx] : (T)0;
     }
 }
 

@@ -198,6 +198,10 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
     const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
     ex.phase([&](int tid) {
+        if (sizeof(T) == 1 && x0 + CTU <= a.w && y0 + CTU <= a.h) {      // whole 8-bit CTU: one dword per lane
+            const uint32_t v = load_u32(a.src[0].p + (size_t)(y0 + (tid >> 3)) * a.src[0].stride + x0 + 4 * (tid & 7));
+            store_u32_aligned(s.src + 4 * tid, v);
+        } else
         for (int i = tid; i < 1024; i += NT) {
             int x = x0 + (i & 31), y = y0 + (i >> 5);
             s.src[i] = (x < a.w && y < a.h) ? (uint8_t)(a.src[0].p[(size_t)y * a.src[0].stride + x] >> msb) : (uint8_t)0;
@@ -292,7 +296,11 @@ template <typename T> struct InterShared {
     int mvx[21], mvy[21];
     unsigned cost[21];           // current best cost of each node (SATD << 4 + lambda * mvd bits)
     uint8_t valid[21];
-    int satd[3][9][16];          // [level][candidate][tile]
+    int satd[3][1][16];          // [level][0][tile]: tile SATDs at the integer vectors
+    unsigned nsum[21];           // per node: sum of its tiles' integer-vector SATDs
+    unsigned fsum[8][21];        // per ring candidate and chosen node: sum of its tiles' SATDs (LDS atomics from the tile lanes)
+    unsigned j16[4];
+    int use16[4], use32;
     uint8_t alias[3][16];        // level whose SATDs stand for (level, tile): a coarser node with the SAME vector as a finer one is not recomputed
     int tile_mvx[16], tile_mvy[16];
     uint8_t tile_node[16];
@@ -552,18 +560,13 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
 
     residual_init(ex, s.rs);
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1536; i += NT) {
-            int pl, x, y;
-            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
-            int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
-            s.src[i] = (gx < pw && gy < ph) ? a.src[pl].p[(size_t)gy * a.src[pl].stride + gx] : (T)0;
-        }
+        load_ctu_source<T>(s.src, a.src, x0, y0, a.w, a.h, tid);
         copy_window<T>(win_y, wys, a.ref[0].p, a.ref[0].stride, oy_x, oy_y, wy, wy, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, tid);
         copy_window<T>(win_u, wcs, a.ref[1].p, a.ref[1].stride, oc_x, oc_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
         copy_window<T>(win_v, wcs, a.ref[2].p, a.ref[2].stride, oc_x, oc_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
         if (tid < 21) {
             const int32_t *m = a.me + ((size_t)ctu * 21 + tid) * 3;
-            s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.valid[tid] = m[2] >= 0; s.cost[tid] = 0;
+            s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.valid[tid] = m[2] >= 0; s.cost[tid] = 0; s.nsum[tid] = 0;
         }
     });
     // SATD of every node at its INTEGER vector: the quadtree is decided on these (+ lambda * mvd bits), the fractional search then
@@ -586,43 +589,44 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.satd[level][0][t] = luma_tile_int<T>(win_y, py * wys + px, wys, s.src + typ * 8 * 32 + txp * 8, 32);
         }
     });
+    // every (level, tile) lane adds its tile's SATD (its own or the finer level's it aliases) to the node's sum
     ex.phase([&](int tid) {
-        if (tid >= 21 || !s.valid[tid]) return;
-        int nx, ny, nl;
-        node_geom(tid, nx, ny, nl);
-        int level = 5 - nl, tiles = 1 << (nl - 3);
-        unsigned satd = 0;
-        for (int j = 0; j < tiles; j++)
-            for (int i = 0; i < tiles; i++) { int t = ((ny >> 3) + j) * 4 + (nx >> 3) + i; satd += (unsigned)s.satd[s.alias[level][t]][0][t]; }
-        s.cost[tid] = (satd << 4) + (unsigned)(lam * (mvd_bits(s.mvx[tid] - 4 * sx) + mvd_bits(s.mvy[tid] - 4 * sy)));
+        if (tid < 3 * 16) {
+            const int level = tid >> 4, t = tid & 15, node = node_of_tile(level, t & 3, t >> 2);
+            if (s.valid[node]) ex.atomic_add(&s.nsum[node], (unsigned)s.satd[s.alias[level][t]][0][t]);
+        }
+        if (tid >= 64 && tid < 64 + 8 * 21) s.fsum[(tid - 64) / 21][(tid - 64) % 21] = 0;
     });
-    // quadtree decision
-    ex.phase([&](int tid) {
+    // quadtree decision, bottom up inside wave 0 (wave-local steps: 21 lanes cost the nodes, 4 lanes settle the 16x16 level, one lane
+    // the 32x32 level, 16 lanes label their tiles); one thread walking the whole tree was 9k cycles of every CTU program
+    ex.wave_step([&](int tid) {
+        if (tid >= 21) return;
+        s.chosen[tid] = 0;
+        s.cost[tid] = s.valid[tid] ? (s.nsum[tid] << 4) + (unsigned)(lam * (mvd_bits(s.mvx[tid] - 4 * sx) + mvd_bits(s.mvy[tid] - 4 * sy))) : 0;
+        if (tid == 0) { s.est = 0; s.ip_cost = 0; s.ip_act = 0; s.ip_tiles = 0; s.ip_sse = 0; }
+    });
+    ex.wave_step([&](int tid) {
+        if (tid >= 4) return;
+        const int q = tid;
+        unsigned js = (unsigned)(lam * 2);
+        for (int t = 0; t < 4; t++) if (s.valid[5 + 4 * q + t]) js += s.cost[5 + 4 * q + t] + (unsigned)(lam * 4);
+        const unsigned jw = s.cost[1 + q] + (unsigned)(lam * 4);
+        s.use16[q] = s.valid[1 + q] && jw <= js;
+        s.j16[q] = s.use16[q] ? jw : js;
+    });
+    ex.wave_step([&](int tid) {
         if (tid != 0) return;
-        s.est = 0; s.ip_cost = 0; s.ip_act = 0; s.ip_tiles = 0; s.ip_sse = 0;
-        unsigned J[21];
-        for (int n = 0; n < 21; n++) J[n] = s.valid[n] ? s.cost[n] + (unsigned)(lam * 4) : 0;
-        int use16[4], use32;
-        unsigned J16[4], js32 = (unsigned)(lam * 2);
-        for (int q = 0; q < 4; q++) {
-            unsigned js = (unsigned)(lam * 2);
-            for (int t = 0; t < 4; t++) if (s.valid[5 + 4 * q + t]) js += J[5 + 4 * q + t];
-            use16[q] = s.valid[1 + q] && J[1 + q] <= js;
-            J16[q] = use16[q] ? J[1 + q] : js;
-            js32 += J16[q];
-        }
-        use32 = s.valid[0] && J[0] <= js32;
-        for (int n = 0; n < 21; n++) s.chosen[n] = 0;
-        for (int t = 0; t < 16; t++) {
-            int txp = t & 3, typ = t >> 2, q = (typ >> 1) * 2 + (txp >> 1);
-            int n8 = node_of_tile(2, txp, typ);
-            int node = use32 ? 0 : use16[q] ? 1 + q : n8;
-            int inside = s.valid[n8];                 // the 8x8 tile itself lies inside the picture
-            s.tile_node[t] = (uint8_t)node;
-            if (inside) s.chosen[node] = 1;
-            s.rs.tu_log2[t] = inside ? (uint8_t)(node == 0 ? 5 : node < 5 ? 4 : 3) : 0;
-            s.rs.tu_intra[t] = 0;
-        }
+        const unsigned js32 = (unsigned)(lam * 2) + s.j16[0] + s.j16[1] + s.j16[2] + s.j16[3];
+        s.use32 = s.valid[0] && s.cost[0] + (unsigned)(lam * 4) <= js32;
+    });
+    ex.phase([&](int tid) {
+        if (tid >= 16) return;
+        const int t = tid, txp = t & 3, typ = t >> 2, q = (typ >> 1) * 2 + (txp >> 1), n8 = node_of_tile(2, txp, typ);
+        const int node = s.use32 ? 0 : s.use16[q] ? 1 + q : n8, inside = s.valid[n8];      // inside: the 8x8 tile itself lies inside the picture
+        s.tile_node[t] = (uint8_t)node;
+        if (inside) s.chosen[node] = 1;                   // several tiles may store the same 1
+        s.rs.tu_log2[t] = inside ? (uint8_t)(node == 0 ? 5 : node < 5 ? 4 : 3) : 0;
+        s.rs.tu_intra[t] = 0;
     });
     // fractional refinement of the chosen CUs: half-pel ring, then quarter-pel ring (the centre's cost is known)
     for (int round = 0; round < 2; round++) {
@@ -634,19 +638,17 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                 int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
                 int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
                 int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                s.satd[0][k][t] = luma_tile((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8), 32, (T *)nullptr, 0);
+                const int satd = luma_tile((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8), 32, (T *)nullptr, 0);
+                ex.atomic_add(&s.fsum[k - 1][node], (unsigned)satd);      // the CU's candidate sum, one LDS atomic per tile
             }
         });
         ex.phase([&](int tid) {
             if (tid >= 21 || !s.valid[tid] || !s.chosen[tid]) return;
-            int nx, ny, nl;
-            node_geom(tid, nx, ny, nl);
-            int tiles = 1 << (nl - 3);
             unsigned long long best = (unsigned long long)s.cost[tid] << 4;
+#pragma unroll
             for (int k = 1; k < 9; k++) {
-                unsigned satd = 0;
-                for (int j = 0; j < tiles; j++)
-                    for (int i = 0; i < tiles; i++) { int t = ((ny >> 3) + j) * 4 + (nx >> 3) + i; satd += (unsigned)s.satd[0][k][t]; }
+                const unsigned satd = s.fsum[k - 1][tid];
+                s.fsum[k - 1][tid] = 0;                                   // ready for the next round
                 int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
                 unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
                 unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;

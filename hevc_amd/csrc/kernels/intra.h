@@ -1,19 +1,27 @@
 // hevc_amd/csrc/kernels/intra.h — K2: intra prediction + mode decision (35 modes, SATD) + K3 residual for the CTUs
-// of an I picture.  One 256-thread workgroup per 32x32 CTU; CTUs are launched one anti-diagonal (x + 2y = d) at a
-// time because a CTU predicts from its left, top-left, top and top-right neighbours' reconstructions.  With a tile
-// grid (prm.tile_cols x tile_rows, PPS 1) prediction stops at tile boundaries, so every tile runs its own wavefront and
-// the launch count drops from W + 2(H-1) to w + 2(h-1) CTUs of one tile.
+// of an I picture (and of the P pictures' intra second pass), in two stages (oracle/hevc_oracle.c intra_plan_ctu / intra_code_ctu):
 //
-// Inside the CTU the quadtree is walked depth first exactly like oracle/hevc_oracle.c intra_tree: the four 8x8
-// children of a 16x16 block first, then the 16x16 block itself, keep the cheaper (whole wins ties); then the same
-// for 32x32.  The CTU's reconstruction, levels and CU records live in LDS until the CTU is final.
-// Prediction is H.265 8.4.4.2 (reference availability by z-scan order, substitution, [1 2 1] / strong smoothing,
+//   A. PLAN (intra_plan_program, k_intra_plan): luma / chroma modes of all 21 quadtree nodes and the quadtree itself, decided on the
+//      SOURCE picture — the source neighbours stand in for the reconstruction under the real availability rules (picture, tile,
+//      z-order), node costs are real RD costs (K3 residual coding, SSE + lambda x estimated bits).  Nothing depends on another CTU, so
+//      one launch plans every CTU of every picture in flight.
+//   B. CODE (intra_code_program, k_intra_diag): the planned CUs only, in decoding order, predicted from the real reconstruction of
+//      their left / top-left / top / top-right neighbours: CTUs are launched one anti-diagonal (x + 2y = d) at a time; with a tile grid
+//      (prm.tile_cols x tile_rows, PPS 1) prediction stops at tile boundaries, so every tile runs its own wavefront and the launch
+//      count drops from W + 2(H-1) to w + 2(h-1) CTUs of one tile.
+//
+// Round 1 searched modes and tree depth first on the reconstruction inside the wavefront (21 CUs x ~16 barrier phases per CTU program,
+// 0.6 ms of latency per anti-diagonal launch: 23 % of the device time for 4 of 300 pictures); the plan costs +0.07 % bits at -0.003 dB on
+// the bench clip's IDR pictures (QP 23) against that search.  The CTU's reconstruction, levels and CU records live in LDS until the CTU
+// is final.  Prediction is H.265 8.4.4.2 (reference availability by z-scan order, substitution, [1 2 1] / strong smoothing,
 // planar, DC, angular with the boundary filters); MPM list per 8.4.2.
 #pragma once
 #include "common.h"
 #include "residual.h"
 
 namespace mihevc {
+
+struct IntraPlan;
 
 template <typename T> struct IntraArgs {
     Plane<const T> src[3];
@@ -26,6 +34,7 @@ template <typename T> struct IntraArgs {
     unsigned long long *est;     // optional: picture-level rate estimate accumulator (1/16 bit)
     int sparse_coef;             // 1: store levels only for TUs with a non-zero level (see InterArgs)
     const IpInfo *ip;            // P pictures' intra second pass: per-CTU hand-over from the inter pass; nullptr in I pictures
+    struct IntraPlan *plan;      // per CTU: k_intra_plan -> k_intra_diag (I pictures); unused when one workgroup runs both stages
 };
 
 // Second pass of a P picture (oracle: intra_in_p_pass).  Candidates may only run together when the CTUs they predict from are
@@ -57,28 +66,36 @@ template <typename T> struct Nx4 {       // per block group g: 0 = luma PU or Cb
     int tmp[2][16];
 };
 
+// what the plan stage hands to the code stage for one CTU: the quadtree's leaves and their modes (k_intra_plan -> k_intra_diag through
+// global memory in I pictures; inside one workgroup in the P pictures' second pass)
+struct IntraPlan {
+    uint8_t chosen[21], mode[21], cmode[21], pad;
+};
+
 template <typename T> struct IntraShared {
     ResidualShared rs;
     T src[1536];
     T pred[1536];
-    T rec_y[33 * RY_STRIDE];
+    T rec_y[33 * RY_STRIDE];     // neighbourhood image: the SOURCE during the plan stage, the reconstruction during the code stage
     T rec_c[2][17 * RC_STRIDE];
-    T save_y[32 * 32];
-    T save_c[2][16 * 16];
-    int16_t coef_acc[1536], coef_save[1536];
-    mihevc_cu_rec cu_acc[16], cu_save[16];
+    mihevc_cu_rec cu_acc[16];
     mihevc_cu_rec left_cu[4];    // CU records of the left CTU's right column (MPM derivation), fetched once per CTU
+    IntraPlan plan;
+    int16_t tab_angle[35], tab_inv[35];   // Tables 8-4 / 8-5 by mode, LDS copies: a global read per use sat on the serial chain
+    int16_t tab_qs[6], tab_ls[6];
+    int16_t nx_mat[2][16];       // 4x4 DST-VII and DCT matrices [k * 4 + n]
+    unsigned est;
+    union {      // the two stages never need each other's working state: one workgroup runs them one after the other at most
+    struct {
+    // ---- code stage: one CU at a time
+    int16_t coef_acc[1536];
     T ref_raw[3][132], ref[3][132], filt[132];   // [plane]: 4N+1 reference samples (raw, substituted); filtered luma
-    uint8_t avail[3][132];
-    int satd[35][16];
-    int16_t hrow[35][64];        // 8x8 CUs: horizontally transformed difference rows of every mode (row-split SATD)
-    int satd8[35];               // 8x8 CUs: sum |H d H| per mode (before the (s+2)>>2 normalisation)
-    unsigned long long mode_key;  // min over modes of (cost << 6 | mode)
+    unsigned avmask[3][5];       // [plane]: bit i = reference sample i is available (zeroed by the previous CU's last phase / the CTU's first)
+    unsigned long long mode_key; // NxN trial: min over modes of (cost << 6 | mode)
     int cand[3], dc_val[3];
     unsigned sse;
     int bits[3];
-    unsigned long long j_cu;
-    unsigned est;
+    unsigned long long j_cu, j_ctu;
     // NxN trial of an 8x8 CU: the 2Nx2N result parked here while four 4x4 PUs are coded in place
     T nx_rec[96];                // Y 8x8, Cb 4x4, Cr 4x4
     int16_t nx_coef[96];
@@ -86,14 +103,27 @@ template <typename T> struct IntraShared {
     unsigned long long nx_j2n;
     unsigned nx_sse;
     int nx_bits, nx_keep;
-    int nx_try;                  // set by intra_cu: the 2Nx2N CU left a luma residual (the NxN trial's condition)
+    int nx_try;                  // set by intra_code_cu: the 2Nx2N CU left a luma residual (the NxN trial's condition)
     unsigned nx_cbf_c;           // CU_CBF_CB / CU_CBF_CR of the NxN trial
-    unsigned csatd[5];           // chroma mode candidates (0 = DM, 1..4 = planar / 26 / 10 / DC): SATD over Cb + Cr
-    int cmode, cmode_k;          // chosen chroma prediction mode and its candidate index
-    int16_t nx_mat[2][16];       // 4x4 DST-VII and DCT matrices [k * 4 + n]
-    int16_t tab_angle[35], tab_inv[35];   // Tables 8-4 / 8-5 by mode, LDS copies: a global read per use sat on the serial chain
-    int16_t tab_qs[6], tab_ls[6];
     Nx4<T> nx;
+    };
+    struct {
+    // ---- plan stage: all 21 quadtree nodes at once
+    T p_ref[21][132], p_filt[21][132];           // luma reference samples of every node (substituted; filtered)
+    T p_refc[21][2][68];                         // chroma reference samples
+    unsigned p_av[21][3][5];
+    int p_dc[21][3];
+    unsigned p_msum[21][35];                     // luma SATD of every (node, mode), summed over the node's 8x8 tiles
+    unsigned long long p_key[21];                // min over modes of (cost << 6 | mode)
+    unsigned p_craw[160];                        // chroma candidates of one level: [node][k][plane][tile] sum |H d H|
+    int16_t p_crow[2560];                        // the same: row-transformed difference lines
+    uint8_t p_valid[21], p_mode[21], p_cmode[21];
+    unsigned p_sse[21];
+    unsigned p_bits[21][3];
+    unsigned long long p_j[21], p_j16[4];
+    int p_use16[4], p_use32;
+    };
+    };
 };
 
 // p[x][y] accessors on the linear 4N+1 layout: L[0] = p[-1][2N-1] ... L[2N] = p[-1][-1] ... L[4N] = p[2N-1][-1]
@@ -235,54 +265,406 @@ DEV bool intra_filter_on(int log2n, int mode)
     return d > (log2n == 3 ? 7 : log2n == 4 ? 1 : 0);
 }
 
-template <typename T, class Ex>
-DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int y0, int cx, int cy, int log2n)
+// tile of a CTU as luma sample bounds: neighbours outside it are unavailable (6.4.1); one tile = the whole picture
+struct TileBox { int x_lo, x_hi, y_lo; };
+template <typename T> DEV TileBox tile_box(const IntraArgs<T> &a, int ctu_x, int ctu_y)
 {
-    const int n = 1 << log2n, bd = a.prm.bit_depth, tiles = n >> 3, ntile = tiles * tiles;
+    const int tcn = a.prm.tile_cols > 1 ? a.prm.tile_cols : 1, trn = a.prm.tile_rows > 1 ? a.prm.tile_rows : 1;
+    const int tci = tile_of(ctu_x, tcn, a.ctus_w), tri = tile_of(ctu_y, trn, a.ctus_h);
+    return TileBox{tile_bd(tci, tcn, a.ctus_w) << CTU_LOG2, tile_bd(tci + 1, tcn, a.ctus_w) << CTU_LOG2, tile_bd(tri, trn, a.ctus_h) << CTU_LOG2};
+}
+// position, in its plane, of reference sample i of a block at (px, py) with np samples per side
+DEV void ref_pos(int px, int py, int np, int i, int &xn, int &yn)
+{
+    if (i < 2 * np) { xn = px - 1; yn = py + 2 * np - 1 - i; }
+    else if (i == 2 * np) { xn = px - 1; yn = py - 1; }
+    else { xn = px + (i - 2 * np - 1); yn = py - 1; }
+}
+// 8.4.4.2.2 substitution source of sample i: the nearest available sample at a lower index, else the first available above, else
+// `total` (nothing available).  Bit scans over the availability words instead of a sample-by-sample walk: a bottom-left run of 2N
+// unavailable samples made this a chain of up to 64 dependent LDS reads.
+DEV int ref_source(const unsigned *m, int i, int total)
+{
+    const unsigned upto = (2u << (i & 31)) - 1u;           // bits 0..(i & 31); all ones when (i & 31) == 31
+    int w = i >> 5;
+    unsigned bits = m[w] & upto;
+    for (;;) {
+        if (bits) return 32 * w + 31 - __builtin_clz(bits);
+        if (--w < 0) break;
+        bits = m[w];
+    }
+    w = i >> 5;
+    bits = m[w] & ~upto;
+    for (;;) {
+        if (bits) return 32 * w + __builtin_ctz(bits);
+        if (++w > 4) break;
+        bits = m[w];
+    }
+    return total;
+}
+DEV int level_first(int level) { return level == 0 ? 0 : level == 1 ? 1 : 5; }      // level 0 / 1 / 2 = the 32x32 / 16x16 / 8x8 nodes
+DEV int mode_bits_for(const int (&cand)[3], int mode) { return mode == cand[0] ? 2 : (mode == cand[1] || mode == cand[2]) ? 3 : 6; }
+DEV void cand_from(int ma, int mb, int (&cand)[3])       // 8.4.2 candModeList from the left (ma) and above (mb) modes
+{
+    if (ma == mb) {
+        if (ma < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+        else { cand[0] = ma; cand[1] = 2 + ((ma + 29) & 31); cand[2] = 2 + ((ma - 2 + 1) & 31); }
+    } else {
+        cand[0] = ma; cand[1] = mb;
+        cand[2] = (ma != 0 && mb != 0) ? 0 : (ma != 1 && mb != 1) ? 1 : 26;
+    }
+}
+// the plan's candidate list of a node: planned modes of the same-level nodes left of and above it inside the CTU, DC outside
+template <typename T> DEV void plan_cand(const IntraShared<T> &s, int node, int level, int (&cand)[3])
+{
+    int cx, cy, l2;
+    node_geom(node, cx, cy, l2);
+    const int n = 1 << l2;
+    const int ma = cx > 0 ? (int)(s.p_key[node_of_tile(level, (cx - n) >> 3, cy >> 3)] & 63) : 1;
+    const int mb = cy > 0 ? (int)(s.p_key[node_of_tile(level, cx >> 3, (cy - n) >> 3)] & 63) : 1;
+    cand_from(ma, mb, cand);
+}
+
+// ------------------------------------------------------------------------------------------ stage A: the plan
+// oracle/hevc_oracle.c intra_plan_ctu: every quadtree node of the CTU is costed on the SOURCE picture (its neighbours stand in for the
+// reconstruction, under the real availability rules), so the CTUs of a picture are independent: one launch plans them all, and the
+// 21 nodes of a CTU are worked on side by side — reference samples of all nodes, then 1680 (node, mode, tile) SATD units over the 256
+// lanes, the MPM-aware mode pick (a z-order chain per level, run by one wave per level), and per level one pass of prediction, K3
+// residual coding of the WHOLE CTU and distortion + rate per node; the tree is then decided bottom-up on those RD costs.
+template <typename T, class Ex>
+DEV void intra_plan_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int ctu_x, int ctu_y)
+{
+    const int x0 = ctu_x * CTU, y0 = ctu_y * CTU, bd = a.prm.bit_depth;
+    const TileBox tb = tile_box(a, ctu_x, ctu_y);
+    residual_init(ex, s.rs);
+    ex.phase([&](int tid) {
+        load_ctu_source<T>(s.src, a.src, x0, y0, a.w, a.h, tid);
+        if (tid >= 64 && tid < 99) { s.tab_angle[tid - 64] = (int16_t)mode_angle(tid - 64); s.tab_inv[tid - 64] = (int16_t)mode_inv_angle(tid - 64); }
+        if (tid >= 128 && tid < 134) { s.tab_qs[tid - 128] = g_tab.quant_scale[tid - 128]; s.tab_ls[tid - 128] = g_tab.level_scale[tid - 128]; }
+        if (tid < 32) s.nx_mat[tid >> 4][tid & 15] = tid < 16 ? g_tab.dst4[(tid >> 2) & 3][tid & 3] : g_tab.mat[((tid >> 2) & 3) * 8][tid & 3];
+        if (tid >= 160 && tid < 181) {
+            int nx, ny, nl;
+            node_geom(tid - 160, nx, ny, nl);
+            s.p_valid[tid - 160] = x0 + nx + (1 << nl) <= a.w && y0 + ny + (1 << nl) <= a.h;
+            s.p_key[tid - 160] = ~0ull;
+        }
+        for (int i = tid; i < 21 * 35; i += NT) s.p_msum[i / 35][i % 35] = 0;
+        for (int i = tid; i < 21 * 15; i += NT) s.p_av[i / 15][(i % 15) / 5][i % 5] = 0;
+        // source neighbourhood ring: row -1 (cols -1..63 luma / -1..31 chroma) and column -1 (rows 0..31 / 0..15)
+        for (int u = tid; u < 65 + 32 + 2 * (33 + 16); u += NT) {
+            int pl, k, row_len;
+            if (u < 97) { pl = 0; k = u; row_len = 65; } else { pl = 1 + (u - 97) / 49; k = (u - 97) % 49; row_len = 33; }
+            int xn, yn;
+            if (k < row_len) { xn = k - 1; yn = -1; } else { xn = -1; yn = k - row_len; }
+            const int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h, gx = (pl ? x0 >> 1 : x0) + xn, gy = (pl ? y0 >> 1 : y0) + yn;
+            T v = 0;
+            if (gx >= 0 && gy >= 0 && gx < pw && gy < ph) v = a.src[pl].p[(ptrdiff_t)gy * a.src[pl].stride + gx];
+            if (pl == 0) s.rec_y[(yn + 1) * RY_STRIDE + xn + 1] = v; else s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] = v;
+        }
+    });
+    ex.phase([&](int tid) {      // the CTU's own source samples complete the neighbourhood image
+        for (int i = tid; i < 1536; i += NT) {
+            if (i < 1024) s.rec_y[((i >> 5) + 1) * RY_STRIDE + (i & 31) + 1] = s.src[i];
+            else { const int k = (i - 1024) & 255; s.rec_c[(i - 1024) >> 8][((k >> 4) + 1) * RC_STRIDE + (k & 15) + 1] = s.src[i]; }
+        }
+    });
+    // reference samples of every node and plane: availability + raw values, substitution (in place: an available sample keeps its value
+    // and only those are read), smoothing + DC
+    auto for_refs = [&](int tid, auto &&f) {
+        for (int level = 0; level < 3; level++) {
+            const int n = 32 >> level, ty = 4 * n + 1, tc = 2 * n + 1, per = ty + 2 * tc, cnt = 1 << (2 * level);
+            for (int u = tid; u < cnt * per; u += NT) {
+                const int r = u % per, nd = level_first(level) + u / per;
+                if (!s.p_valid[nd]) continue;
+                const int pl = r < ty ? 0 : r < ty + tc ? 1 : 2, i = pl == 0 ? r : pl == 1 ? r - ty : r - ty - tc;
+                f(nd, n, pl, i);
+            }
+        }
+    };
+    ex.phase([&](int tid) {
+        for_refs(tid, [&](int nd, int n, int pl, int i) {
+            int cx, cy, l2, xn, yn;
+            node_geom(nd, cx, cy, l2);
+            ref_pos(pl ? cx >> 1 : cx, pl ? cy >> 1 : cy, pl ? n >> 1 : n, i, xn, yn);
+            const int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;
+            const bool ok = lx >= tb.x_lo && ly >= tb.y_lo && lx < a.w && lx < tb.x_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(x0 + cx, y0 + cy, a.ctus_w);
+            const T v = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
+            if (pl) s.p_refc[nd][pl - 1][i] = v; else s.p_ref[nd][i] = v;
+            if (ok) ex.atomic_or(&s.p_av[nd][pl][i >> 5], 1u << (i & 31));
+        });
+    });
+    ex.phase([&](int tid) {
+        for_refs(tid, [&](int nd, int n, int pl, int i) {
+            const int total = (pl ? 2 * n : 4 * n) + 1, j = ref_source(s.p_av[nd][pl], i, total);
+            if (j == i) return;
+            T *R = pl ? s.p_refc[nd][pl - 1] : s.p_ref[nd];
+            R[i] = j < total ? R[j] : (T)(1 << (bd - 1));
+        });
+    });
+    ex.phase([&](int tid) {
+        for (int level = 0; level < 3; level++) {
+            const int n = 32 >> level, total = 4 * n + 1, cnt = 1 << (2 * level);
+            for (int u = tid; u < cnt * total; u += NT) {
+                const int i = u % total, nd = level_first(level) + u / total;
+                if (!s.p_valid[nd]) continue;
+                const T *L = s.p_ref[nd];
+                int v;
+                if (i == 0 || i == total - 1) v = L[i];
+                else if (n == 32 && iabs(L[64] + L[128] - 2 * L[96]) < (1 << (bd - 5)) && iabs(L[64] + L[0] - 2 * L[32]) < (1 << (bd - 5)))
+                    v = i == 64 ? L[64] : i < 64 ? (i * L[64] + (64 - i) * L[0] + 32) >> 6 : ((128 - i) * L[64] + (i - 64) * L[128] + 32) >> 6;
+                else v = (L[i - 1] + 2 * L[i] + L[i + 1] + 2) >> 2;
+                s.p_filt[nd][i] = (T)v;
+            }
+        }
+        for (int u = tid; u < 63; u += NT) {
+            const int nd = u / 3, pl = u % 3;
+            if (!s.p_valid[nd]) continue;
+            int cx, cy, l2;
+            node_geom(nd, cx, cy, l2);
+            const int np = pl ? 1 << (l2 - 1) : 1 << l2, lg = pl ? l2 - 1 : l2;
+            const T *L = pl ? s.p_refc[nd][pl - 1] : s.p_ref[nd];
+            int sum = np;
+            for (int i = 0; i < np; i++) sum += ref_top(L, np, i) + ref_left(L, np, i);
+            s.p_dc[nd][pl] = sum >> (lg + 1);
+        }
+    });
+    // 35 modes x every 8x8 tile of every node: 3 x 560 SATD units
+    ex.phase([&](int tid) {
+        for (int u = tid; u < 3 * 560; u += NT) {
+            const int level = 2 - u / 560, v = u % 560;        // the 8x8 level first: its lanes diverge least
+            const int k = level == 2 ? v / 35 : level == 1 ? v / 140 : 0, mode = level == 2 ? v % 35 : level == 1 ? (v % 140) >> 2 : v >> 4;
+            const int t = level == 2 ? 0 : level == 1 ? v & 3 : v & 15, nd = level_first(level) + k;
+            if (!s.p_valid[nd]) continue;
+            int cx, cy, l2;
+            node_geom(nd, cx, cy, l2);
+            const int tiles = 1 << (l2 - 3), tx = (t % tiles) * 8, ty = (t / tiles) * 8;
+            const T *L = intra_filter_on(l2, mode) ? s.p_filt[nd] : s.p_ref[nd];
+            int m[8][8];
+            intra_tile_diff<T>(L, l2, mode, s.tab_angle[mode], s.tab_inv[mode], tx, ty, bd, s.p_dc[nd][0], s.src + (cy + ty) * 32 + cx + tx, 32, m);
+            ex.atomic_add(&s.p_msum[nd][mode], (unsigned)hadamard8_satd(m));
+        }
+    });
+    // mode pick: inside a level a node's candidate list needs its left / top neighbours' picks, so each level is a z-order chain; wave w
+    // runs level 2 - w with wave-local steps (35 lanes = the modes), all three chains side by side
+    for (int i = 0; i < 16; i++)
+        ex.wave_step([&](int tid) {
+            const int level = 2 - (tid >> 6), mode = tid & 63;
+            if (level < 0 || mode >= 35 || i >= (1 << (2 * level))) return;
+            const int nd = level_first(level) + i;
+            if (!s.p_valid[nd]) return;
+            int cand[3];
+            plan_cand(s, nd, level, cand);
+            const unsigned cost = (s.p_msum[nd][mode] << 4) + (unsigned)(a.prm.lambda_sad_q4 * mode_bits_for(cand, mode));
+            ex.atomic_min(&s.p_key[nd], ((unsigned long long)cost << 6) | (unsigned)mode);      // ties -> lowest mode
+        });
+    ex.phase([&](int) {});       // the wave steps carry no barrier: everybody waits here for the three chains
+    for (int level = 0; level < 3; level++) {
+        const int log2n = 5 - level, n = 1 << log2n, nc = n >> 1, l2c = log2n - 1, tw = nc >= 8 ? 8 : 4, ct = nc / tw, ntc = ct * ct;
+        const int cnt = 1 << (2 * level), first = level_first(level);
+        // intra_chroma_pred_mode: DM or planar / 26 / 10 / DC (a candidate equal to the luma mode stands for 34) by SATD over Cb + Cr +
+        // lambda * (1 bit DM, 3 bits otherwise), DM wins ties; every tile split into lines: one lane predicts a row and transforms it,
+        // a second phase finishes one column each
+        if (a.prm.chroma_modes) {
+            const int nline = cnt * 5 * 2 * ntc * tw;
+            ex.phase([&](int tid) {
+                for (int u = tid; u < nline; u += NT) {
+                    const int y = u % tw, t = (u / tw) % ntc, pl = 1 + (u / (tw * ntc)) % 2, k = (u / (tw * ntc * 2)) % 5, nk = u / (tw * ntc * 10), nd = first + nk;
+                    if (!s.p_valid[nd]) continue;
+                    const int mode = (int)(s.p_key[nd] & 63), base = k == 1 ? 0 : k == 2 ? 26 : k == 3 ? 10 : 1, m = k == 0 ? mode : (base == mode ? 34 : base);
+                    int cx, cy, l2;
+                    node_geom(nd, cx, cy, l2);
+                    const T *L = s.p_refc[nd][pl - 1];
+                    const int tx = (t % ct) * tw, ty = (t / ct) * tw, ang = s.tab_angle[m], inv = s.tab_inv[m];
+                    const int sbase = 1024 + (pl - 1) * 256 + ((cy >> 1) + ty + y) * 16 + (cx >> 1) + tx;
+                    int d[8];
+#pragma unroll
+                    for (int x = 0; x < 8; x++) d[x] = x < tw ? (int)s.src[sbase + x] - intra_sample<T>(L, l2c, m, ang, inv, tx + x, ty + y, pl, bd, s.p_dc[nd][pl]) : 0;
+                    if (tw == 8) {
+#pragma unroll
+                        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                if (!(i & st)) { int p = d[i], q = d[i + st]; d[i] = p + q; d[i + st] = p - q; }
+                    } else {
+                        const int p0 = d[0] + d[1], p1 = d[0] - d[1], p2 = d[2] + d[3], p3 = d[2] - d[3];
+                        d[0] = p0 + p2; d[1] = p1 + p3; d[2] = p0 - p2; d[3] = p1 - p3;
+                    }
+                    int16_t *o = s.p_crow + ((((nk * 5 + k) * 2 + (pl - 1)) * ntc + t) * tw + y) * tw;
+#pragma unroll
+                    for (int x = 0; x < 8; x++) if (x < tw) o[x] = (int16_t)d[x];
+                }
+                for (int i = tid; i < 160; i += NT) s.p_craw[i] = 0;
+            });
+            ex.phase([&](int tid) {
+                for (int u = tid; u < nline; u += NT) {
+                    const int x = u % tw, t = (u / tw) % ntc, pl = (u / (tw * ntc)) % 2, k = (u / (tw * ntc * 2)) % 5, nk = u / (tw * ntc * 10);
+                    if (!s.p_valid[first + nk]) continue;
+                    const int16_t *c = s.p_crow + (((nk * 5 + k) * 2 + pl) * ntc + t) * tw * tw + x;
+                    int sum;
+                    if (tw == 8) {
+                        int d[8];
+#pragma unroll
+                        for (int y = 0; y < 8; y++) d[y] = c[y * 8];
+#pragma unroll
+                        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+                            for (int i = 0; i < 8; i++)
+                                if (!(i & st)) { int p = d[i], q = d[i + st]; d[i] = p + q; d[i + st] = p - q; }
+                        sum = 0;
+#pragma unroll
+                        for (int y = 0; y < 8; y++) sum += iabs(d[y]);
+                    } else {
+                        const int p0 = c[0] + c[4], p1 = c[0] - c[4], p2 = c[8] + c[12], p3 = c[8] - c[12];
+                        sum = iabs(p0 + p2) + iabs(p1 + p3) + iabs(p0 - p2) + iabs(p1 - p3);
+                    }
+                    ex.atomic_add(&s.p_craw[((nk * 5 + k) * 2 + pl) * ntc + t], (unsigned)sum);
+                }
+            });
+        }
+        ex.phase([&](int tid) {
+            if (tid < cnt && s.p_valid[first + tid]) {
+                const int nd = first + tid, mode = (int)(s.p_key[nd] & 63);
+                int cmode = mode;
+                if (a.prm.chroma_modes) {
+                    unsigned long long best = ~0ull;
+                    for (int k = 0; k < 5; k++) {
+                        unsigned satd = 0;          // per tile (sum |H d H| + 2) >> 2 for 8x8 tiles, (sum + 1) >> 1 for the 4x4 blocks
+                        for (int p = 0; p < 2 * ntc; p++) { const unsigned r = s.p_craw[(tid * 5 + k) * 2 * ntc + p]; satd += tw == 8 ? (r + 2) >> 2 : (r + 1) >> 1; }
+                        const unsigned long long key = ((unsigned long long)((satd << 4) + (unsigned)(a.prm.lambda_sad_q4 * (k == 0 ? 1 : 3))) << 3) | (unsigned)k;
+                        best = key < best ? key : best;
+                    }
+                    const int k = (int)(best & 7), base = k == 1 ? 0 : k == 2 ? 26 : k == 3 ? 10 : 1;
+                    if (k) cmode = base == mode ? 34 : base;
+                }
+                s.p_mode[nd] = (uint8_t)mode; s.p_cmode[nd] = (uint8_t)cmode;
+                s.p_sse[nd] = 0; s.p_bits[nd][0] = s.p_bits[nd][1] = s.p_bits[nd][2] = 0;
+            }
+            if (tid >= 64 && tid < 80) {
+                const int t = tid - 64;
+                s.rs.tu_log2[t] = s.p_valid[node_of_tile(level, t & 3, t >> 2)] ? (uint8_t)log2n : 0;
+                s.rs.tu_intra[t] = 1;
+            }
+            if (tid >= 96 && tid < 99) s.rs.cbf[tid - 96] = 0;
+        });
+        // RD cost of every node of the level with its modes: prediction (still from the source neighbourhood), K3 over the whole CTU,
+        // distortion and rate per node
+        ex.phase([&](int tid) {
+            for (int i = tid; i < 1536; i += NT) {
+                SampleLoc l = locate(s.rs, i);
+                s.rs.desc[i] = pack_loc(l);
+                if (!l.log2n) continue;
+                const int sh = l.plane ? 2 : 3, nd = node_of_tile(level, l.x >> sh, l.y >> sh);
+                int cx, cy, l2, v;
+                node_geom(nd, cx, cy, l2);
+                if (l.plane == 0) {
+                    const int mode = s.p_mode[nd];
+                    const T *L = intra_filter_on(log2n, mode) ? s.p_filt[nd] : s.p_ref[nd];
+                    v = intra_sample<T>(L, log2n, mode, s.tab_angle[mode], s.tab_inv[mode], l.x - cx, l.y - cy, 0, bd, s.p_dc[nd][0]);
+                } else {
+                    const int cm = s.p_cmode[nd];
+                    v = intra_sample<T>(s.p_refc[nd][l.plane - 1], l2c, cm, s.tab_angle[cm], s.tab_inv[cm], l.x - (cx >> 1), l.y - (cy >> 1), l.plane, bd, s.p_dc[nd][l.plane]);
+                }
+                s.pred[i] = (T)v;
+                s.rs.res[i] = (int16_t)((int)s.src[i] - v);
+            }
+        });
+        residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, whole_ctu());
+        ex.phase([&](int tid) {
+            const int maxv = (1 << bd) - 1;
+            for (int i = 4 * tid; i < 1536; i += 4 * NT) {
+                SampleLoc l = locate(s.rs, i);
+                if (!l.log2n) continue;
+                const int sh = l.plane ? 2 : 3;
+                unsigned sse = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int d = (int)s.src[i + j] - clip3(0, maxv, (int)s.pred[i + j] + s.rs.res[i + j]); sse += (unsigned)(d * d); }
+                if (sse) ex.atomic_add(&s.p_sse[node_of_tile(level, l.x >> sh, l.y >> sh)], sse);
+            }
+            for (int sb = tid; sb < 96; sb += NT) {       // 64 luma + 16 + 16 chroma 4x4 sub-blocks
+                const int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
+                const int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0, sh = pl ? 2 : 3;
+                const int tile = (by >> sh) * 4 + (bx >> sh);
+                if (!s.rs.tu_log2[tile]) continue;
+                const int b = subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
+                if (b) ex.atomic_add(&s.p_bits[node_of_tile(level, tile & 3, tile >> 2)][pl], (unsigned)b);
+            }
+        });
+        ex.phase([&](int tid) {
+            if (tid >= cnt) return;
+            const int nd = first + tid;
+            if (!s.p_valid[nd]) { s.p_j[nd] = 0; return; }
+            int cand[3];
+            plan_cand(s, nd, level, cand);
+            unsigned bits = 16u * (unsigned)mode_bits_for(cand, s.p_mode[nd]) + 16 + 24 + (s.p_cmode[nd] != s.p_mode[nd] ? 32 : 0);
+            for (int p = 0; p < 3; p++) bits += s.p_bits[nd][p] ? s.p_bits[nd][p] + R_TU : 0;
+            s.p_j[nd] = ((unsigned long long)s.p_sse[nd] << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)bits) >> 4);
+        });
+    }
+    // the tree, bottom-up (wave 0): split = lambda + children, whole = own + lambda, whole wins ties; a node that does not fit is split
+    const unsigned long long lam_split = (unsigned long long)a.prm.lambda_q4;     // (lambda_q4 * 16) >> 4
+    ex.wave_step([&](int tid) {
+        if (tid >= 4) return;
+        const int q = tid;
+        unsigned long long js = lam_split;
+        int any = 0;
+        for (int k = 0; k < 4; k++) if (s.p_valid[5 + 4 * q + k]) { js += s.p_j[5 + 4 * q + k]; any = 1; }
+        const unsigned long long jw = s.p_j[1 + q] + lam_split;
+        s.p_use16[q] = s.p_valid[1 + q] && jw <= js;
+        s.p_j16[q] = !any ? 0 : s.p_use16[q] ? jw : js;
+    });
+    ex.wave_step([&](int tid) {
+        if (tid != 0) return;
+        s.p_use32 = s.p_valid[0] && s.p_j[0] + lam_split <= lam_split + s.p_j16[0] + s.p_j16[1] + s.p_j16[2] + s.p_j16[3];
+    });
+    ex.phase([&](int tid) {
+        if (tid >= 21) return;
+        const int nd = tid;
+        s.plan.chosen[nd] = (uint8_t)(s.p_valid[nd] && (nd == 0 ? s.p_use32 : nd < 5 ? (!s.p_use32 && s.p_use16[nd - 1]) : (!s.p_use32 && !s.p_use16[(nd - 5) >> 2])));
+        s.plan.mode[nd] = s.p_mode[nd]; s.plan.cmode[nd] = s.p_cmode[nd];
+        if (a.plan) {       // I pictures: k_intra_diag picks it up from memory
+            IntraPlan &o = a.plan[ctu_y * a.ctus_w + ctu_x];
+            o.chosen[nd] = s.plan.chosen[nd]; o.mode[nd] = s.p_mode[nd]; o.cmode[nd] = s.p_cmode[nd];
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------ stage B: coding the planned CUs
+// one planned 2Nx2N CU (oracle intra_cu): reference samples from the reconstruction, prediction with the planned modes, K3, reconstruction
+// into the LDS neighbourhood, distortion + rate, records
+template <typename T, class Ex>
+DEV void intra_code_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int y0, const TileBox &tb, int cx, int cy, int log2n, int mode, int cmode)
+{
+    const int n = 1 << log2n, bd = a.prm.bit_depth;
     const Region rg{cx, cy, log2n};
     const int rcnt = rg.count();
     const int gx = x0 + cx, gy = y0 + cy;        // picture coordinates of the CU
-    // tile of this CTU as CTB bounds (neighbours outside it are unavailable, 6.4.1); one tile = the whole picture
-    const int ctu_x = x0 >> CTU_LOG2, ctu_y = y0 >> CTU_LOG2;
-    const int tcn = a.prm.tile_cols > 1 ? a.prm.tile_cols : 1, trn = a.prm.tile_rows > 1 ? a.prm.tile_rows : 1;
-    const int tci = tile_of(ctu_x, tcn, a.ctus_w), tri = tile_of(ctu_y, trn, a.ctus_h);
-    const int tx_lo = tile_bd(tci, tcn, a.ctus_w) << CTU_LOG2, tx_hi = tile_bd(tci + 1, tcn, a.ctus_w) << CTU_LOG2;
-    const int ty_lo = tile_bd(tri, trn, a.ctus_h) << CTU_LOG2;
-    // reference samples: availability + raw values for the three planes
-    ex.phase([&](int tid) {
+    ex.phase([&](int tid) {      // reference samples: availability + raw values for the three planes
         for (int u = tid; u < 3 * 129; u += NT) {
-            int pl = u / 129, i = u % 129, np = pl ? n >> 1 : n, total = 4 * np + 1;
-            if (i >= total) continue;
-            int px = pl ? cx >> 1 : cx, py = pl ? cy >> 1 : cy, xn, yn;
-            if (i < 2 * np) { xn = px - 1; yn = py + 2 * np - 1 - i; }
-            else if (i == 2 * np) { xn = px - 1; yn = py - 1; }
-            else { xn = px + (i - 2 * np - 1); yn = py - 1; }
-            int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;      // luma picture position of the neighbour
-            bool ok = lx >= tx_lo && ly >= ty_lo && lx < a.w && lx < tx_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(gx, gy, a.ctus_w);
-            s.avail[pl][i] = ok;
+            const int pl = u / 129, i = u % 129, np = pl ? n >> 1 : n;
+            if (i >= 4 * np + 1) continue;
+            int xn, yn;
+            ref_pos(pl ? cx >> 1 : cx, pl ? cy >> 1 : cy, np, i, xn, yn);
+            const int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;      // luma picture position of the neighbour
+            const bool ok = lx >= tb.x_lo && ly >= tb.y_lo && lx < a.w && lx < tb.x_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(gx, gy, a.ctus_w);
+            if (ok) ex.atomic_or(&s.avmask[pl][i >> 5], 1u << (i & 31));
             s.ref_raw[pl][i] = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
         }
-        if (tid == 0) {   // 8.4.2 candModeList
+        if (tid == 0) {   // 8.4.2 candModeList from the CUs actually coded around this one (rate estimate only)
             int cand[3];
-            mpm_cand(s, cx, cy, x0 > tx_lo, cand);
+            mpm_cand(s, cx, cy, x0 > tb.x_lo, cand);
             s.cand[0] = cand[0]; s.cand[1] = cand[1]; s.cand[2] = cand[2];
             s.sse = 0; s.bits[0] = s.bits[1] = s.bits[2] = 0;
-            s.mode_key = ~0ull;
         }
     });
-    // substitution (8.4.4.2.2): nearest available sample at a lower index, else the first available above
-    ex.phase([&](int tid) {
+    ex.phase([&](int tid) {      // substitution (8.4.4.2.2)
         for (int u = tid; u < 3 * 129; u += NT) {
-            int pl = u / 129, i = u % 129, np = pl ? n >> 1 : n, total = 4 * np + 1;
+            const int pl = u / 129, i = u % 129, np = pl ? n >> 1 : n, total = 4 * np + 1;
             if (i >= total) continue;
-            int j = i;
-            while (j >= 0 && !s.avail[pl][j]) j--;
-            if (j < 0) { j = i + 1; while (j < total && !s.avail[pl][j]) j++; }
+            const int j = ref_source(s.avmask[pl], i, total);
             s.ref[pl][i] = j < total ? s.ref_raw[pl][j] : (T)(1 << (bd - 1));
         }
     });
-    // smoothing filter for luma (8.4.4.2.3) + DC values
-    ex.phase([&](int tid) {
+    ex.phase([&](int tid) {      // smoothing filter for luma (8.4.4.2.3) + DC values + the CU's transform units
         const T *L = s.ref[0];
         const int total = 4 * n + 1;
         bool strong = false;
@@ -297,138 +679,23 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
             else v = (L[i - 1] + 2 * L[i] + L[i + 1] + 2) >> 2;
             s.filt[i] = (T)v;
         }
-        if (tid < 3) {
-            int np = tid ? n >> 1 : n, lg = tid ? log2n - 1 : log2n, sum = np;
-            for (int i = 0; i < np; i++) sum += ref_top(s.ref[tid], np, i) + ref_left(s.ref[tid], np, i);
-            s.dc_val[tid] = sum >> (lg + 1);
+        if (tid >= 192 && tid < 195) {
+            const int pl = tid - 192, np = pl ? n >> 1 : n, lg = pl ? log2n - 1 : log2n;
+            int sum = np;
+            for (int i = 0; i < np; i++) sum += ref_top(s.ref[pl], np, i) + ref_left(s.ref[pl], np, i);
+            s.dc_val[pl] = sum >> (lg + 1);
         }
-    });
-    // 35 modes x 8x8 tiles: prediction and SATD against the source
-    if (log2n == 3) {
-        // an 8x8 CU has one tile per mode: 35 busy lanes would leave the workgroup idle while this CU blocks the rest of
-        // the CTU.  Split every tile by rows: 280 lanes each predict one row and transform it horizontally, then
-        // 280 lanes each finish one column (the 2-D Hadamard is separable, so the sum is unchanged).
-        ex.phase([&](int tid) {
-            for (int u = tid; u < 35 * 8; u += NT) {
-                const int mode = u >> 3, y = u & 7;
-                const T *L = intra_filter_on(3, mode) ? s.filt : s.ref[0];
-                const int ang = s.tab_angle[mode], inv = s.tab_inv[mode];
-                int d[8];
-#pragma unroll
-                for (int x = 0; x < 8; x++) d[x] = (int)s.src[(cy + y) * 32 + cx + x] - intra_sample<T>(L, 3, mode, ang, inv, x, y, 0, bd, s.dc_val[0]);
-#pragma unroll
-                for (int st = 1; st < 8; st <<= 1)
-#pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (!(i & st)) { int p = d[i], q = d[i + st]; d[i] = p + q; d[i + st] = p - q; }
-#pragma unroll
-                for (int x = 0; x < 8; x++) s.hrow[mode][y * 8 + x] = (int16_t)d[x];
-            }
-            if (tid < 35) s.satd8[tid] = 0;
-        });
-        ex.phase([&](int tid) {
-            for (int u = tid; u < 35 * 8; u += NT) {
-                const int mode = u >> 3, x = u & 7;
-                int d[8];
-#pragma unroll
-                for (int y = 0; y < 8; y++) d[y] = s.hrow[mode][y * 8 + x];
-#pragma unroll
-                for (int st = 1; st < 8; st <<= 1)
-#pragma unroll
-                    for (int i = 0; i < 8; i++)
-                        if (!(i & st)) { int p = d[i], q = d[i + st]; d[i] = p + q; d[i + st] = p - q; }
-                int sum = 0;
-#pragma unroll
-                for (int y = 0; y < 8; y++) sum += iabs(d[y]);
-                ex.atomic_add(&s.satd8[mode], sum);
-            }
-        });
-    } else {
-    ex.phase([&](int tid) {
-        for (int u = tid; u < 35 * ntile; u += NT) {
-            int mode = u / ntile, t = u % ntile, tx = (t % tiles) * 8, ty = (t / tiles) * 8;
-            const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
-            int m[8][8];
-            intra_tile_diff<T>(L, log2n, mode, s.tab_angle[mode], s.tab_inv[mode], tx, ty, bd, s.dc_val[0], s.src + (cy + ty) * 32 + cx + tx, 32, m);
-            s.satd[mode][t] = hadamard8_satd(m);
-        }
-    });
-    }
-    ex.phase([&](int tid) {
-        if (tid < 35) {
-            unsigned satd = 0;
-            if (log2n == 3) satd = (unsigned)((s.satd8[tid] + 2) >> 2);
-            else for (int t = 0; t < ntile; t++) satd += (unsigned)s.satd[tid][t];
-            int bits = tid == s.cand[0] ? 2 : (tid == s.cand[1] || tid == s.cand[2]) ? 3 : 6;
-            unsigned cost = (satd << 4) + (unsigned)(a.prm.lambda_sad_q4 * bits);
-            ex.atomic_min(&s.mode_key, ((unsigned long long)cost << 6) | (unsigned)tid);      // ties -> lowest mode
-        }
-        if (tid >= 64 && tid < 80) {
-            int t = tid - 64, tx = t & 3, ty = t >> 2;
+        if (tid >= 208 && tid < 224) {
+            int t = tid - 208, tx = t & 3, ty = t >> 2;
             bool in = tx * 8 >= cx && tx * 8 < cx + n && ty * 8 >= cy && ty * 8 < cy + n;
             s.rs.tu_log2[t] = in ? (uint8_t)log2n : 0;
             s.rs.tu_intra[t] = 1;
         }
-        if (tid >= 80 && tid < 83) s.rs.cbf[tid - 80] = 0;
-        if (tid >= 96 && tid < 101) s.csatd[tid - 96] = 0;
-        if (tid == 101) { s.cmode_k = 0; }
+        if (tid >= 224 && tid < 227) s.rs.cbf[tid - 224] = 0;
     });
-    // intra_chroma_pred_mode (oracle intra_cu): DM or planar / 26 / 10 / DC (a candidate equal to the luma mode stands for 34), by SATD
-    // over Cb + Cr + lambda * (1 bit DM, 3 bits otherwise); DM wins ties
-    if (a.prm.chroma_modes) {
-        ex.phase([&](int tid) {
-            const int mode = (int)(s.mode_key & 63), l2c = log2n - 1, nc = n >> 1, ct = nc >= 8 ? nc >> 3 : 1, ntc = ct * ct;
-            for (int u = tid; u < 5 * 2 * ntc; u += NT) {
-                const int k = u / (2 * ntc), pl = 1 + (u / ntc) % 2, t = u % ntc;
-                const int base = k == 1 ? 0 : k == 2 ? 26 : k == 3 ? 10 : 1, m = k == 0 ? mode : (base == mode ? 34 : base);
-                const T *L = s.ref[pl];
-                const int sbase = 1024 + (pl - 1) * 256 + (cy >> 1) * 16 + (cx >> 1);
-                int satd;
-                if (nc == 4) {
-                    int d[16];
-                    const int ang = s.tab_angle[m], inv = s.tab_inv[m];
-#pragma unroll
-                    for (int i = 0; i < 16; i++) d[i] = (int)s.src[sbase + (i >> 2) * 16 + (i & 3)] - intra_sample<T>(L, 2, m, ang, inv, i & 3, i >> 2, pl, bd, s.dc_val[pl]);
-#pragma unroll
-                    for (int y = 0; y < 4; y++) {
-                        int p0 = d[y * 4] + d[y * 4 + 1], p1 = d[y * 4] - d[y * 4 + 1], p2 = d[y * 4 + 2] + d[y * 4 + 3], p3 = d[y * 4 + 2] - d[y * 4 + 3];
-                        d[y * 4] = p0 + p2; d[y * 4 + 1] = p1 + p3; d[y * 4 + 2] = p0 - p2; d[y * 4 + 3] = p1 - p3;
-                    }
-                    int sum = 0;
-#pragma unroll
-                    for (int x = 0; x < 4; x++) {
-                        int p0 = d[x] + d[4 + x], p1 = d[x] - d[4 + x], p2 = d[8 + x] + d[12 + x], p3 = d[8 + x] - d[12 + x];
-                        sum += iabs(p0 + p2) + iabs(p1 + p3) + iabs(p0 - p2) + iabs(p1 - p3);
-                    }
-                    satd = (sum + 1) >> 1;
-                } else {
-                    int mm[8][8];
-                    const int tx = (t % ct) * 8, ty = (t / ct) * 8;
-                    intra_tile_diff<T>(L, l2c, m, s.tab_angle[m], s.tab_inv[m], tx, ty, bd, s.dc_val[pl], s.src + sbase + ty * 16 + tx, 16, mm, false);
-                    satd = hadamard8_satd(mm);
-                }
-                ex.atomic_add(&s.csatd[k], (unsigned)satd);
-            }
-        });
-        ex.phase([&](int tid) {
-            if (tid != 0) return;
-            const int mode = (int)(s.mode_key & 63);
-            unsigned long long best = ~0ull;
-            for (int k = 0; k < 5; k++) {
-                const unsigned long long key = ((unsigned long long)((s.csatd[k] << 4) + (unsigned)(a.prm.lambda_sad_q4 * (k == 0 ? 1 : 3))) << 3) | (unsigned)k;
-                best = key < best ? key : best;
-            }
-            const int k = (int)(best & 7), base = k == 1 ? 0 : k == 2 ? 26 : k == 3 ? 10 : 1;
-            s.cmode_k = k;
-            s.cmode = k == 0 ? mode : (base == mode ? 34 : base);
-        });
-    }
-    // prediction of the chosen mode (luma) and the chosen chroma mode (DM unless prm.chroma_modes), residual
-    ex.phase([&](int tid) {
-        const int mode = (int)(s.mode_key & 63), cmode = s.cmode_k ? s.cmode : mode;
-        const int cang = s.tab_angle[cmode], cinv = s.tab_inv[cmode];
+    ex.phase([&](int tid) {      // prediction with the planned modes, residual
+        const int cang = s.tab_angle[cmode], cinv = s.tab_inv[cmode], ang = s.tab_angle[mode], inv = s.tab_inv[mode];
         const T *L = intra_filter_on(log2n, mode) ? s.filt : s.ref[0];
-        const int ang = s.tab_angle[mode], inv = s.tab_inv[mode];
         for (int k = tid; k < rcnt; k += NT) {
             const int i = rg.index(k);
             SampleLoc l = locate(s.rs, i);
@@ -442,8 +709,7 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         }
     });
     residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, rg);
-    // reconstruction into the LDS neighbourhood, distortion, rate estimate
-    ex.phase([&](int tid) {
+    ex.phase([&](int tid) {      // reconstruction into the LDS neighbourhood, distortion, rate estimate
         const int maxv = (1 << bd) - 1;
         unsigned sse = 0;
         for (int k = tid; k < rcnt; k += NT) {
@@ -468,20 +734,19 @@ DEV void intra_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, int 
         }
     });
     ex.phase([&](int tid) {
-        const int mode = (int)(s.mode_key & 63);
         int t0 = (cy >> 3) * 4 + (cx >> 3);
         if (tid < 16 && s.rs.tu_log2[tid]) {
             mihevc_cu_rec r;
             r.log2_size = (uint8_t)log2n;
             r.flags = (uint8_t)(((s.rs.cbf[0] >> t0) & 1 ? CU_CBF_Y : 0) | ((s.rs.cbf[1] >> t0) & 1 ? CU_CBF_CB : 0) | ((s.rs.cbf[2] >> t0) & 1 ? CU_CBF_CR : 0));
-            r.chroma_mode = (uint8_t)(s.cmode_k ? s.cmode : mode); r.qp = (uint8_t)a.prm.qp;
+            r.chroma_mode = (uint8_t)cmode; r.qp = (uint8_t)a.prm.qp;
             r.intra_mode[0] = r.intra_mode[1] = r.intra_mode[2] = r.intra_mode[3] = (uint8_t)mode;
             r.mvx = r.mvy = 0; r.cbf_y4 = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
             s.cu_acc[tid] = r;
         }
+        if (tid >= 64 && tid < 79) s.avmask[(tid - 64) / 5][(tid - 64) % 5] = 0;      // for the next CU's reference samples
         if (tid == 0) {
-            int mb = mode == s.cand[0] ? 2 : (mode == s.cand[1] || mode == s.cand[2]) ? 3 : 6;
-            int bits = 16 * mb + 16 + 24 + (s.cmode_k ? 32 : 0);
+            int bits = 16 * mode_bits_for(s.cand, mode) + 16 + 24 + (cmode != mode ? 32 : 0);
             for (int p = 0; p < 3; p++) bits += s.bits[p] ? s.bits[p] + R_TU : 0;
             s.j_cu = ((unsigned long long)s.sse << 4) + (((unsigned long long)a.prm.lambda_q4 * (unsigned long long)bits) >> 4);
             s.nx_try = (int)((s.rs.cbf[0] >> t0) & 1);
@@ -701,56 +966,37 @@ DEV void intra_cu_nxn(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0, 
     });
 }
 
-// copy the region (cx,cy,n) of the accumulated state to the save area (dir = 0) or back (dir = 1)
-template <typename T, class Ex> DEV void intra_save_restore(Ex &ex, IntraShared<T> &s, int cx, int cy, int n, int dir)
-{
-    const Region rg{cx, cy, n == 32 ? 5 : 4};
-    ex.phase([&](int tid) {
-        for (int k = tid; k < rg.count(); k += NT) {
-            const int i = rg.index(k);
-            int pl, x, y;
-            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int kk = i - 1024; pl = 1 + (kk >> 8); kk &= 255; x = kk & 15; y = kk >> 4; }
-            T *live = pl ? &s.rec_c[pl - 1][(y + 1) * RC_STRIDE + x + 1] : &s.rec_y[(y + 1) * RY_STRIDE + x + 1];
-            T *save = pl ? &s.save_c[pl - 1][y * 16 + x] : &s.save_y[y * 32 + x];
-            if (dir == 0) { *save = *live; s.coef_save[i] = s.coef_acc[i]; }
-            else { *live = *save; s.coef_acc[i] = s.coef_save[i]; }
-        }
-        if (tid < 16) {
-            int tx = (tid & 3) * 8, ty = (tid >> 2) * 8;
-            if (tx >= cx && tx < cx + n && ty >= cy && ty < cy + n) {
-                if (dir == 0) s.cu_save[tid] = s.cu_acc[tid]; else s.cu_acc[tid] = s.cu_save[tid];
-            }
-        }
-    });
-}
-
+// Stage B of one CTU (oracle intra_code_ctu): the plan's CUs in decoding order, the NxN trial on top of a planned 8x8 CU, then the
+// CTU's reconstruction, levels, records and rate estimate to memory.  `fresh`: the workgroup did not run the plan stage itself (I
+// pictures: k_intra_plan left the plan in a.plan), so tables, source image and plan are loaded here.
 template <typename T, class Ex>
-DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int ctu_x, int ctu_y)
+DEV void intra_code_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int ctu_x, int ctu_y, bool fresh)
 {
     const int x0 = ctu_x * CTU, y0 = ctu_y * CTU;
+    const TileBox tb = tile_box(a, ctu_x, ctu_y);
     const unsigned long long lam_split = (unsigned long long)a.prm.lambda_q4;     // (lambda_q4 * 16) >> 4
-    residual_init(ex, s.rs);
+    if (fresh) residual_init(ex, s.rs);
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1536; i += NT) {
-            int pl, x, y;
-            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
-            int gx = (pl ? x0 >> 1 : x0) + x, gy = (pl ? y0 >> 1 : y0) + y, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
-            s.src[i] = (gx < pw && gy < ph) ? a.src[pl].p[(size_t)gy * a.src[pl].stride + gx] : (T)0;
-            s.coef_acc[i] = 0;
+        if (fresh) {
+            load_ctu_source<T>(s.src, a.src, x0, y0, a.w, a.h, tid);
+            if (tid >= 64 && tid < 99) { s.tab_angle[tid - 64] = (int16_t)mode_angle(tid - 64); s.tab_inv[tid - 64] = (int16_t)mode_inv_angle(tid - 64); }
+            if (tid >= 128 && tid < 134) { s.tab_qs[tid - 128] = g_tab.quant_scale[tid - 128]; s.tab_ls[tid - 128] = g_tab.level_scale[tid - 128]; }
+            if (tid < 32) s.nx_mat[tid >> 4][tid & 15] = tid < 16 ? g_tab.dst4[(tid >> 2) & 3][tid & 3] : g_tab.mat[((tid >> 2) & 3) * 8][tid & 3];
+            if (tid >= 160 && tid < 181) {
+                const IntraPlan &p = a.plan[ctu_y * a.ctus_w + ctu_x];
+                s.plan.chosen[tid - 160] = p.chosen[tid - 160]; s.plan.mode[tid - 160] = p.mode[tid - 160]; s.plan.cmode[tid - 160] = p.cmode[tid - 160];
+            }
         }
+        for (int i = tid; i < 1536; i += NT) s.coef_acc[i] = 0;
         if (tid == 0) s.est = 0;
-        if (tid >= 64 && tid < 99) { s.tab_angle[tid - 64] = (int16_t)mode_angle(tid - 64); s.tab_inv[tid - 64] = (int16_t)mode_inv_angle(tid - 64); }
-        if (tid >= 128 && tid < 134) { s.tab_qs[tid - 128] = g_tab.quant_scale[tid - 128]; s.tab_ls[tid - 128] = g_tab.level_scale[tid - 128]; }
-        if (tid < 32) s.nx_mat[tid >> 4][tid & 15] = tid < 16 ? g_tab.dst4[(tid >> 2) & 3][tid & 3] : g_tab.mat[((tid >> 2) & 3) * 8][tid & 3];
+        if (tid >= 224 && tid < 239) s.avmask[(tid - 224) / 5][(tid - 224) % 5] = 0;
         if (tid < 4 && x0 > 0 && y0 + tid * 8 < a.h) s.left_cu[tid] = a.cu[(size_t)((y0 >> 3) + tid) * (a.w >> 3) + ((x0 - 1) >> 3)];
         // neighbourhood: row -1 (cols -1..63 luma / -1..31 chroma) and column -1 (rows 0..31 / 0..15) from the picture
         for (int u = tid; u < 65 + 32 + 2 * (33 + 16); u += NT) {
-            int pl, k, row_len, col_len;
-            if (u < 97) { pl = 0; k = u; row_len = 65; col_len = 32; }
-            else { pl = 1 + (u - 97) / 49; k = (u - 97) % 49; row_len = 33; col_len = 16; }
+            int pl, k, row_len;
+            if (u < 97) { pl = 0; k = u; row_len = 65; } else { pl = 1 + (u - 97) / 49; k = (u - 97) % 49; row_len = 33; }
             int xn, yn;
             if (k < row_len) { xn = k - 1; yn = -1; } else { xn = -1; yn = k - row_len; }
-            (void)col_len;
             int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
             int gx = (pl ? x0 >> 1 : x0) + xn, gy = (pl ? y0 >> 1 : y0) + yn;
             T v = 0;
@@ -758,37 +1004,29 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
             if (pl == 0) s.rec_y[(yn + 1) * RY_STRIDE + xn + 1] = v; else s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] = v;
         }
     });
-    unsigned long long j16[4];
+    // Which CUs run is uniform over the workgroup: plan.chosen is written once (above, or by the plan stage behind a barrier) and never
+    // again; j_cu / nx_try are words the CU's last phase writes and nobody rewrites before the next CU's last phase.
+    unsigned long long jctu = lam_split;
     for (int q = 0; q < 4; q++) {
         const int qx = (q & 1) * 16, qy = (q >> 1) * 16;
-        j16[q] = 0;
-        if (x0 + qx >= a.w || y0 + qy >= a.h) continue;
-        unsigned long long jsplit = lam_split;
+        bool any = false;
         for (int b = 0; b < 4; b++) {
+            if (!s.plan.chosen[5 + 4 * q + b]) continue;
             const int bx = qx + (b & 1) * 8, by = qy + (b >> 1) * 8;
-            if (x0 + bx >= a.w || y0 + by >= a.h) continue;
-            intra_cu(ex, s, a, x0, y0, bx, by, 3);
-            // NxN trial only when the 2Nx2N CU left a luma residual.  The condition must be uniform over the workgroup, so it is read from
-            // a word nobody writes before the next intra_cu ends — NOT from cu_acc[].flags, which the trial's first phase rewrites while
-            // slower waves may still be evaluating this line (that race made waves skip the trial and its barriers on loaded devices)
+            any = true;
+            intra_code_cu(ex, s, a, x0, y0, tb, bx, by, 3, s.plan.mode[5 + 4 * q + b], s.plan.cmode[5 + 4 * q + b]);
             if (a.prm.intra_nxn && s.nx_try) intra_cu_nxn(ex, s, a, x0, y0, bx, by);
-            jsplit += s.j_cu;
+            jctu += s.j_cu;
         }
-        const bool fits = x0 + qx + 16 <= a.w && y0 + qy + 16 <= a.h;
-        if (!fits) { j16[q] = jsplit; continue; }
-        intra_save_restore(ex, s, qx, qy, 16, 0);
-        intra_cu(ex, s, a, x0, y0, qx, qy, 4);
-        const unsigned long long jwhole = s.j_cu + lam_split;
-        if (jwhole <= jsplit) j16[q] = jwhole;
-        else { intra_save_restore(ex, s, qx, qy, 16, 1); j16[q] = jsplit; }
+        if (any) jctu += lam_split;
+        if (s.plan.chosen[1 + q]) {
+            intra_code_cu(ex, s, a, x0, y0, tb, qx, qy, 4, s.plan.mode[1 + q], s.plan.cmode[1 + q]);
+            jctu += s.j_cu + lam_split;
+        }
     }
-    unsigned long long jctu = lam_split + j16[0] + j16[1] + j16[2] + j16[3];
-    if (x0 + 32 <= a.w && y0 + 32 <= a.h) {
-        const unsigned long long jsplit = jctu;
-        intra_save_restore(ex, s, 0, 0, 32, 0);
-        intra_cu(ex, s, a, x0, y0, 0, 0, 5);
-        if (s.j_cu + lam_split > jsplit) intra_save_restore(ex, s, 0, 0, 32, 1);
-        else jctu = s.j_cu + lam_split;
+    if (s.plan.chosen[0]) {
+        intra_code_cu(ex, s, a, x0, y0, tb, 0, 0, 5, s.plan.mode[0], s.plan.cmode[0]);
+        jctu += s.j_cu;
     }
     // P picture: the intra version replaces the inter one only when it is cheaper (uniform over the workgroup)
     if (a.ip && jctu >= a.ip[ctu_y * a.ctus_w + ctu_x].jinter) return;
@@ -833,6 +1071,14 @@ DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int
     });
     // in a P picture the CTU's inter estimate is already in the picture total: add the difference (modulo 2^64)
     if (a.est) ex.phase([&](int tid) { if (tid == 0) ex.atomic_add_global(a.est, (unsigned long long)s.est - (a.ip ? (unsigned long long)a.ip[ctu_y * a.ctus_w + ctu_x].est : 0ull)); });
+}
+
+// plan + code of one CTU in one workgroup: the P pictures' second pass (k_intra_p) and the CPU stepping of the kernel source
+template <typename T, class Ex>
+DEV void intra_ctu_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int ctu_x, int ctu_y)
+{
+    intra_plan_program<T>(ex, s, a, ctu_x, ctu_y);
+    intra_code_program<T>(ex, s, a, ctu_x, ctu_y, false);
 }
 
 }  // namespace mihevc

@@ -18,11 +18,12 @@ DEV int pair_off(int log2n) { return log2n == 2 ? 0 : log2n == 3 ? 8 : log2n == 
 struct ResidualShared {
     // transform matrices as dword pairs for v_dot2_i32_i16, laid out so that the lanes of a wave (consecutive x)
     // read consecutive dwords: mp[off + p*n + u] = (M[u][2p], M[u][2p+1]),  mq[off + p*n + y] = (M[2p][y], M[2p+1][y])
-    uint32_t mp[680], mq[680];
-    int16_t res[1536];         // residual in, reconstructed residual out
-    int16_t tmp[1536];         // stage intermediates, row-pair interleaved: element (r, c) at (r & ~1) * stride + 2c + (r & 1)
-    int16_t coef[1536];        // transform coefficients / inverse stage-1 output (natural layout)
-    int16_t lvl[1536];         // quantised levels (TU-local raster at CTU coordinates)
+    alignas(16) uint32_t mp[680];
+    alignas(16) uint32_t mq[680];
+    alignas(16) int16_t res[1536];         // residual in, reconstructed residual out
+    alignas(16) int16_t tmp[1536];         // stage intermediates, row-pair interleaved: element (r, c) at (r & ~1) * stride + 2c + (r & 1)
+    alignas(16) int16_t coef[1536];        // transform coefficients / inverse stage-1 output (natural layout)
+    alignas(16) int16_t lvl[1536];         // quantised levels (TU-local raster at CTU coordinates)
     uint32_t desc[1536];       // per sample: TU geometry, written by the caller while it forms the residual
     uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
     uint8_t tu_intra[16];      // per tile: 1 = intra rounding
@@ -50,6 +51,15 @@ struct Region {
         k -= n2;
         const int q = n2 >> 2, pl = k >= q, kk = pl ? k - q : k, l2 = log2n - 1;
         return 1024 + pl * 256 + ((cy >> 1) + (kk >> l2)) * 16 + (cx >> 1) + (kk & ((1 << l2) - 1));
+    }
+    // k-th block of 2 rows x 4 columns (count() / 8 of them: luma first, then Cb, Cr) -> index of its top-left sample
+    DEV int block_index(int k) const
+    {
+        const int nb = 1 << (2 * log2n - 3);             // luma blocks: (n / 2) x (n / 4)
+        if (k < nb) { const int per = 1 << (log2n - 2); return (cy + 2 * (k >> (log2n - 2))) * 32 + cx + 4 * (k & (per - 1)); }
+        k -= nb;
+        const int q = nb >> 2, pl = k >= q, kk = pl ? k - q : k, l2 = log2n - 3;      // chroma plane: (n / 4) x (n / 8) blocks
+        return 1024 + pl * 256 + ((cy >> 1) + 2 * (kk >> l2)) * 16 + (cx >> 1) + 4 * (kk & ((1 << l2) - 1));
     }
 };
 DEV Region whole_ctu() { return Region{0, 0, 5}; }
@@ -82,83 +92,190 @@ DEV SampleLoc unpack_loc(uint32_t d, int idx)
     return l;
 }
 
+// 16 / 8 bytes of an LDS image whose address is 16- / 8-byte aligned as one ds_read_b128 / ds_read_b64 (and the matching stores)
+DEV void load_x4(const void *p, uint32_t (&v)[4]) { __builtin_memcpy(v, __builtin_assume_aligned(p, 16), 16); }
+DEV void load_x2(const void *p, uint32_t (&v)[2]) { __builtin_memcpy(v, __builtin_assume_aligned(p, 8), 8); }
+DEV void store_x4(void *p, const uint32_t (&v)[4]) { __builtin_memcpy(__builtin_assume_aligned(p, 16), v, 16); }
+DEV void store_x2(void *p, const uint32_t (&v)[2]) { __builtin_memcpy(__builtin_assume_aligned(p, 8), v, 8); }
+
 // forward + quant + scaling + inverse for every TU of the region; s.desc must describe the region's samples
-// (callers fill it while they form the residual).  qp / qp_c are syntax QPs.  Every inner loop is a v_dot2_i32_i16
-// over (matrix pair, sample pair) dwords whose addresses are consecutive across the lanes of a wave.
+// (callers fill it while they form the residual).  qp / qp_c are syntax QPs.
+// One lane owns a BLOCK of 2 rows x 4 columns of outputs per stage (TUs are at least 4x4 and 4-aligned, so a block never straddles a
+// TU): a matrix operand fetched once (ds_read_b128 / b64) feeds 8 v_dot2_i32_i16, the sample operands come as b128 rows or as the
+// row-pair dwords of `tmp`, results leave as b64 / b128 stores.  The one-output-per-lane form spent two ds_read_b32 per dot2 and was
+// LDS-issue bound (a third of k_inter_ctu's instructions, profiles/r02 phase table); a CTU is 192 blocks = one pass of the workgroup.
 template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth, Region rg)
 {
-    const int cnt = rg.count();
+    const int nblk = rg.count() >> 3;
+    // row stages (forward 1, inverse 2): out(y, u) = sum_p M-pair(p, u) . in(y, 2p..2p+1); column stages (forward 2, inverse 1):
+    // out(v, x) = sum_p M-pair(p, v) . in-row-pair(p, x), the row pairs of `tmp` being single dwords
+    auto row_stage = [&](const uint32_t *mat, const int16_t *in, const SampleLoc &l, int (&acc)[2][4]) {
+        const int n = 1 << l.log2n, u4 = l.x - l.tx0;
+        const uint32_t *m = mat + pair_off(l.log2n) + u4;
+        const int16_t *r0 = in + l.base + l.y * l.stride + l.tx0, *r1 = r0 + l.stride;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[j][i] = 0;
+        if (n == 4) {
+            uint32_t d0[2], d1[2];
+            load_x2(r0, d0); load_x2(r1, d1);
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                uint32_t mm[4];
+                load_x4(m + p * 4, mm);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { acc[0][i] = dot2_i16(mm[i], d0[p], acc[0][i]); acc[1][i] = dot2_i16(mm[i], d1[p], acc[1][i]); }
+            }
+            return;
+        }
+        for (int p0 = 0; p0 < n / 2; p0 += 4) {
+            uint32_t d0[4], d1[4];
+            load_x4(r0 + 2 * p0, d0); load_x4(r1 + 2 * p0, d1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t mm[4];
+                load_x4(m + (p0 + j) * n, mm);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { acc[0][i] = dot2_i16(mm[i], d0[j], acc[0][i]); acc[1][i] = dot2_i16(mm[i], d1[j], acc[1][i]); }
+            }
+        }
+    };
+    auto col_stage = [&](const uint32_t *mat, const SampleLoc &l, int (&acc)[2][4]) {
+        const int n = 1 << l.log2n, v2 = l.y - l.ty0;
+        const uint32_t *m = mat + pair_off(l.log2n) + v2;
+        const int16_t *t = s.tmp + l.base + l.ty0 * l.stride + 2 * l.x;
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[j][i] = 0;
+#pragma unroll 4
+        for (int p = 0; p < n / 2; p++) {
+            uint32_t d[4], mm[2];
+            load_x4(t + 2 * p * l.stride, d);
+            load_x2(m + p * n, mm);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { acc[0][i] = dot2_i16(mm[0], d[i], acc[0][i]); acc[1][i] = dot2_i16(mm[1], d[i], acc[1][i]); }
+        }
+    };
+    // rows (y, y+1) x columns (x..x+3) into the row-pair interleaved `tmp`: four dwords
+    auto store_pairs = [&](const SampleLoc &l, const int (&v)[2][4]) {
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = pack_lo16(v[0][i], v[1][i]);
+        store_x4(s.tmp + l.base + l.y * l.stride + 2 * l.x, o);
+    };
+    auto store_rows = [&](int16_t *dst, const SampleLoc &l, const int (&v)[2][4]) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            uint32_t o[2] = {pack_lo16(v[j][0], v[j][1]), pack_lo16(v[j][2], v[j][3])};
+            store_x2(dst + l.base + (l.y + j) * l.stride + l.x, o);
+        }
+    };
     ex.phase([&](int tid) {      // forward stage 1: rows
-        for (int k = tid; k < cnt; k += NT) {
-            const int idx = rg.index(k);
+        for (int k = tid; k < nblk; k += NT) {
+            const int idx = rg.block_index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            const int n = 1 << l.log2n, sh1 = l.log2n + bit_depth - 9, u = l.x - l.tx0;
-            const uint32_t *m = s.mp + pair_off(l.log2n) + u;
-            const int16_t *r = s.res + l.base + l.y * l.stride + l.tx0;
-            int acc = 0;
-            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(r + 2 * p), acc);
-            s.tmp[l.base + (l.y & ~1) * l.stride + 2 * l.x + (l.y & 1)] = (int16_t)(sh1 > 0 ? (acc + (1 << (sh1 - 1))) >> sh1 : acc);
+            const int sh1 = l.log2n + bit_depth - 9;
+            int acc[2][4];
+            row_stage(s.mp, s.res, l, acc);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[j][i] = sh1 > 0 ? (acc[j][i] + (1 << (sh1 - 1))) >> sh1 : acc[j][i];
+            store_pairs(l, acc);
         }
     });
     ex.phase([&](int tid) {      // forward stage 2: columns
-        for (int k = tid; k < cnt; k += NT) {
-            const int idx = rg.index(k);
+        for (int k = tid; k < nblk; k += NT) {
+            const int idx = rg.block_index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n) continue;
-            const int n = 1 << l.log2n, sh2 = l.log2n + 6, v = l.y - l.ty0;
-            const uint32_t *m = s.mp + pair_off(l.log2n) + v;
-            const int16_t *t = s.tmp + l.base + l.ty0 * l.stride + 2 * l.x;
-            int acc = 0;
-            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(t + 2 * p * l.stride), acc);
-            acc = (acc + (1 << (sh2 - 1))) >> sh2;
-            s.coef[idx] = (int16_t)clip3(-32768, 32767, acc);
+            const int sh2 = l.log2n + 6;
+            int acc[2][4];
+            col_stage(s.mp, l, acc);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[j][i] = clip3(-32768, 32767, (acc[j][i] + (1 << (sh2 - 1))) >> sh2);
+            store_rows(s.coef, l, acc);
         }
     });
     ex.phase([&](int tid) {      // quantisation + scaling (8.6.4.1, flat m = 16)
-        for (int k = tid; k < cnt; k += NT) {
-            const int idx = rg.index(k);
+        for (int k = tid; k < nblk; k += NT) {
+            const int idx = rg.block_index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
-            if (!l.log2n) { s.lvl[idx] = 0; continue; }
-            int q = (l.plane ? qp_c : qp) + 6 * (bit_depth - 8);
-            int qbits = 14 + q / 6 + (15 - bit_depth - l.log2n);
-            long long add = (long long)(l.intra ? 171 : 85) << (qbits - 9);
-            int c = s.coef[idx];
-            long long a = ((long long)iabs(c) * s.quant_scale[q % 6] + add) >> qbits;
-            if (a > 32767) a = 32767;
-            int lev = (int)(c < 0 ? -a : a);
-            s.lvl[idx] = (int16_t)lev;
-            if (lev) ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
-            int bd_shift = bit_depth + l.log2n - 5;
-            long long scale = (long long)16 * s.level_scale[q % 6] << (q / 6);
-            long long d = (lev * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
-            s.tmp[l.base + (l.y & ~1) * l.stride + 2 * l.x + (l.y & 1)] = (int16_t)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
+            int lev[2][4], deq[2][4];
+            if (!l.log2n) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) lev[j][i] = 0;
+                store_rows(s.lvl, l, lev);
+                continue;
+            }
+            const int q = (l.plane ? qp_c : qp) + 6 * (bit_depth - 8);
+            const int qbits = 14 + q / 6 + (15 - bit_depth - l.log2n), bd_shift = bit_depth + l.log2n - 5;
+            const long long add = (long long)(l.intra ? 171 : 85) << (qbits - 9);
+            const long long scale = (long long)16 * s.level_scale[q % 6] << (q / 6);
+            const int qs = s.quant_scale[q % 6];
+            int any = 0;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                uint32_t c2[2];
+                load_x2(s.coef + l.base + (l.y + j) * l.stride + l.x, c2);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int c = (int)(int16_t)(c2[i >> 1] >> (16 * (i & 1)));
+                    long long a = ((long long)iabs(c) * qs + add) >> qbits;
+                    if (a > 32767) a = 32767;
+                    const int lv = (int)(c < 0 ? -a : a);
+                    lev[j][i] = lv;
+                    any |= lv;
+                    const long long d = (lv * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
+                    deq[j][i] = (int)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
+                }
+            }
+            store_rows(s.lvl, l, lev);
+            if (any) ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
+            store_pairs(l, deq);
         }
     });
     ex.phase([&](int tid) {      // inverse stage 1: columns, shift 7, clip to 16 bit (8.6.4.2)
-        for (int k = tid; k < cnt; k += NT) {
-            const int idx = rg.index(k);
+        for (int k = tid; k < nblk; k += NT) {
+            const int idx = rg.block_index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
             if (!l.log2n || !((s.cbf[l.plane] >> l.tile0) & 1)) continue;     // a TU without levels reconstructs to zero: nothing to invert
-            const int n = 1 << l.log2n, yy = l.y - l.ty0;
-            const uint32_t *m = s.mq + pair_off(l.log2n) + yy;
-            const int16_t *d = s.tmp + l.base + l.ty0 * l.stride + 2 * l.x;
-            int acc = 0;
-            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(d + 2 * p * l.stride), acc);
-            s.coef[idx] = (int16_t)clip3(-32768, 32767, (acc + 64) >> 7);
+            int acc[2][4];
+            col_stage(s.mq, l, acc);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[j][i] = clip3(-32768, 32767, (acc[j][i] + 64) >> 7);
+            store_rows(s.coef, l, acc);
         }
     });
     ex.phase([&](int tid) {      // inverse stage 2: rows, shift 20 - bitDepth
-        for (int k = tid; k < cnt; k += NT) {
-            const int idx = rg.index(k);
+        for (int k = tid; k < nblk; k += NT) {
+            const int idx = rg.block_index(k);
             SampleLoc l = unpack_loc(s.desc[idx], idx);
-            if (!l.log2n || !((s.cbf[l.plane] >> l.tile0) & 1)) { s.res[idx] = 0; continue; }
-            const int n = 1 << l.log2n, xx = l.x - l.tx0, sh = 20 - bit_depth;
-            const uint32_t *m = s.mq + pair_off(l.log2n) + xx;
-            const int16_t *g = s.coef + l.base + l.y * l.stride + l.tx0;
-            int acc = 0;
-            for (int p = 0; p < n / 2; p++) acc = dot2_i16(m[p * n], load_u32_aligned(g + 2 * p), acc);
-            s.res[idx] = (int16_t)((acc + (1 << (sh - 1))) >> sh);
+            int acc[2][4];
+            if (!l.log2n || !((s.cbf[l.plane] >> l.tile0) & 1)) {
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[j][i] = 0;
+                store_rows(s.res, l, acc);
+                continue;
+            }
+            const int sh = 20 - bit_depth;
+            row_stage(s.mq, s.coef, l, acc);
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[j][i] = (int)(int16_t)((acc[j][i] + (1 << (sh - 1))) >> sh);
+            store_rows(s.res, l, acc);
         }
     });
 }

@@ -164,6 +164,7 @@ struct mihevc_session {
         void *work_base[3], *work_p[3]; int work_stride[3];           // pre-deblock / deblocked picture (unpadded)
         int32_t *me = nullptr;
         IpInfo *ip = nullptr;      // per CTU: inter pass -> intra second pass of P pictures
+        IntraPlan *plan = nullptr; // per CTU: k_intra_plan -> k_intra_diag (IDR pictures)
         void *lsrc = nullptr, *lref = nullptr;   // 1/4-size source / reference luma of the step's picture (pre-search)
         int16_t *centers = nullptr;              // per CTU search centre
         uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
@@ -241,6 +242,7 @@ int ensure_lanes(mihevc_session *s, int n)
         if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, false)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
+        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, (void **)&L.plan));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lsrc));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lref));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, (void **)&L.centers));
@@ -402,6 +404,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             const bool ipass = t > 0 && s->cfg.intra_in_p;
             A.inter.ip = ipass ? L.ip : nullptr;
             A.intra.ip = ipass ? L.ip : nullptr;
+            A.intra.plan = t == 0 ? L.plan : nullptr;      // P pictures' second pass plans and codes a CTU inside one workgroup
             if (t > 0) { A.intra.prm.tile_cols = A.intra.prm.tile_rows = 1; }
             A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
             A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
@@ -931,6 +934,7 @@ void mihevc_close(mihevc_session *s)
         free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
+        bc.release(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, L.plan);
         bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lsrc);
         bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lref);
         bc.release(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, L.centers);

@@ -919,8 +919,129 @@ static int intra_mode_bits(const int cand[3], int mode)
     return 6;
 }
 
-/* one 2Nx2N intra CU: SATD mode search, reconstruction (Y, Cb, Cr), records; returns RD cost */
-static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
+/* ---- stage A of an intra CTU: the PLAN.  Every quadtree node is costed on the SOURCE picture (its neighbours stand in for the
+ * reconstruction, with the real availability rules: picture, tile, z-order), so all CTUs of a picture are independent and the device plans
+ * them in one launch; only stage B (intra_cu below: prediction from the real reconstruction, residual, reconstruction) runs as a CTU
+ * wavefront, and only for the CUs the plan chose.  Round 1 searched modes and tree depth-first on the reconstruction: 21 CUs x ~16 barrier
+ * phases inside the wavefront, 23 % of the device time for 4 of 300 pictures.
+ *   luma mode of a node: min over 35 modes of (SATD << 4) + lambda_sad * bits, bits 2 / 3 / 6 against a candidate list built (8.4.2) from
+ *     the planned modes of the SAME-LEVEL nodes left of and above it inside the CTU (DC outside the CTU); ties -> lowest mode
+ *   chroma mode: DM / planar / 26 / 10 / DC (a candidate equal to the luma mode stands for 34) by SATD over Cb + Cr + lambda_sad * (1 | 3)
+ *   node cost J = (SSE << 4) + lambda * estimated bits of coding Y, Cb, Cr with those modes (prediction still from the source neighbourhood)
+ *   tree: bottom-up, split = lambda + children, whole = J + lambda, whole wins ties */
+typedef struct { uint8_t chosen[21], mode[21], cmode[21]; } intra_plan;
+
+static void intra_plan_ctu(const intra_ctx *c, int x0, int y0, intra_plan *pl)
+{
+    const orc_params *prm = c->prm;
+    const int bd = prm->bit_depth, lam = prm->lambda_sad_q4;
+    int valid[21], nx[21], ny[21], nl[21];
+    uint64_t J[21];
+    pix ref[129], filt[129], pred[32 * 32];
+    memset(pl, 0, sizeof *pl);
+    for (int nd = 0; nd < 21; nd++) {
+        node_geom(nd, &nx[nd], &ny[nd], &nl[nd]);
+        valid[nd] = x0 + nx[nd] + (1 << nl[nd]) <= c->w && y0 + ny[nd] + (1 << nl[nd]) <= c->h;
+        J[nd] = 0;
+    }
+    for (int level = 2; level >= 0; level--) {
+        int first = level == 2 ? 5 : level == 1 ? 1 : 0, count = level == 2 ? 16 : level == 1 ? 4 : 1;
+        for (int nd = first; nd < first + count; nd++) {
+            if (!valid[nd]) continue;
+            const int log2n = nl[nd], n = 1 << log2n, x = x0 + nx[nd], y = y0 + ny[nd];
+            int a = 1, b = 1, cand[3];
+            for (int k = first; k < nd; k++) {
+                if (!valid[k]) continue;
+                if (nx[k] + n == nx[nd] && ny[k] == ny[nd]) a = pl->mode[k];
+                if (ny[k] + n == ny[nd] && nx[k] == nx[nd]) b = pl->mode[k];
+            }
+            if (a == b) {
+                if (a < 2) { cand[0] = 0; cand[1] = 1; cand[2] = 26; }
+                else { cand[0] = a; cand[1] = 2 + ((a + 29) & 31); cand[2] = 2 + ((a - 2 + 1) & 31); }
+            } else {
+                cand[0] = a; cand[1] = b;
+                cand[2] = (a != 0 && b != 0) ? 0 : (a != 1 && b != 1) ? 1 : 26;
+            }
+            orc_intra_build_ref_tiles(c->src[0], c->sstride[0], x, y, log2n, c->w, c->h, 0, bd, prm->tile_cols, prm->tile_rows, ref);
+            const pix *s = c->src[0] + y * c->sstride[0] + x;
+            uint64_t best = ~0ull;
+            for (int mode = 0; mode < 35; mode++) {
+                orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
+                orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
+                uint32_t cst = ((uint32_t)orc_satd(s, c->sstride[0], pred, n, n, n) << 4) + (uint32_t)(lam * intra_mode_bits(cand, mode));
+                uint64_t key = ((uint64_t)cst << 6) | (uint32_t)mode;
+                if (key < best) best = key;
+            }
+            const int mode = (int)(best & 63);
+            uint32_t cost = (uint32_t)(best >> 6);
+            int cmode = mode;
+            if (prm->chroma_modes) {
+                static const int base[4] = {0, 26, 10, 1};
+                int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
+                pix refc[2][129];
+                for (int ci = 1; ci < 3; ci++)
+                    orc_intra_build_ref_tiles(c->src[ci], c->sstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, refc[ci - 1]);
+                uint64_t bestc = ~0ull;
+                for (int k = 0; k < 5; k++) {
+                    int m = k == 0 ? mode : (base[k - 1] == mode ? 34 : base[k - 1]);
+                    uint32_t satd = 0;
+                    for (int ci = 1; ci < 3; ci++) {
+                        orc_intra_pred(refc[ci - 1], pred, nc, l2, m, ci, bd);
+                        satd += (uint32_t)orc_satd(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc, nc, nc);
+                    }
+                    uint64_t key = ((uint64_t)((satd << 4) + (uint32_t)(lam * (k == 0 ? 1 : 3))) << 3) | (uint32_t)k;
+                    if (key < bestc) bestc = key;
+                }
+                int k = (int)(bestc & 7);
+                if (k) cmode = base[k - 1] == mode ? 34 : base[k - 1];
+                cost += (uint32_t)(bestc >> 3);
+            }
+            pl->mode[nd] = (uint8_t)mode; pl->cmode[nd] = (uint8_t)cmode;
+            /* RD cost of the node with these modes, still on the source neighbourhood: residual coding of Y, Cb, Cr into scratch */
+            {
+                pix rec_tmp[32 * 32];
+                int16_t coef_tmp[32 * 32];
+                int64_t sse, sse_total = 0;
+                int bits, bits_total = 16 * intra_mode_bits(cand, mode) + 16 + 24 + (cmode != mode ? 32 : 0);
+                orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
+                orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
+                code_tu(s, c->sstride[0], pred, n, rec_tmp, n, coef_tmp, n, log2n, prm->qp, bd, 1, 0, &sse, &bits);
+                sse_total += sse; bits_total += bits;
+                for (int ci = 1; ci < 3; ci++) {
+                    int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
+                    orc_intra_build_ref_tiles(c->src[ci], c->sstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
+                    orc_intra_pred(ref, pred, nc, l2, cmode, ci, bd);
+                    code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc, rec_tmp, nc, coef_tmp, nc, l2, prm->qp_c, bd, 1, 0, &sse, &bits);
+                    sse_total += sse; bits_total += bits;
+                }
+                J[nd] = ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);
+            }
+            (void)cost;
+        }
+    }
+    /* tree, bottom-up on the RD costs: split = lambda + children, whole = own + lambda, whole wins ties (the rule the depth-first search
+     * on the reconstruction used); nodes outside the picture count 0, a node that does not fit is always split */
+    const uint64_t lam_split = ((uint64_t)prm->lambda_q4 * 16) >> 4;
+    int use16[4], use32;
+    uint64_t J16[4], js32 = lam_split;
+    for (int q = 0; q < 4; q++) {
+        uint64_t js = lam_split;
+        for (int k = 0; k < 4; k++) if (valid[5 + 4 * q + k]) js += J[5 + 4 * q + k];
+        use16[q] = valid[1 + q] && J[1 + q] + lam_split <= js;
+        J16[q] = use16[q] ? J[1 + q] + lam_split : js;
+        int any = 0;
+        for (int k = 0; k < 4; k++) any |= valid[5 + 4 * q + k];
+        js32 += any ? J16[q] : 0;
+    }
+    use32 = valid[0] && J[0] + lam_split <= js32;
+    for (int nd = 0; nd < 21; nd++) {
+        if (!valid[nd]) continue;
+        pl->chosen[nd] = (uint8_t)(nd == 0 ? use32 : nd < 5 ? (!use32 && use16[nd - 1]) : (!use32 && !use16[(nd - 5) >> 2]));
+    }
+}
+
+/* ---- stage B: one planned 2Nx2N intra CU: prediction from the reconstruction, residual coding (Y, Cb, Cr), records; returns RD cost */
+static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n, int mode, int cmode)
 {
     const orc_params *prm = c->prm;
     int n = 1 << log2n, bd = prm->bit_depth;
@@ -928,17 +1049,7 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
     int cand[3];
     mpm_list(c, x, y, cand);
     orc_intra_build_ref_tiles(c->rec[0], c->rstride[0], x, y, log2n, c->w, c->h, 0, bd, prm->tile_cols, prm->tile_rows, ref);
-    uint64_t best = ~0ull;
     const pix *s = c->src[0] + y * c->sstride[0] + x;
-    for (int mode = 0; mode < 35; mode++) {
-        orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
-        orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
-        uint32_t cst = ((uint32_t)orc_satd(s, c->sstride[0], pred, n, n, n) << 4) +
-                       (uint32_t)(prm->lambda_sad_q4 * intra_mode_bits(cand, mode));
-        uint64_t key = ((uint64_t)cst << 6) | (uint32_t)mode;
-        if (key < best) best = key;
-    }
-    int mode = (int)(best & 63);
     int64_t sse, sse_total = 0;
     int bits, bits_total = 16 * intra_mode_bits(cand, mode) + 16 + 24;
     int flags = 0;
@@ -947,29 +1058,8 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n)
     if (code_tu(s, c->sstride[0], pred, n, c->rec[0] + y * c->rstride[0] + x, c->rstride[0],
                 c->coef[0] + y * c->w + x, c->w, log2n, prm->qp, bd, 1, 0, &sse, &bits)) flags |= ORC_F_CBF_Y;
     sse_total += sse; bits_total += bits;
-    /* intra_chroma_pred_mode (7.4.9.6 / Table 8-2): DM (= the luma mode) or planar / vertical / horizontal / DC, where a candidate equal
-     * to the luma mode stands for mode 34.  Chosen by SATD over Cb + Cr plus lambda * (1 bit for DM, 3 for the others); DM wins ties. */
-    int cmode = mode;
-    if (prm->chroma_modes) {
-        static const int base[4] = {0, 26, 10, 1};
-        int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
-        pix refc[2][129];
-        for (int ci = 1; ci < 3; ci++)
-            orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, refc[ci - 1]);
-        uint64_t bestc = ~0ull;
-        for (int k = 0; k < 5; k++) {
-            int m = k == 0 ? mode : (base[k - 1] == mode ? 34 : base[k - 1]);
-            uint32_t satd = 0;
-            for (int ci = 1; ci < 3; ci++) {
-                orc_intra_pred(refc[ci - 1], pred, nc, l2, m, ci, bd);
-                satd += (uint32_t)orc_satd(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc, nc, nc);
-            }
-            uint64_t key = ((uint64_t)((satd << 4) + (uint32_t)(prm->lambda_sad_q4 * (k == 0 ? 1 : 3))) << 3) | (uint32_t)k;
-            if (key < bestc) bestc = key;
-        }
-        int k = (int)(bestc & 7);
-        if (k) { cmode = base[k - 1] == mode ? 34 : base[k - 1]; bits_total += 32; }
-    }
+    /* intra_chroma_pred_mode (7.4.9.6 / Table 8-2) other than DM: 2 more bits in the rate estimate */
+    if (cmode != mode) bits_total += 32;
     for (int ci = 1; ci < 3; ci++) {
         int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
         orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
@@ -1047,59 +1137,53 @@ static void region_copy16(int16_t *dst, int ds, const int16_t *src, int ss, int 
     for (int y = 0; y < h; y++) memcpy(dst + y * ds, src + y * ss, w * sizeof(int16_t));
 }
 
-/* depth-first: children first, then the whole block; keep the cheaper (whole wins ties) */
-static uint64_t intra_tree(intra_ctx *c, int x, int y, int log2n)
+/* stage B of one CTU: the plan's CUs in decoding order (z-order), NxN trial on top of a planned 8x8 CU; returns the CTU's RD cost
+ * (sum of the CU costs + lambda per quadtree node above the leaves), which the P pictures' second pass holds against the inter cost */
+static uint64_t intra_code_ctu(intra_ctx *c, int x0, int y0, const intra_plan *pl)
 {
-    if (x >= c->w || y >= c->h) return 0;
-    int n = 1 << log2n;
-    if (log2n == ORC_MINCU_LOG2) {
-        uint64_t j2n = intra_cu(c, x, y, log2n);
-        if (!c->prm->intra_nxn) return j2n;
-        /* a 2Nx2N CU whose luma residual quantised to nothing is predicted well enough: no NxN trial */
-        if (!(c->cu[(y >> 3) * c->w8 + (x >> 3)].flags & ORC_F_CBF_Y)) return j2n;
-        /* try NxN on top of the 2Nx2N result; 2Nx2N wins ties */
-        pix sv[3][64];
-        int16_t sc[3][64];
-        orc_cu_rec scu = c->cu[(y >> 3) * c->w8 + (x >> 3)];
-        for (int ci = 0; ci < 3; ci++) {
-            int sh = ci ? 1 : 0;
-            region_copy(sv[ci], 8 >> sh, c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], 8 >> sh, 8 >> sh);
-            region_copy16(sc[ci], 8 >> sh, c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, 8 >> sh, 8 >> sh);
+    const uint64_t lam_split = ((uint64_t)c->prm->lambda_q4 * 16) >> 4;
+    uint64_t j = lam_split;
+    for (int q = 0; q < 4; q++) {
+        int any = 0;
+        for (int k = 0; k < 4; k++) {
+            int nd = 5 + 4 * q + k, x, y, l;
+            node_geom(nd, &x, &y, &l);
+            x += x0; y += y0;
+            if (!pl->chosen[nd]) continue;
+            any = 1;
+            uint64_t j2n = intra_cu(c, x, y, 3, pl->mode[nd], pl->cmode[nd]);
+            /* NxN trial: only when the 2Nx2N CU left a luma residual; 2Nx2N wins ties */
+            if (c->prm->intra_nxn && (c->cu[(y >> 3) * c->w8 + (x >> 3)].flags & ORC_F_CBF_Y)) {
+                pix sv[3][64];
+                int16_t sc[3][64];
+                orc_cu_rec scu = c->cu[(y >> 3) * c->w8 + (x >> 3)];
+                for (int ci = 0; ci < 3; ci++) {
+                    int sh = ci ? 1 : 0;
+                    region_copy(sv[ci], 8 >> sh, c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], 8 >> sh, 8 >> sh);
+                    region_copy16(sc[ci], 8 >> sh, c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, 8 >> sh, 8 >> sh);
+                }
+                uint64_t jnxn = intra_cu_nxn(c, x, y);
+                if (jnxn < j2n) j2n = jnxn;
+                else {
+                    for (int ci = 0; ci < 3; ci++) {
+                        int sh = ci ? 1 : 0;
+                        region_copy(c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], sv[ci], 8 >> sh, 8 >> sh, 8 >> sh);
+                        region_copy16(c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, sc[ci], 8 >> sh, 8 >> sh, 8 >> sh);
+                    }
+                    c->cu[(y >> 3) * c->w8 + (x >> 3)] = scu;
+                }
+            }
+            j += j2n;
         }
-        uint64_t jnxn = intra_cu_nxn(c, x, y);
-        if (jnxn < j2n) return jnxn;
-        for (int ci = 0; ci < 3; ci++) {
-            int sh = ci ? 1 : 0;
-            region_copy(c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], sv[ci], 8 >> sh, 8 >> sh, 8 >> sh);
-            region_copy16(c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, sc[ci], 8 >> sh, 8 >> sh, 8 >> sh);
+        if (any) j += lam_split;
+        if (pl->chosen[1 + q]) {
+            int x, y, l;
+            node_geom(1 + q, &x, &y, &l);
+            j += intra_cu(c, x0 + x, y0 + y, 4, pl->mode[1 + q], pl->cmode[1 + q]) + lam_split;
         }
-        c->cu[(y >> 3) * c->w8 + (x >> 3)] = scu;
-        return j2n;
     }
-    int fits = x + n <= c->w && y + n <= c->h;
-    uint64_t jsplit = ((uint64_t)c->prm->lambda_q4 * 16) >> 4;
-    for (int q = 0; q < 4; q++) jsplit += intra_tree(c, x + (q & 1) * (n / 2), y + (q >> 1) * (n / 2), log2n - 1);
-    if (!fits) return jsplit;
-    pix sv[3][32 * 32];
-    int16_t sc[3][32 * 32];
-    orc_cu_rec scu[16];
-    for (int ci = 0; ci < 3; ci++) {
-        int sh = ci ? 1 : 0;
-        region_copy(sv[ci], n >> sh, c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], n >> sh, n >> sh);
-        region_copy16(sc[ci], n >> sh, c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, n >> sh, n >> sh);
-    }
-    for (int yy = 0; yy < n / 8; yy++)
-        for (int xx = 0; xx < n / 8; xx++) scu[yy * 4 + xx] = c->cu[((y >> 3) + yy) * c->w8 + (x >> 3) + xx];
-    uint64_t jwhole = intra_cu(c, x, y, log2n) + (((uint64_t)c->prm->lambda_q4 * 16) >> 4);
-    if (jwhole <= jsplit) return jwhole;
-    for (int ci = 0; ci < 3; ci++) {
-        int sh = ci ? 1 : 0;
-        region_copy(c->rec[ci] + (y >> sh) * c->rstride[ci] + (x >> sh), c->rstride[ci], sv[ci], n >> sh, n >> sh, n >> sh);
-        region_copy16(c->coef[ci] + (y >> sh) * (c->w >> sh) + (x >> sh), c->w >> sh, sc[ci], n >> sh, n >> sh, n >> sh);
-    }
-    for (int yy = 0; yy < n / 8; yy++)
-        for (int xx = 0; xx < n / 8; xx++) c->cu[((y >> 3) + yy) * c->w8 + (x >> 3) + xx] = scu[yy * 4 + xx];
-    return jsplit;
+    if (pl->chosen[0]) j += intra_cu(c, x0, y0, 5, pl->mode[0], pl->cmode[0]);
+    return j;
 }
 
 /* Intra second pass of a P picture.  The first pass coded every CTU inter; CTUs flagged in cand[] are re-coded as intra
@@ -1158,7 +1242,9 @@ static void intra_in_p_pass(const pix *src_y, const pix *src_u, const pix *src_v
                 }
                 for (int yy = 0; yy < bh / 8; yy++)
                     for (int xx = 0; xx < bw / 8; xx++) scu[yy * 4 + xx] = cu[((y0 >> 3) + yy) * c.w8 + (x0 >> 3) + xx];
-                uint64_t jintra = intra_tree(&c, x0, y0, ORC_CTU_LOG2);
+                intra_plan pl;
+                intra_plan_ctu(&c, x0, y0, &pl);
+                uint64_t jintra = intra_code_ctu(&c, x0, y0, &pl);
                 if (jintra < jinter[cy * wc + cx]) continue;
                 for (int ci = 0; ci < 3; ci++) {
                     int sh = ci ? 1 : 0;
@@ -1183,7 +1269,11 @@ void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_
     c.coef[0] = coef_y; c.coef[1] = coef_u; c.coef[2] = coef_v;
     c.cu = cu; c.w = w; c.h = h; c.w8 = w >> 3; c.prm = prm;
     for (int y = 0; y < h; y += ORC_CTU)
-        for (int x = 0; x < w; x += ORC_CTU) intra_tree(&c, x, y, ORC_CTU_LOG2);
+        for (int x = 0; x < w; x += ORC_CTU) {
+            intra_plan pl;
+            intra_plan_ctu(&c, x, y, &pl);
+            intra_code_ctu(&c, x, y, &pl);
+        }
     if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, NULL);
 }
 

@@ -185,7 +185,7 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
         for (int i = 0; i < 3; i++) { ia.src[i] = a.src[i]; ia.rec[i] = a.rec[i]; ia.coef[i] = a.coef[i]; }
         ia.w = w; ia.h = h; ia.ctus_w = a.ctus_w; ia.ctus_h = (h + CTU - 1) / CTU;
         ia.prm = a.prm; ia.prm.tile_cols = ia.prm.tile_rows = 1;
-        ia.cu = cu; ia.diagonal = 0; ia.est = est; ia.sparse_coef = 0; ia.ip = a.ip;
+        ia.cu = cu; ia.diagonal = 0; ia.est = est; ia.sparse_coef = 0; ia.ip = a.ip; ia.plan = nullptr;
         for (int round = 0; round < 2; round++)
             for (int c = 0; c < n_ctu; c++) {
                 if (!ip_eligible(ia.ip, ia.ctus_w, ia.ctus_h, c % ia.ctus_w, c / ia.ctus_w, round)) continue;
@@ -208,7 +208,7 @@ static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, cons
     a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU;
-    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0; a.ip = nullptr;
+    a.prm = to_prm(prm); a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0; a.ip = nullptr; a.plan = nullptr;
     if (est) *est = 0;
     SeqExec ex; ex.order = emu_order();
     // same launch order as the device: per tile, one anti-diagonal (cx + 2 cy inside the tile) at a time

@@ -32,7 +32,7 @@ def test_bench_spawns_one_process_per_rank():
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and len(out["per_rank_fps"]) == 2
     # the stub's rank 1 sleeps twice as long as rank 0: the job time is the MAX over ranks, the aggregate counts both ranks' frames
     assert out["per_rank_fps"][0] > out["per_rank_fps"][1]
-    assert abs(out["value"] - 2 * out["per_rank_fps"][1]) / out["value"] < 0.2
+    assert abs(out["value"] - 2 * out["per_rank_fps"][1]) / out["value"] < 0.35
 
 
 def test_bench_under_the_drivers_launcher():
