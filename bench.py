@@ -295,6 +295,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed legs (stream check, PCIe-inclusive run, 2160p config, libx265 probe run)")
     ap.add_argument("--host-threads", type=int, default=0, help="CABAC worker threads (0 = library default)")
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
+    ap.add_argument("--profile-stages", type=int, default=2, help="HIP events in the timed steps: 2 = around the dominant kernel (inter_ctu) only, 1 = every stage, 0 = none")
     ap.add_argument("--stub", action="store_true", help="tests only: no GPU, no encoder — exercises the rank spawn / rendezvous / JSON path (tests/test_bench_ranks.py)")
     for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes"):
         ap.add_argument("--" + name, type=int, default=None, help="experiments only: override cfg." + name.replace("-", "_"))
@@ -349,7 +350,7 @@ def main():
         return info, config_for(info, crf, maxrate, bufsize, gop, level, tier), (crf, maxrate, bufsize, gop)
 
     info, cfg, (crf, maxrate, bufsize, gop) = operating_point(W, H, N, False)
-    cfg.me_range, cfg.profile_stages = args.me_range, 1
+    cfg.me_range, cfg.profile_stages = args.me_range, args.profile_stages
     cfg.qp = args.qp
     cfg.host_threads = args.host_threads
     for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes"):
@@ -417,6 +418,7 @@ def main():
         stage_pics += np.array(st.stage_pictures[:])
         last = (st, nbytes, psnr, hdrs)
     own = time.perf_counter() - t0                   # this rank's own K steps (every step ends with the last NAL byte on the host)
+    roof_ms, roof_launch, roof_pics = stage_ms[2], stage_launch[2], stage_pics[2]      # inter_ctu, measured live in the timed steps
     barrier()
     dts = ranks.gather(time.perf_counter() - t0)     # barrier to barrier; the job takes the MAX over ranks
     dt = max(dts)
@@ -424,6 +426,11 @@ def main():
     st, nbytes, psnr, hdrs = last
 
     # ---- untimed legs ----
+    if rank == 0 and args.profile_stages != 1:       # one more step with every stage bracketed: the per-stage table (events cost ~5 % fps)
+        cfg.profile_stages = 1
+        stp = step()[0]
+        stage_ms, stage_launch, stage_pics = np.array(stp.stage_ms[:]), np.array(stp.stage_launches[:], dtype=float), np.array(stp.stage_pictures[:], dtype=float)
+        cfg.profile_stages = args.profile_stages
     check = {"stream_ok": None}
     if not args.no_extras:
         check = verify_stream(kept, hdrs, cfg, clip, st)            # every rank checks its own stream
@@ -436,10 +443,14 @@ def main():
         # me_search reads source + reference luma = 2*W*H; intra = S read + S write; loop filters: see DESIGN.md.
         S = W * ((H + 7) & ~7) * 3 // 2
         per_pic = {0: 2 * S, 1: 2 * W * ((H + 7) & ~7), 2: 3 * S, 3: 4 * S, 4: 4 * S, 5: S, 6: 2 * S}
-        dom = int(np.argmax(stage_ms[:7]))
-        launches = max(1.0, stage_launch[dom])
-        avg_ms = stage_ms[dom] / launches
-        bytes_per_launch = per_pic[dom] * stage_pics[dom] / launches
+        dom = int(np.argmax(stage_ms[:7]))               # by the fully bracketed step; the timed steps bracket inter_ctu, the dominant kernel
+        if args.profile_stages == 2 or dom == 2:
+            dom, launches, avg_ms = 2, max(1.0, roof_launch), roof_ms / max(1.0, roof_launch)
+            bytes_per_launch = per_pic[2] * roof_pics / launches
+        else:
+            launches = max(1.0, stage_launch[dom])
+            avg_ms = stage_ms[dom] / launches
+            bytes_per_launch = per_pic[dom] * stage_pics[dom] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kname = "k_" + _lib.STAGE_NAMES[dom] if dom else "k_intra_diag"
         traffic, traffic_src = measured_traffic(kname, (W, H, N, args.me_range))
@@ -465,7 +476,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": _lib.STAGE_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "avg_launch_ms": round(avg_ms, 4), "pictures_per_launch": round(stage_pics[dom] / launches, 2),
+                         "avg_launch_ms": round(avg_ms, 4), "pictures_per_launch": round(bytes_per_launch / per_pic[dom], 2),
+                         "dominant_by_full_profile": _lib.STAGE_NAMES[int(np.argmax(stage_ms[:7]))],
                          "valu_issue_frac": valu["valu_issue_frac"] if valu else None, "valu": valu,
                          "note": "integer-VALU/LDS bound path: the HBM fraction is small by construction (SURVEY.md §0.5); valu_issue_frac is the "
                                  "share of SIMD issue slots the kernel fills, from the committed SQ counter pass"},

@@ -28,9 +28,9 @@ template <typename T> __global__ __launch_bounds__(NT, 3) void k_me_search(const
     me_search_program<T>(ex, s, win, a, ctu);
 }
 
-// workgroups per CU: 4 for 8-bit (144 VGPRs without the hoisted lane arithmetic, see GpuExec::lane_id; 0.196 -> 0.169 ms/picture),
-// 3 for Main10 (167 VGPRs)
-template <typename T> __global__ __launch_bounds__(NT, (sizeof(T) == 1 ? 4 : 3)) void k_inter_ctu(const InterArgs<T> *args, int n_ctu)
+// 4 workgroups per CU (97 / 116 VGPRs for 8 / 10 bit and no scratch since the fractional search runs two lanes per tile; LDS allows 4 at
+// 8 bit, 3 at 10 bit)
+template <typename T> __global__ __launch_bounds__(NT, 4) void k_inter_ctu(const InterArgs<T> *args, int n_ctu)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ctu = xcd_remap(blockIdx.x, n_ctu);

@@ -69,15 +69,24 @@ struct PreShared {
 };
 template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s, const PreArgs<T> &a, int ctu)
 {
-    constexpr int R = PRE_RANGE, span = PRE_SPAN, wh = 8 + 2 * R;
+    constexpr int R = PRE_RANGE, span = PRE_SPAN;
     const int lw = a.w >> 2, lh = a.h >> 2, wc = (lw + 7) >> 3, cx = ctu % wc, cy = ctu / wc;
     const int bw = lw - 8 * cx < 8 ? lw - 8 * cx : 8, bh = lh - 8 * cy < 8 ? lh - 8 * cy : 8;
     ex.phase([&](int tid) {
         if (tid < 64) { const int x = tid & 7, y = tid >> 3; s.blk[tid] = (x < bw && y < bh) ? a.lsrc[(8 * cy + y) * lw + 8 * cx + x] : (uint8_t)0; }
-        for (int i = tid; i < wh * PRE_WIN_W; i += NT) {
-            const int wx = i % PRE_WIN_W, wy = i / PRE_WIN_W;
-            const int x = clip3(0, lw - 1, 8 * cx + wx - R), y = clip3(0, lh - 1, 8 * cy + wy - R);
-            s.win[wy * PRE_WIN_STRIDE + wx] = a.lref[y * lw + x];
+        {   // the window: every lane's loads are issued before its first LDS store (this loop was a 95k-cycle chain of dependent loads)
+            constexpr int NW = (8 + 2 * PRE_RANGE) * PRE_WIN_W, IT = (NW + NT - 1) / NT;
+            uint8_t v[IT];
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                const int i = tid + k * NT;
+                if (i < NW) v[k] = a.lref[clip3(0, lh - 1, 8 * cy + i / PRE_WIN_W - R) * lw + clip3(0, lw - 1, 8 * cx + i % PRE_WIN_W - R)];
+            }
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                const int i = tid + k * NT;
+                if (i < NW) s.win[(i / PRE_WIN_W) * PRE_WIN_STRIDE + i % PRE_WIN_W] = v[k];
+            }
         }
         if (tid == 0) s.best = ~0ull;
     });
@@ -495,6 +504,124 @@ DEV int luma_tile(const uint16_t *win, int i00, int ws, int fx, int fy, int bit_
     return diff_src ? hadamard8_satd(acc) : 0;
 }
 
+// ---- fractional search, two lanes per (tile, candidate): each lane owns 4 of the tile's 8 columns.  The whole-tile form (luma_tile with a
+// source) kept 64 accumulators + filter state live and spilled at 4 workgroups per CU, and left half of the workgroup idle.
+// Difference (source - quarter-sample prediction, 8.5.3.3.3.1) of the 8 rows x 4 columns whose first integer sample is window element i00.
+DEV void luma_half_diff(const uint8_t *win, int i00, int ws, int fx, int fy, int, const uint8_t *src, int src_stride, int (&m)[8][4])
+{
+    const uint32_t tlo = load_u32(&g_tab.luma_tap[fx][0]), thi = load_u32(&g_tab.luma_tap[fx][4]);
+    uint32_t typ[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) typ[k] = pack_lo16(g_tab.luma_tap[fy][2 * k], g_tab.luma_tap[fy][2 * k + 1]);
+    int acc[8][4], prev[4];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+        const int idx = i00 + (r - 3) * ws - 3, off = idx & 3;
+        const uint8_t *p = win + (idx - off);
+        uint32_t d[4], q[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = load_u32_aligned(p + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 3; k++) q[k] = align_bytes(d[k + 1], d[k], off) ^ 0x80808080u;      // bytes 4k..4k+3 of the row, signed
+        int hv[4];
+        hv[0] = dot4_i8(q[0], tlo, dot4_i8(q[1], thi, 128 * 64));
+#pragma unroll
+        for (int i = 1; i < 4; i++) hv[i] = dot4_i8(align_bytes(q[1], q[0], i), tlo, dot4_i8(align_bytes(q[2], q[1], i), thi, 128 * 64));
+        if (r > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t pr = pack_lo16(prev[i], hv[i]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = r - 1 - 2 * k;
+                    if (j >= 0 && j < 8) acc[j][i] = dot2_i16(pr, typ[k], acc[j][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) prev[i] = hv[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t w = load_u32_aligned(src + j * src_stride);
+#pragma unroll
+        for (int i = 0; i < 4; i++) m[j][i] = (int)((w >> (8 * i)) & 255) - clip3(0, 255, ((acc[j][i] >> 6) + 32) >> 6);
+    }
+}
+DEV void luma_half_diff(const uint16_t *win, int i00, int ws, int fx, int fy, int bit_depth, const uint16_t *src, int src_stride, int (&m)[8][4])
+{
+    uint32_t txp[4], typ[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        txp[k] = pack_lo16(g_tab.luma_tap[fx][2 * k], g_tab.luma_tap[fx][2 * k + 1]);
+        typ[k] = pack_lo16(g_tab.luma_tap[fy][2 * k], g_tab.luma_tap[fy][2 * k + 1]);
+    }
+    const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1, off3 = 1 << (shift3 - 1);
+    int acc[8][4], prev[4];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+        const int idx = i00 + (r - 3) * ws - 3, off = idx & 1;
+        const uint16_t *p = win + (idx - off);
+        uint32_t d[7], e[6], o[5];
+#pragma unroll
+        for (int k = 0; k < 7; k++) d[k] = load_u32_aligned(p + 2 * k);
+#pragma unroll
+        for (int k = 0; k < 6; k++) e[k] = align_bytes(d[k + 1], d[k], 2 * off);     // samples (2k, 2k+1) of the row
+#pragma unroll
+        for (int k = 0; k < 5; k++) o[k] = align_bytes(e[k + 1], e[k], 2);           // samples (2k+1, 2k+2)
+        int hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v = dot2_i16((i & 1) ? o[(i >> 1) + k] : e[(i >> 1) + k], txp[k], v);
+            hv[i] = v >> shift1;
+        }
+        if (r > 0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t pr = pack_lo16(prev[i], hv[i]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = r - 1 - 2 * k;
+                    if (j >= 0 && j < 8) acc[j][i] = dot2_i16(pr, typ[k], acc[j][i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) prev[i] = hv[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) m[j][i] = (int)src[j * src_stride + i] - clip3(0, maxv, ((acc[j][i] >> 6) + off3) >> shift3);
+}
+// the half tile's share of the 8x8 Hadamard transform: all three vertical stages and the two horizontal stages inside its 4 columns;
+// the last horizontal stage pairs column c of the two halves (inter_ctu_program)
+DEV void hadamard_half(int (&m)[8][4])
+{
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+        for (int st = 1; st < 8; st <<= 1)
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (!(i & st)) { int p = m[i][x], q = m[i + st][x]; m[i][x] = p + q; m[i + st][x] = p - q; }
+#pragma unroll
+    for (int y = 0; y < 8; y++) {
+        const int p0 = m[y][0] + m[y][1], p1 = m[y][0] - m[y][1], p2 = m[y][2] + m[y][3], p3 = m[y][2] - m[y][3];
+        m[y][0] = p0 + p2; m[y][1] = p1 + p3; m[y][2] = p0 - p2; m[y][3] = p1 - p3;
+    }
+}
+
 // SATD of one 8x8 tile against the window at an INTEGER vector (both fractions zero: the prediction is the window itself)
 template <typename T> DEV int luma_tile_int(const T *win, int i00, int ws, const T *src, int src_stride)
 {
@@ -631,16 +758,45 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     // fractional refinement of the chosen CUs: half-pel ring, then quarter-pel ring (the centre's cost is known)
     for (int round = 0; round < 2; round++) {
         const int step = round == 0 ? 2 : 1;
-        ex.phase([&](int tid) {
-            for (int u = tid; u < 8 * 16; u += NT) {
-                int k = 1 + (u >> 4), t = u & 15;
-                if (!s.rs.tu_log2[t]) continue;
-                int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
-                int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
-                int px = x0 + txp * 8 + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
-                const int satd = luma_tile((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8), 32, (T *)nullptr, 0);
-                ex.atomic_add(&s.fsum[k - 1][node], (unsigned)satd);      // the CU's candidate sum, one LDS atomic per tile
+        // 16 tiles x 8 ring positions x 2 column halves = the whole workgroup.  Wave-local steps: both lanes of a pair sit in one wave.
+        ex.wave_step([&](int tid) {
+            const int u = tid >> 1, half = tid & 1, k = 1 + (u >> 4), t = u & 15;
+            if (!s.rs.tu_log2[t]) return;
+            const int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
+            const int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
+            const int px = x0 + txp * 8 + 4 * half + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
+            int m[8][4];
+            luma_half_diff((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8 + 4 * half), 32, m);
+            hadamard_half(m);
+            uint32_t *x = s.rs.scratch + tid * 16;       // |values| <= 32 x the sample range: they fit 16 bits
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const uint32_t o[4] = {pack_lo16(m[j][0], m[j][1]), pack_lo16(m[j][2], m[j][3]), pack_lo16(m[j + 1][0], m[j + 1][1]), pack_lo16(m[j + 1][2], m[j + 1][3])};
+                store_x4(x + 2 * j, o);
             }
+        });
+        ex.wave_step([&](int tid) {      // the last butterfly stage across the halves: this lane takes rows 4 half .. 4 half + 3
+            const int u = tid >> 1, half = tid & 1, t = u & 15;
+            if (!s.rs.tu_log2[t]) return;
+            const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16 + 8 * half, *xb = xa + 16;
+            unsigned sum = 0;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                uint32_t va[4], vb[4];
+                load_x4(xa + 4 * c, va); load_x4(xb + 4 * c, vb);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int a0 = (int)(int16_t)(va[i] & 0xffff), a1 = (int)(int16_t)(va[i] >> 16), b0 = (int)(int16_t)(vb[i] & 0xffff), b1 = (int)(int16_t)(vb[i] >> 16);
+                    sum += (unsigned)(iabs(a0 + b0) + iabs(a0 - b0) + iabs(a1 + b1) + iabs(a1 - b1));
+                }
+            }
+            s.rs.scratch[4096 + tid] = sum;
+        });
+        ex.phase([&](int tid) {
+            const int u = tid >> 1, k = 1 + (u >> 4), t = u & 15;
+            if ((tid & 1) || !s.rs.tu_log2[t]) return;
+            const unsigned satd = (s.rs.scratch[4096 + tid] + s.rs.scratch[4096 + tid + 1] + 2) >> 2;
+            ex.atomic_add(&s.fsum[k - 1][s.tile_node[t]], satd);      // the CU's candidate sum, one LDS atomic per tile
         });
         ex.phase([&](int tid) {
             if (tid >= 21 || !s.valid[tid] || !s.chosen[tid]) return;

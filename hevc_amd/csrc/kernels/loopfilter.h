@@ -112,6 +112,7 @@ struct SaoShared {
     // deblocked CTB + 1-sample halo, staged once with row-contiguous loads: every sample's 8 neighbours are then LDS reads
     uint16_t tile_y[34 * 36];
     uint16_t tile_c[2][18 * 20];
+    alignas(4) uint16_t src[1536];   // the source CTB (Y, U, V as in the CTU kernels), held as T samples
     // 16 private copies of the statistics (copy = lane & 15, odd stride -> distinct banks): neighbouring samples mostly
     // fall in the same category/band, and 64 lanes hitting one LDS word serialise (SQ_LDS_BANK_CONFLICT, r01 profiles)
     // count and difference sum share one word, (1 << 20) + (d + bias) per sample: half the LDS atomics.  A copy sees at most
@@ -162,12 +163,29 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
         int *z = &s.eo_n[0][0][0];
         for (int i = tid; i < 3 * (20 + 20 + 32 + 32); i += NT) z[i] = 0;
         for (int i = tid; i < 3 * 16 * 53; i += NT) (&s.priv[0][0][0])[i] = 0;
-        for (int i = tid; i < 34 * 34 + 2 * 18 * 18; i += NT) {
-            int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), k = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
-            int tx = k % dim, ty = k / dim, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
-            int gx = clip3(0, pw - 1, (pl ? cx * 16 : cx * 32) + tx - 1), gy = clip3(0, ph - 1, (pl ? cy * 16 : cy * 32) + ty - 1);
-            uint16_t v = (uint16_t)a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
-            if (pl) s.tile_c[pl - 1][ty * 20 + tx] = v; else s.tile_y[ty * 36 + tx] = v;
+        // deblocked CTB + halo and the source CTB: all of a lane's loads are issued before its first LDS store (one wait for memory per
+        // lane instead of one per sample: these two loops were 60k-cycle chains of dependent round trips, profiles/r02 phase table)
+        constexpr int NH = 34 * 34 + 2 * 18 * 18, ITH = (NH + NT - 1) / NT;
+        T hv[ITH];
+#pragma unroll
+        for (int k = 0; k < ITH; k++) {
+            const int i = tid + k * NT;
+            if (i < NH) {
+                int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), kk = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
+                int tx = kk % dim, ty = kk / dim, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
+                int gx = clip3(0, pw - 1, (pl ? cx * 16 : cx * 32) + tx - 1), gy = clip3(0, ph - 1, (pl ? cy * 16 : cy * 32) + ty - 1);
+                hv[k] = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+            }
+        }
+        load_ctu_source<T>((T *)s.src, a.src, cx * 32, cy * 32, a.w, a.h, tid);
+#pragma unroll
+        for (int k = 0; k < ITH; k++) {
+            const int i = tid + k * NT;
+            if (i < NH) {
+                int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), kk = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
+                int tx = kk % dim, ty = kk / dim;
+                if (pl) s.tile_c[pl - 1][ty * 20 + tx] = (uint16_t)hv[k]; else s.tile_y[ty * 36 + tx] = (uint16_t)hv[k];
+            }
         }
     });
     ex.phase([&](int tid) {
@@ -179,7 +197,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             const uint16_t *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
             const int ts = pl ? 20 : 36, ti = (y + 1) * ts + x + 1;
             int r = tp[ti];
-            int d = (int)a.src[pl].p[(ptrdiff_t)gy * a.src[pl].stride + gx] - r;
+            int d = (int)((const T *)s.src)[i] - r;
             int b = r >> (bd - 5);
             unsigned *pv = s.priv[pl][tid & 15];
             const unsigned one = (1u << 20) + (unsigned)(d + (1 << bd));      // count 1, sum d + bias
@@ -228,29 +246,34 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
     });
     ex.phase([&](int tid) {
         if (tid != 0) return;
-        // candidates per plane in fixed order: 0 off, 1 band (best of 29 positions), 2..5 edge classes
+        // candidates per plane in fixed order: 0 off, 1 band (best of 29 positions), 2..5 edge classes.  Every loop is unrolled so the
+        // small tables stay in registers (they were 160 bytes of scratch per lane in round 1)
         long long cost[3][6];
         int band[3];
+#pragma unroll
         for (int pl = 0; pl < 3; pl++) {
             band[pl] = (int)(s.band_key[pl] & 255);
             long long bestb = (long long)(s.band_key[pl] >> 8) - (1ll << 50);
             cost[pl][0] = 0;
             cost[pl][1] = bestb + (long long)lam * 7;
+#pragma unroll
             for (int c = 0; c < 4; c++) cost[pl][2 + c] = s.eo_cost[pl][c];
         }
         int bl = 0, bc = 0;
+        long long best_l = cost[0][0], best_c = cost[1][0] + cost[2][0];
+#pragma unroll
         for (int k = 1; k < 6; k++) {
-            if (cost[0][k] < cost[0][bl]) bl = k;
-            if (cost[1][k] + cost[2][k] < cost[1][bc] + cost[2][bc]) bc = k;
+            if (cost[0][k] < best_l) { best_l = cost[0][k]; bl = k; }
+            if (cost[1][k] + cost[2][k] < best_c) { best_c = cost[1][k] + cost[2][k]; bc = k; }
         }
-        mihevc_sao_ctu o;
-        for (unsigned i = 0; i < sizeof o; i++) ((uint8_t *)&o)[i] = 0;
-        const int sel[3] = {bl, bc, bc};
+        mihevc_sao_ctu o = {};
+#pragma unroll
         for (int pl = 0; pl < 3; pl++) {
-            int k = sel[pl], type = k == 0 ? 0 : k == 1 ? 1 : 2;
+            const int k = pl == 0 ? bl : bc, type = k == 0 ? 0 : k == 1 ? 1 : 2;
             if (pl < 2) { o.type[pl] = (uint8_t)type; o.eo_class[pl] = (uint8_t)(type == 2 ? k - 2 : 0); }
             o.band_pos[pl] = (uint8_t)(type == 1 ? band[pl] : 0);
-            for (int i = 0; i < 4; i++) o.offset[pl][i] = type == 1 ? s.bo_off[pl][band[pl] + i] : type == 2 ? s.eo_off[pl][k - 2][i] : 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) o.offset[pl][i] = type == 1 ? s.bo_off[pl][band[pl] + i] : type == 2 ? s.eo_off[pl][k == 0 ? 0 : k < 2 ? 0 : k - 2][i] : (int8_t)0;
         }
         a.sao[ctu] = o;
     });

@@ -20,11 +20,16 @@ struct ResidualShared {
     // read consecutive dwords: mp[off + p*n + u] = (M[u][2p], M[u][2p+1]),  mq[off + p*n + y] = (M[2p][y], M[2p+1][y])
     alignas(16) uint32_t mp[680];
     alignas(16) uint32_t mq[680];
+    union {
+    struct {
     alignas(16) int16_t res[1536];         // residual in, reconstructed residual out
     alignas(16) int16_t tmp[1536];         // stage intermediates, row-pair interleaved: element (r, c) at (r & ~1) * stride + 2c + (r & 1)
     alignas(16) int16_t coef[1536];        // transform coefficients / inverse stage-1 output (natural layout)
     alignas(16) int16_t lvl[1536];         // quantised levels (TU-local raster at CTU coordinates)
     uint32_t desc[1536];       // per sample: TU geometry, written by the caller while it forms the residual
+    };
+    alignas(16) uint32_t scratch[4608];    // the same 18 KB for a caller's own use while no residual is in flight (k_inter_ctu: fractional search)
+    };
     uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
     uint8_t tu_intra[16];      // per tile: 1 = intra rounding
     unsigned cbf[3];           // bit t set: tile t's TU has a non-zero level in that plane (all tiles of a TU set the TU's first tile bit)

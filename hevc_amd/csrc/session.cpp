@@ -486,7 +486,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     HIPCK(s, hipEventCreate(&t_begin)); HIPCK(s, hipEventCreate(&t_end));
     HIPCK(s, hipEventRecord(t_begin, s->st_compute));
     auto mark = [&](int stage, int pictures, bool begin) -> int {       // bracket a stage with events when profiling
-        if (!s->cfg.profile_stages) return 0;
+        if (!s->cfg.profile_stages || (s->cfg.profile_stages == 2 && stage != 2)) return 0;      // 2: the dominant stage (inter_ctu) only
         size_t need_ev = s->marks.size() * 2 + 2;
         while (s->ev_pool.size() < need_ev) { hipEvent_t e; HIPCK(s, hipEventCreate(&e)); s->ev_pool.push_back(e); }
         if (begin) { s->marks.push_back({stage, pictures, s->marks.size() * 2}); HIPCK(s, hipEventRecord(s->ev_pool[s->marks.back().ev], s->st_compute)); }
