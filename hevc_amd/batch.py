@@ -7,11 +7,19 @@ on completion, a CSV log rewritten after every finished file with the six refere
 workers (gui/mainwindow.py:303-308) — queued files keep starting, as in the reference.
 New: GPU affinity.  Worker k is pinned to MI355X ordinal `k % n_devices`, so a batch shards one clip per GPU across
 the node with no collective (BASELINE.json configs[3]).  Extra CSV columns follow the six.
+
+One PROCESS per worker when the real `convert_video` drives MI355X devices (one process per GPU): at ~3000 fps per device
+the per-frame Python of eight clips would queue on one interpreter lock, and a fault in one device's runtime must not take the other
+seven clips down.  The workers are spawned (never forked: the parent may already hold a GPU context), take files from the parent one at
+a time and send progress / results back over a queue; the parent keeps the FIFO, the CSV and the callbacks.  With an injected `convert`
+(tests) or no device the workers are threads, as in round 1.
 """
 from __future__ import annotations
 
 import csv
+import importlib
 import logging
+import multiprocessing as mp
 import threading
 import time
 from collections import deque
@@ -33,11 +41,40 @@ def scan_inputs(input_dir: Path) -> List[Path]:
     return sorted(p for p in Path(input_dir).rglob('*') if p.is_file() and p.suffix.lower() in INPUT_EXTS)
 
 
+def _proc_worker(slot, device, task_q, result_q, stop_ev, out_dir, kw, convert_ref):
+    """Body of one worker process: files arrive one at a time from the parent; progress is throttled to ~10 messages a second."""
+    mod, name = convert_ref
+    convert = getattr(importlib.import_module(mod), name)
+    while True:
+        f = task_q.get()
+        if f is None:
+            return
+        stop_ev.clear()                      # a stop signalled while this worker was idle concerned the previous file
+        last = [0.0]
+
+        def progress(fname, frame, total):
+            now = time.time()
+            if frame >= total or now - last[0] > 0.1:
+                last[0] = now
+                result_q.put(('progress', slot, fname, frame, total))
+        t0 = time.time()
+        try:
+            k = dict(kw)
+            if device is not None:
+                k['device'] = device
+            res = dict(convert(Path(f), Path(out_dir), progress_callback=progress, stop_event=stop_ev, **k))
+        except Exception as exc:             # gui/worker.py:43-52: last-resort FAILED/UNKNOWN result
+            res = {'file': Path(f).name, 'status': 'FAILED', 'quality': None, 'retries': 0, 'method': 'UNKNOWN', 'hdr': False, 'error': str(exc)}
+        res['seconds'] = round(time.time() - t0, 3)
+        res['device'] = device if res.get('method') == 'MI355X' else ''
+        result_q.put(('done', slot, res))
+
+
 class BatchRunner:
     def __init__(self, files: List[Path], out_dir: Path, max_workers: Optional[int] = None, debug=False, skip_validator=False,
                  force_cpu=False, force_gpu=False, csv_path: Optional[Path] = None,
                  on_progress: Optional[Callable[[str, int, int], None]] = None, on_finished: Optional[Callable[[Dict], None]] = None,
-                 convert=convert_video, n_devices: Optional[int] = None):
+                 convert=convert_video, n_devices: Optional[int] = None, use_processes: Optional[bool] = None):
         self.queue = deque(Path(f) for f in files)
         self.out_dir = Path(out_dir)
         self.n_devices = mi355x_device_count() if n_devices is None else n_devices
@@ -45,10 +82,73 @@ class BatchRunner:
         self.kw = dict(debug=debug, skip_validator=skip_validator, force_cpu=force_cpu, force_gpu=force_gpu)
         self.csv_path = Path(csv_path) if csv_path else self.out_dir / 'transcode_log.csv'
         self.on_progress, self.on_finished, self.convert = on_progress, on_finished, convert
+        self.use_processes = (convert is convert_video and self.n_devices > 0) if use_processes is None else bool(use_processes)
         self.results: List[Dict] = []
         self._lock = threading.Lock()
         self._active: Dict[int, threading.Event] = {}
         self._threads: List[threading.Thread] = []
+        self._procs: list = []
+
+    # -- process mode: one spawned process per worker slot, the parent dispatches
+    def _start_processes(self, n: int):
+        ctx = mp.get_context('spawn')
+        self._result_q = ctx.Queue()
+        self._task_q = [ctx.Queue() for _ in range(n)]
+        self._stop_ev = [ctx.Event() for _ in range(n)]
+        ref = (self.convert.__module__, self.convert.__name__)
+        for k in range(n):
+            device = k % self.n_devices if self.n_devices else None
+            p = ctx.Process(target=_proc_worker, args=(k, device, self._task_q[k], self._result_q, self._stop_ev[k], str(self.out_dir), self.kw, ref), daemon=True)
+            p.start()
+            self._procs.append(p)
+        t = threading.Thread(target=self._dispatch, args=(n,), daemon=True)
+        self._threads.append(t)
+        t.start()
+
+    def _dispatch(self, n: int):
+        busy = 0
+        with self._lock:
+            for k in range(n):
+                if self.queue:
+                    self._task_q[k].put(str(self.queue.popleft()))
+                    self._active[k] = self._stop_ev[k]
+                    busy += 1
+                else:
+                    self._task_q[k].put(None)
+        while busy:
+            try:
+                msg = self._result_q.get(timeout=1.0)
+            except Exception:
+                dead = [k for k, p in enumerate(self._procs) if not p.is_alive() and k in self._active]
+                for k in dead:               # a worker process that died takes its file with it: FAILED/UNKNOWN, like a raised exception
+                    with self._lock:
+                        self._active.pop(k, None)
+                        self.results.append({'file': '?', 'status': 'FAILED', 'quality': None, 'retries': 0, 'method': 'UNKNOWN', 'hdr': False,
+                                             'seconds': '', 'device': ''})
+                        self.save_csv()
+                    busy -= 1
+                continue
+            if msg[0] == 'progress':
+                if self.on_progress:
+                    try:
+                        self.on_progress(msg[2], msg[3], msg[4])
+                    except Exception:
+                        logger.debug('on_progress raised', exc_info=True)
+                continue
+            _, k, res = msg
+            with self._lock:
+                self.results.append(res)
+                self.save_csv()
+                nxt = self.queue.popleft() if self.queue else None
+                if nxt is None:
+                    self._active.pop(k, None)
+                    busy -= 1
+            self._task_q[k].put(str(nxt) if nxt is not None else None)
+            if self.on_finished:
+                try:
+                    self.on_finished(res)
+                except Exception:
+                    logger.debug('on_finished raised', exc_info=True)
 
     # -- reference: MainWindow.start_batch / _start_next_worker / on_finished
     def _worker(self, slot: int):
@@ -85,6 +185,9 @@ class BatchRunner:
     def start(self):
         self.out_dir.mkdir(parents=True, exist_ok=True)
         n = min(self.max_workers, len(self.queue))
+        if self.use_processes and n:
+            self._start_processes(n)
+            return self
         for k in range(n):
             t = threading.Thread(target=self._worker, args=(k,), daemon=True)
             self._threads.append(t)
@@ -102,6 +205,8 @@ class BatchRunner:
     def wait(self) -> List[Dict]:
         for t in self._threads:
             t.join()
+        for p in self._procs:
+            p.join(timeout=10)
         return self.results
 
     def save_csv(self):

@@ -29,6 +29,12 @@ _COLOUR_CODES = {  # ffprobe names -> H.265 Table E.3/E.4/E.5 code points
 }
 
 
+def bit_depth_of(info: VideoInfo) -> int:
+    """10 for 10-bit sample formats (yuv420p10le, p010le, ...) and for anything probed as HDR, else 8."""
+    fmt = (info.pix_fmt or '').lower()
+    return 10 if (info.hdr or '10' in fmt) else 8
+
+
 def config_for(info: VideoInfo, crf: int, vbv_maxrate: int, vbv_bufsize: int, gop: int, level: str, tier: str,
                master_display: str = "", max_cll: str = "") -> _lib.Config:
     """Map the reference's libx265 operating point (build_ffmpeg_params CPU branch) onto a mihevc_config."""
@@ -38,7 +44,8 @@ def config_for(info: VideoInfo, crf: int, vbv_maxrate: int, vbv_bufsize: int, go
     fr = Fraction(str(info.fps or 30.0)).limit_denominator(1001)
     cfg.fps_num, cfg.fps_den = fr.numerator, fr.denominator
     hdr = bool(info.hdr)
-    cfg.bit_depth = 10 if hdr else 8
+    # bit depth follows the SAMPLE format, not the HDR vote: a 10-bit SDR source is coded Main10 without the HDR10 SEI set
+    cfg.bit_depth = bit_depth_of(info)
     cfg.level_idc = int(round(float(level) * 30))
     cfg.tier = 1 if tier == "high" else 0
     cfg.crf, cfg.qp = int(crf), -1
@@ -93,8 +100,15 @@ class Encoder:
 
     # -- data path
     def send(self, y: np.ndarray, u: np.ndarray, v: np.ndarray, pts: Optional[int] = None):
-        """Planes as uint8 (8 bit) or uint16 (10 bit) arrays of the DISPLAY size."""
-        dt = np.uint8 if self.cfg.bit_depth == 8 else np.uint16
+        """Planes as uint8 (8 bit) or uint16 (10 bit) arrays of the DISPLAY size.  Shape and sample width are checked here: the C ABI takes
+        plain pointers, so a short plane would be read past its end and 10-bit samples handed to an 8-bit session would wrap modulo 256."""
+        c = self.cfg
+        dt = np.uint8 if c.bit_depth == 8 else np.uint16
+        if y.shape != (c.height, c.width) or u.shape != (c.height // 2, c.width // 2) or v.shape != u.shape:
+            raise ValueError(f"plane shapes {y.shape}/{u.shape}/{v.shape} do not match the session's {c.width}x{c.height} 4:2:0")
+        for p in (y, u, v):
+            if p.dtype.itemsize > np.dtype(dt).itemsize:
+                raise ValueError(f"{p.dtype} samples handed to a {c.bit_depth}-bit session (open it with bit_depth 10 or down-convert first)")
         y, u, v = (np.ascontiguousarray(p, dtype=dt) for p in (y, u, v))
         pts = self._pts if pts is None else pts
         self._pts = pts + 1
@@ -173,6 +187,7 @@ class ShardedEncoder:
         for t in self._threads:
             t.start()
         self._n_in, self._next_out = 0, 0
+        self._aborted = False
 
     def _worker(self, k):
         enc, q = self._encs[k], self._q[k]
@@ -184,8 +199,9 @@ class ShardedEncoder:
                 y, u, v, pts = item
                 enc.send(y, u, v, pts=pts)          # ctypes releases the GIL: the sessions run concurrently
                 self._collect(enc)
-            enc.flush()
-            self._collect(enc)
+            if not self._aborted:
+                enc.flush()
+                self._collect(enc)
         except Exception as exc:                    # surfaced by send()/finish() on the caller's thread
             self._err.append(exc)
 
@@ -197,10 +213,16 @@ class ShardedEncoder:
                     self._out[pts] = (data, key)
 
     def send(self, y, u, v):
-        if self._err:
-            raise self._err[0]
+        import queue
         k = (self._n_in // self.chunk) % len(self.devices)
-        self._q[k].put((y, u, v, self._n_in))
+        while True:                                 # a bounded queue whose worker has died must not block the caller for ever
+            if self._err:
+                raise self._err[0]
+            try:
+                self._q[k].put((y, u, v, self._n_in), timeout=0.2)
+                break
+            except queue.Full:
+                continue
         self._n_in += 1
 
     def ready(self):
@@ -213,14 +235,35 @@ class ShardedEncoder:
                 self._next_out += 1
         return out
 
-    def finish(self):
-        for q in self._q:
-            q.put(None)
+    def _stop_workers(self, drain: bool):
+        """Hand every worker its sentinel and join it; drain=True first throws away what is still queued (abort)."""
+        import queue
+        for q, t in zip(self._q, self._threads):
+            while t.is_alive():
+                if drain:
+                    try:
+                        while True:
+                            q.get_nowait()
+                    except queue.Empty:
+                        pass
+                try:
+                    q.put(None, timeout=0.2)
+                    break
+                except queue.Full:
+                    continue
         for t in self._threads:
             t.join()
+
+    def finish(self):
+        self._stop_workers(drain=False)
         if self._err:
             raise self._err[0]
         return self.ready()
+
+    def abort(self):
+        """Cancel / failure path: no session may be closed while its worker can still be inside a native call."""
+        self._aborted = True
+        self._stop_workers(drain=True)
 
     def headers(self) -> bytes:
         return self._encs[0].headers()
@@ -229,8 +272,30 @@ class ShardedEncoder:
         return [e.stats() for e in self._encs]
 
     def close(self):
+        if any(t.is_alive() for t in self._threads):
+            self.abort()
         for e in self._encs:
             e.close()
+
+
+def remux_audio(video_mp4: Path, source: Path, out_path: Path, info: VideoInfo) -> bool:
+    """The native path writes video only; the reference always carries the source's audio as AAC (core/transcoder.py:423-450,480-489).
+    When the source has audio (only container inputs can, and those need ffmpeg to be decoded at all) the video track is copied and the
+    audio encoded with the reference's own flags.  False when ffmpeg is missing or fails: the caller then falls down the ladder."""
+    import shutil
+    import subprocess
+    from .transcoder import VIDEO_METADATA_FLAGS, get_audio_flags
+    if shutil.which('ffmpeg') is None:
+        return False
+    cmd = ['ffmpeg', '-hide_banner', '-y', '-i', str(video_mp4), '-i', str(source), '-map', '0:v:0', '-map', '1:a:0?', '-map_metadata', '1',
+           '-c:v', 'copy', '-tag:v', 'hvc1'] + VIDEO_METADATA_FLAGS
+    for kv in ('handler_name=SoundHandler', f'language={info.audio_language or "eng"}', 'title="Main Audio"'):
+        cmd += ['-metadata:s:a:0', kv]
+    cmd += get_audio_flags(info.audio_channels) + ['-brand', 'mp42', '-movflags', '+write_colr+use_metadata_tags+faststart', str(out_path)]
+    try:
+        return subprocess.run(cmd, capture_output=True).returncode == 0 and Path(out_path).exists()
+    except Exception:
+        return False
 
 
 def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callback: Optional[Callable[[str, int, int], None]] = None,
@@ -241,63 +306,78 @@ def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callb
     from . import mp4, yuvio
     from .transcoder import calculate_apple_hevc_level, calculate_dynamic_values
 
-    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info)
     level, tier = calculate_apple_hevc_level(info)
-    cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
     clip = yuvio.open_any(Path(file_path), info)
+    mux = None
+    ok = False
     try:
+        if clip.bit_depth > 8 and bit_depth_of(info) == 8:      # the file's own header outranks the probe (a y4m tagged C420p10 probed as SDR)
+            info.pix_fmt = 'yuv420p10le'
+        cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
         total = clip.n_frames or total_frames
-        mux = mp4.Mp4Writer(Path(out_path), cfg)
-        if devices and len(devices) > 1:            # one clip over several GPUs, GOP chunks round-robin
-            sh = ShardedEncoder(cfg, devices)
-            n_out = 0
-            try:
-                def drain(pkts):
-                    nonlocal n_out
-                    for data, pts, key in pkts:
-                        mux.add_sample(data, pts, key)
-                        n_out += 1
-                    if pkts and progress_callback:
-                        try:
-                            progress_callback(Path(file_path).name, n_out, total)
-                        except Exception:
-                            logger.debug("progress_callback raised", exc_info=True)
-                for y, u, v in clip.frames():
-                    if stop_event is not None and stop_event.is_set():
-                        mux.abort()
-                        return 1
-                    sh.send(y, u, v)
-                    drain(sh.ready())
-                drain(sh.finish())
-                mux.finish(sh.headers())
-            finally:
-                sh.close()
-            return 0 if n_out > 0 else 1
-        with Encoder(cfg, device=device or 0) as enc:
-            n_out = 0
-            for i, (y, u, v) in enumerate(clip.frames()):
-                if stop_event is not None and stop_event.is_set():
-                    mux.abort()
-                    return 1
-                enc.send(y, u, v, pts=i)
-                for data, pts, key in enc.packets():
-                    mux.add_sample(data, pts, key)
-                    n_out += 1
-                if progress_callback:
-                    try:
-                        progress_callback(Path(file_path).name, n_out, total)
-                    except Exception:
-                        logger.debug("progress_callback raised", exc_info=True)
-            enc.flush()
-            for data, pts, key in enc.packets():
-                mux.add_sample(data, pts, key)
-                n_out += 1
+        wants_audio = bool(info.audio_channels and info.audio_channels > 0) and Path(file_path).suffix.lower() not in ('.y4m', '.yuv')
+        video_path = Path(out_path).with_suffix('.video.mp4') if wants_audio else Path(out_path)
+        mux = mp4.Mp4Writer(video_path, cfg)
+        n_out = 0
+
+        def progress():
             if progress_callback:
                 try:
                     progress_callback(Path(file_path).name, n_out, total)
                 except Exception:
                     logger.debug("progress_callback raised", exc_info=True)
-            mux.finish(enc.headers())
-        return 0 if n_out > 0 else 1
+
+        if devices and len(devices) > 1:            # one clip over several GPUs, GOP chunks round-robin
+            sh = ShardedEncoder(cfg, devices)
+            try:
+                for y, u, v in clip.frames():
+                    if stop_event is not None and stop_event.is_set():
+                        return 1
+                    sh.send(y, u, v)
+                    for data, pts, key in sh.ready():
+                        mux.add_sample(data, pts, key)
+                        n_out += 1
+                    progress()
+                for data, pts, key in sh.finish():
+                    mux.add_sample(data, pts, key)
+                    n_out += 1
+                progress()
+                headers = sh.headers()
+            finally:
+                sh.close()                          # joins the workers (abort) before any session is closed
+        else:
+            with Encoder(cfg, device=device or 0) as enc:
+                for i, (y, u, v) in enumerate(clip.frames()):
+                    if stop_event is not None and stop_event.is_set():
+                        return 1
+                    enc.send(y, u, v, pts=i)
+                    for data, pts, key in enc.packets():
+                        mux.add_sample(data, pts, key)
+                        n_out += 1
+                    progress()
+                enc.flush()
+                for data, pts, key in enc.packets():
+                    mux.add_sample(data, pts, key)
+                    n_out += 1
+                progress()
+                headers = enc.headers()
+        if n_out == 0:
+            return 1
+        mux.finish(headers)
+        mux = None
+        if wants_audio:
+            good = remux_audio(video_path, Path(file_path), Path(out_path), info)
+            try:
+                video_path.unlink()
+            except OSError:
+                pass
+            if not good:
+                logger.warning("%s: audio could not be carried over (ffmpeg remux failed); falling back to the ffmpeg path", Path(file_path).name)
+                return 1
+        ok = True
+        return 0
     finally:
+        if mux is not None and not ok:
+            mux.abort()                             # cancel, failure or exception: no .mdat.tmp and no open handle stay behind
         clip.close()

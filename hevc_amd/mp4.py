@@ -130,8 +130,14 @@ class Mp4Writer:
         stsc = full_box(b'stsc', 0, 0, struct.pack('>IIII', 1, 1, n, 1))
         stsz = full_box(b'stsz', 0, 0, struct.pack('>II', 0, n), b''.join(struct.pack('>I', s) for s in self._sizes))
 
+        payload = sum(self._sizes)
+        big_mdat = payload + 8 >= 1 << 32
+        head = 16 if big_mdat else 8
+        # the chunk offset is ftyp + moov + mdat header: 64-bit (co64) exactly when the file needs a 64-bit mdat or moov alone could reach
+        # 4 GiB — decided ONCE, before moov is sized (sizing moov with stco and then switching to co64 left the offset 4 bytes short)
+        big = big_mdat or 4 * len(self._sizes) + (1 << 16) >= 1 << 32
+
         def moov_with(chunk_offset: int) -> bytes:
-            big = chunk_offset >= 1 << 32
             stco = full_box(b'co64' if big else b'stco', 0, 0, struct.pack('>I', 1), struct.pack('>Q' if big else '>I', chunk_offset))
             stbl = box(b'stbl', self._stsd(headers), stts, stss, stsc, stsz, stco)
             minf = box(b'minf', full_box(b'vmhd', 0, 1, b'\0' * 8), box(b'dinf', full_box(b'dref', 0, 0, struct.pack('>I', 1), full_box(b'url ', 0, 1))), stbl)
@@ -143,11 +149,12 @@ class Mp4Writer:
                             struct.pack('>I', 2))
             return box(b'moov', mvhd, box(b'trak', tkhd, mdia))
 
-        payload = sum(self._sizes)
-        big_mdat = payload + 8 >= 1 << 32
-        head = 16 if big_mdat else 8
         moov = moov_with(0)
-        moov = moov_with(len(ftyp) + len(moov) + head)        # box sizes do not depend on the offset value (< 4 GiB case)
+        moov = moov_with(len(ftyp) + len(moov) + head)        # box sizes do not depend on the offset VALUE once its width is fixed
+        self.layout = {'co64': big, 'big_mdat': big_mdat, 'chunk_offset': len(ftyp) + len(moov) + head}
+        if getattr(self, 'dry_run', False):                   # tests: layout decisions for sizes that cannot be written for real
+            self._moov = moov
+            return
         with open(self.path, 'wb') as out, open(self._tmp, 'rb') as src:
             out.write(ftyp)
             out.write(moov)

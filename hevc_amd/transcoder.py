@@ -37,7 +37,7 @@ from pathlib import Path
 from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple
 
 from .probe import VideoInfo, probe_media
-from .utils import build_hdr_metadata, detect_gpu_type, has_mi355x, has_nvenc
+from .utils import build_hdr_metadata, has_mi355x
 
 logger = logging.getLogger(__name__)
 
@@ -111,22 +111,6 @@ def calculate_apple_hevc_level(info: VideoInfo) -> Tuple[str, str]:
 def level_idc(level: str) -> int:
     """'4' -> 120, '3.1' -> 93 (general_level_idc = 30 * level)."""
     return int(round(float(level) * 30))
-
-
-def calculate_nvenc_hevc_level(info: VideoInfo) -> Tuple[str, str, str, str]:
-    """(level, tier, profile, pix_fmt) of the reference's NVENC branch (core/transcoder.py:189-209).
-    Only the *shape* of that branch survives here; no NVENC code path is built."""
-    longest = max(info.width, info.height)
-    level = '4.0' if longest <= 1920 else '4.1' if longest <= 2560 else '5.1' if longest <= 3840 else '5.2'
-    if info.hdr:
-        return level, 'high', 'main10', 'p010le'
-    return level, 'main', 'main', 'yuv420p'
-
-
-def select_nvenc_preset(info: VideoInfo, gpu_name: str) -> str:
-    longest = max(info.width, info.height)
-    step = 2 if longest >= 3840 else 1 if longest >= 2560 else 0
-    return f'p{(5 if info.hdr else 4) + step}'
 
 
 # ---------------------------------------------------------------------------------------------
@@ -218,85 +202,19 @@ def calculate_dynamic_values(info: VideoInfo, use_nvenc: bool = True, gpu_name: 
     return crf, crf + 1, maxrate, bufsize, gop
 
 
-# ---------------------------------------------------------------------------------------------
-# NVENC retry ladder (shape only; reused as the template for the MI355X -> libx265 fallback)
-# ---------------------------------------------------------------------------------------------
-NVENC_RETRIES = [
-    {'-bf': '3', '-b_ref_mode': 'middle'},
-    {'-bf': '0', '-b_ref_mode': 'disabled'},
-    {'-bf': '0', '-b_ref_mode': 'disabled', '-temporal-aq': '0'},
-    {'-bf': '0', '-b_ref_mode': 'disabled', '-temporal-aq': '0', '-spatial-aq': '0'},
-]
-
-
-def adjust_nvenc_params(params: List[str], attempt: int) -> List[str]:
-    """Overlay retry step `attempt` (1-based, saturating) on a flat `-key value` list."""
-    if attempt <= 0:
-        return list(params)
-    overlay = NVENC_RETRIES[min(attempt, len(NVENC_RETRIES)) - 1]
-    table: Dict[str, str] = {}
-    it = iter(range(len(params)))
-    for i in it:
-        key = params[i]
-        if i + 1 < len(params) and not params[i + 1].startswith('-'):
-            table[key] = params[i + 1]
-            next(it, None)
-        else:
-            table[key] = ''
-    table.update(overlay)
-    flat: List[str] = []
-    for key, val in table.items():
-        flat.append(key)
-        if val not in (None, ''):
-            flat.append(str(val))
-    return flat
-
-
-def ensure_bitstream_headers(vparams: List[str], encoder: str = 'x265', ensure_repeat=True, ensure_aud=True,
-                             ensure_chromaloc=True) -> List[str]:
-    """Append `-aud 1` (and `-chromaloc 0` for x265) when absent (core/transcoder.py:136-155)."""
-    joined = ' '.join(map(str, vparams))
-    out = list(vparams)
-    if ensure_aud and 'aud=1' not in joined and '-aud' not in joined:
-        out += ['-aud', '1']
-    if ensure_chromaloc and encoder.lower() == 'x265' and 'chromaloc' not in joined:
-        out += ['-chromaloc', '0']
-    return out
-
-
-def build_ffmpeg_params(info: VideoInfo, use_nvenc: bool, gpu_name: str) -> FFmpegParams:
-    """Encoder operating point for one file (core/transcoder.py:357-412)."""
+def build_ffmpeg_params(info: VideoInfo, use_nvenc: bool = False, gpu_name: str = '') -> FFmpegParams:
+    """libx265 operating point for one file (core/transcoder.py:357-412, CPU branch).  The reference's hevc_nvenc branch is out of
+    scope here: `use_nvenc` / `gpu_name` keep the reference's positional signature and are ignored."""
     hdr = bool(info.hdr)
-    if use_nvenc:
-        level, tier, profile, pix_fmt = calculate_nvenc_hevc_level(info)
-    else:
-        level, tier = calculate_apple_hevc_level(info)
-        profile, pix_fmt = ('main10', 'p010le') if hdr else ('main', 'yuv420p')
-    crf, cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc, gpu_name)
-
-    if not use_nvenc:
-        fields = [f'crf={crf}', 'preset=slow', 'log-level=error', 'nal-hrd=vbr', f'vbv-maxrate={maxrate}',
-                  f'vbv-bufsize={bufsize}', f'tier={tier}', f'keyint={gop}', f'min-keyint={max(2, gop // 2)}',
-                  f'profile={profile}', f'level-idc={level}']
-        if hdr:
-            fields += build_hdr_metadata(info.master_display, info.max_cll, use_nvenc=False, fps=info.fps)[1].split(':')
-        return FFmpegParams('libx265', pix_fmt, profile, level, [], ['-x265-params', ':'.join(fields), '-threads', '0'], [])
-
-    longest = max(info.width, info.height)
-    lookahead: Any = int(min(info.fps * 1.5, 120))
-    aq = 6
-    if hdr and longest >= 3840:
-        aq, lookahead = 7, min(info.fps * 2, 120)        # stays a float in the reference ("60.0")
-    if hdr and longest >= 7680:
-        aq, lookahead = 8, 120
-    vparams = ['-rc', 'vbr', '-tune', 'hq', '-multipass', 'fullres', '-cq', str(cq), '-b:v', '0',
-               '-maxrate', str(maxrate * 1000), '-bufsize', str(bufsize * 1000),
-               '-bf', '3', '-b_ref_mode', 'middle', '-rc-lookahead', str(lookahead),
-               '-spatial-aq', '1', '-aq-strength', str(aq), '-temporal-aq', '1',
-               '-preset', select_nvenc_preset(info, gpu_name), '-no-scenecut', '1', '-g', str(gop), '-tier', tier]
-    vparams = ensure_bitstream_headers(vparams, encoder='nvenc')
-    meta = build_hdr_metadata(info.master_display, info.max_cll, use_nvenc=True, fps=info.fps) if hdr else []
-    return FFmpegParams('hevc_nvenc', pix_fmt, profile, level, [], vparams, meta)
+    level, tier = calculate_apple_hevc_level(info)
+    profile, pix_fmt = ('main10', 'p010le') if hdr else ('main', 'yuv420p')
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info)
+    fields = [f'crf={crf}', 'preset=slow', 'log-level=error', 'nal-hrd=vbr', f'vbv-maxrate={maxrate}',
+              f'vbv-bufsize={bufsize}', f'tier={tier}', f'keyint={gop}', f'min-keyint={max(2, gop // 2)}',
+              f'profile={profile}', f'level-idc={level}']
+    if hdr:
+        fields += build_hdr_metadata(info.master_display, info.max_cll, use_nvenc=False, fps=info.fps)[1].split(':')
+    return FFmpegParams('libx265', pix_fmt, profile, level, [], ['-x265-params', ':'.join(fields), '-threads', '0'], [])
 
 
 # ---------------------------------------------------------------------------------------------
@@ -408,16 +326,11 @@ def run_apple_validator(file_path: Path, refresh_cache=False) -> bool:
 # encoder choice
 # ---------------------------------------------------------------------------------------------
 def choose_backend(info: Optional[VideoInfo], force_cpu: bool, force_gpu: bool) -> str:
-    """'CPU' | 'MI355X' | 'NVENC'.  force_cpu wins; otherwise a present MI355X is preferred, then
-    NVENC (reference behaviour), else CPU.  force_gpu with no GPU encoder silently yields 'CPU',
-    as in the reference (core/transcoder.py:70-75)."""
+    """'CPU' | 'MI355X'.  force_cpu wins; otherwise a present MI355X is used, else the CPU (libx265 through ffmpeg).  force_gpu with
+    no GPU encoder silently yields 'CPU', as in the reference (core/transcoder.py:70-75)."""
     if force_cpu:
         return 'CPU'
-    if has_mi355x():
-        return 'MI355X'
-    if has_nvenc():
-        return 'NVENC'
-    return 'CPU'
+    return 'MI355X' if has_mi355x() else 'CPU'
 
 
 def decide_encoder(info: Optional[VideoInfo], force_cpu: bool, force_gpu: bool) -> bool:
@@ -435,18 +348,16 @@ def convert_video(file_path: Path, out_dir: Path, progress_callback: ProgressCb 
     """Transcode one file to `out_dir/<stem>.mp4`; never raises for encode failures.
 
     Returns {"file","status","quality","retries","method","hdr"} — the six CSV columns of the
-    reference (gui/mainwindow.py:351).  `method` is the path that produced the file: 'MI355X',
-    'NVENC' or 'CPU'.  `device` (new, optional) pins the MI355X ordinal for the batch scheduler; `devices`
+    reference (gui/mainwindow.py:351).  `method` is the path that produced the file: 'MI355X'
+    or 'CPU'.  `device` (new, optional) pins the MI355X ordinal for the batch scheduler; `devices`
     (new, optional) spreads ONE clip over several MI355X, GOP chunks round-robin (hevc_amd.encoder.ShardedEncoder)."""
     file_path, out_dir = Path(file_path), Path(out_dir)
     info = probe_media(file_path)
-    gpu_name = detect_gpu_type()
     out_path = out_dir / (file_path.stem + '.mp4')
     backend = choose_backend(info, force_cpu, force_gpu)
     result: Dict[str, Any] = {'file': file_path.name, 'status': 'FAILED', 'quality': None, 'retries': 0,
                               'method': backend, 'hdr': info.hdr}
-    crf, _cq, _, _, _ = calculate_dynamic_values(info, use_nvenc=False)
-    _, nvenc_cq, _, _, _ = calculate_dynamic_values(info, use_nvenc=True, gpu_name=gpu_name)
+    crf, _cq, _, _, _ = calculate_dynamic_values(info)
     total_frames = max(1, int(info.duration * info.fps)) if info.duration and info.fps else 1
 
     if backend == 'MI355X':
@@ -460,24 +371,10 @@ def convert_video(file_path: Path, out_dir: Path, progress_callback: ProgressCb 
         if rc == 0:
             result.update(status='SUCCESS', quality=crf, retries=0, method='MI355X')
         elif not (stop_event is not None and stop_event.is_set()):
-            backend = 'NVENC' if has_nvenc() else 'CPU'      # fall down the ladder
-
-    if backend == 'NVENC' and result['status'] != 'SUCCESS':
-        ff = build_ffmpeg_params(info, True, gpu_name)
-        ladder = NVENC_RETRIES + [None]
-        for attempt, mods in enumerate(ladder, 1):
-            vparams = adjust_nvenc_params(ff.vparams, attempt) if mods else ff.vparams
-            cmd = build_ffmpeg_command(file_path, out_path, ff, info.audio_channels, info.audio_language, extra_vparams=vparams)
-            rc, text = run_ffmpeg(cmd, progress_callback, file_path.name, total_frames, stop_event=stop_event, debug=debug)
-            if rc == 0:
-                result.update(status='SUCCESS', quality=nvenc_cq, retries=min(attempt, len(NVENC_RETRIES)), method='NVENC')
-                break
-            logger.warning('NVENC attempt %d failed: %s | %s', attempt, file_path.name, text[:1000])
-        else:
-            backend = 'CPU'
+            backend = 'CPU'                                   # fall down the ladder: libx265 through ffmpeg, as the reference's NVENC ladder does
 
     if backend == 'CPU' and result['status'] != 'SUCCESS':
-        ff = build_ffmpeg_params(info, False, gpu_name)
+        ff = build_ffmpeg_params(info)
         cmd = build_ffmpeg_command(file_path, out_path, ff, info.audio_channels, info.audio_language)
         rc, text = run_ffmpeg(cmd, progress_callback, file_path.name, total_frames, stop_event=stop_event, debug=debug)
         if rc == 0:

@@ -1,8 +1,8 @@
 """Encoder / GPU detection and HDR10 signalling strings.
 
-Mirror of the reference's core/utils.py: `has_nvenc` (core/utils.py:9-15), `detect_gpu_type`
-(core/utils.py:17-26), `build_hdr_metadata` (core/utils.py:29-70).  `has_mi355x` is the new
-selection hook: the analogue of `has_nvenc` for the native path.
+Mirror of the reference's core/utils.py for this path: `build_hdr_metadata` (core/utils.py:29-70, libx265 branch) and `has_mi355x`,
+the selection hook that stands where the reference asks `has_nvenc` (core/utils.py:9-15).  The reference's
+hevc_nvenc helpers (`has_nvenc`, `detect_gpu_type`, the NVENC argv) are out of scope and not built.
 """
 from __future__ import annotations
 
@@ -23,16 +23,6 @@ def has_ffmpeg() -> bool:
     return shutil.which('ffmpeg') is not None
 
 
-def has_nvenc() -> bool:
-    """True iff the ffmpeg on PATH lists hevc_nvenc (core/utils.py:9-15)."""
-    try:
-        out = subprocess.run(['ffmpeg', '-hide_banner', '-encoders'],
-                             capture_output=True, text=True, check=True, encoding='utf-8')
-    except Exception:
-        return False
-    return 'hevc_nvenc' in out.stdout
-
-
 def has_libx265() -> bool:
     try:
         out = subprocess.run(['ffmpeg', '-hide_banner', '-encoders'],
@@ -40,17 +30,6 @@ def has_libx265() -> bool:
     except Exception:
         return False
     return 'libx265' in out.stdout
-
-
-@lru_cache(maxsize=1)
-def detect_gpu_type() -> str:
-    """Lower-cased NVIDIA GPU name, or 'unknown' (core/utils.py:17-26).  Cached like the reference."""
-    try:
-        out = subprocess.run(['nvidia-smi', '--query-gpu=name', '--format=csv,noheader'],
-                             capture_output=True, text=True, check=True, encoding='utf-8')
-        return out.stdout.strip().lower()
-    except Exception:
-        return 'unknown'
 
 
 @lru_cache(maxsize=1)
@@ -68,17 +47,11 @@ def has_mi355x() -> bool:
     return mi355x_device_count() > 0
 
 
-def build_hdr_metadata(master_display: str, max_cll: str, use_nvenc: bool, fps: float = 30.0) -> List[str]:
-    """HDR10 argv fragment: `-metadata` pairs + colour flags for NVENC, one `-x265-params` string for
-    libx265.  Empty inputs fall back to the reference's P3-D65 1000-nit defaults."""
+def build_hdr_metadata(master_display: str, max_cll: str, use_nvenc: bool = False, fps: float = 30.0) -> List[str]:
+    """HDR10 argv fragment for libx265: one `-x265-params` string (core/utils.py:58-69).  Empty inputs fall back to the reference's
+    P3-D65 1000-nit defaults.  `use_nvenc` keeps the reference's signature; its hevc_nvenc branch is out of scope and not built."""
     md = (master_display or '').strip() or DEFAULT_MASTER_DISPLAY
     cll = (max_cll or '').strip() or DEFAULT_MAX_CLL
-    if use_nvenc:
-        out: List[str] = []
-        for key, val in (('color_primaries', 'bt2020'), ('color_trc', 'smpte2084'), ('colorspace', 'bt2020nc'),
-                         ('master_display', md), ('max_cll', cll)):
-            out += ['-metadata:s:v:0', f'{key}={val}']
-        return out + ['-color_primaries', 'bt2020', '-color_trc', 'smpte2084', '-colorspace', 'bt2020nc']
     fields = ['hdr10=1', 'colorprim=bt2020', 'transfer=smpte2084', 'colormatrix=bt2020nc',
               f'master-display={md}', f'max-cll={cll}', 'hrd=1', 'aud=1', 'chromaloc=0', 'repeat-headers=1']
     return ['-x265-params', ':'.join(fields)]

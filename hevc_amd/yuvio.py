@@ -87,26 +87,36 @@ def open_clip(path: Path) -> Clip:
 
 
 class _PipeClip:
-    """Any container decoded by an `ffmpeg -f rawvideo` child (only when ffmpeg exists on this host)."""
+    """Any container decoded by an `ffmpeg -f rawvideo` child (only when ffmpeg exists on this host).  A decode error or a short
+    stream raises: a truncated clip must not come out as SUCCESS."""
 
     def __init__(self, path: Path, info):
         self.width, self.height, self.fps = info.width, info.height, info.fps
-        self.bit_depth = 10 if info.hdr else 8
+        self.bit_depth = 10 if (info.hdr or '10' in (info.pix_fmt or '')) else 8
         self.n_frames = info.nb_frames or (int(info.duration * info.fps) if info.duration and info.fps else 0)
         pix = 'yuv420p10le' if self.bit_depth > 8 else 'yuv420p'
+        self._name = Path(path).name
         self._p = subprocess.Popen(['ffmpeg', '-v', 'error', '-i', str(path), '-f', 'rawvideo', '-pix_fmt', pix, '-'],
-                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
 
     def frames(self) -> Iterator[Planes]:
         w, h = self.width, self.height
         fb = w * h * 3 // 2 * (2 if self.bit_depth > 8 else 1)
         dt = np.dtype('<u2') if self.bit_depth > 8 else np.uint8
+        n = 0
         while True:
             buf = self._p.stdout.read(fb)
             if len(buf) < fb:
-                return
+                break
             a = np.frombuffer(buf, dt)
+            n += 1
             yield a[:w * h].reshape(h, w), a[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), a[w * h * 5 // 4:].reshape(h // 2, w // 2)
+        rc = self._p.wait()
+        err = (self._p.stderr.read() or b'').decode('utf-8', 'replace')[-500:]
+        if rc != 0:
+            raise RuntimeError(f'{self._name}: ffmpeg decode failed (exit {rc}): {err}')
+        if self.n_frames and n < self.n_frames - max(2, self.n_frames // 100):      # container frame counts can be off by a frame or two
+            raise RuntimeError(f'{self._name}: decoded {n} of {self.n_frames} frames')
 
     def close(self):
         try:

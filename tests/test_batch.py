@@ -127,3 +127,39 @@ def test_two_rank_sharding_and_max_over_ranks_timing_on_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs)
     assert abs(outs[0]["max_dt"] - 0.2) < 1e-6 and outs[0]["frames"] == 4.0 and abs(outs[0]["value"] - 20.0) < 1e-3
     assert outs[0]["sum0"] != outs[1]["sum1"]            # different seeds -> different clips
+
+
+def convert_for_process_test(f, out_dir, progress_callback=None, stop_event=None, device=None, **kw):
+    """stand-in for convert_video in the worker PROCESSES (top level so a spawned child can import it)"""
+    import os
+    for i in range(3):
+        if stop_event.is_set():
+            return {"file": f.name, "status": "CANCELLED", "quality": None, "retries": 0, "method": "MI355X", "hdr": False}
+        progress_callback(f.name, i + 1, 3)
+        time.sleep(0.02)
+    (Path(out_dir) / (f.stem + ".pid")).write_text(f"{os.getpid()} {device}")
+    return {"file": f.name, "status": "SUCCESS", "quality": 19, "retries": 0, "method": "MI355X", "hdr": False}
+
+
+def test_one_worker_process_per_device(tmp_path):
+    """process mode (what a real MI355X batch uses): two spawned workers pinned to devices 0 / 1 take files from the parent's FIFO,
+    progress and results come back over the queue, the CSV carries method and device"""
+    import os
+    files = [tmp_path / f"clip{i}.mp4" for i in range(5)]
+    for f in files:
+        f.write_bytes(b"x")
+    out = tmp_path / "out"
+    prog, done = [], []
+    r = batch.BatchRunner(files, out, max_workers=2, convert=convert_for_process_test, n_devices=2, use_processes=True,
+                          on_progress=lambda n, a, b: prog.append((n, a, b)), on_finished=done.append).start()
+    res = r.wait()
+    assert len(res) == 5 and all(x["status"] == "SUCCESS" for x in res) and len(done) == 5
+    pids = {}
+    for f in files:
+        pid, dev = (out / (f.stem + ".pid")).read_text().split()
+        pids.setdefault(pid, set()).add(dev)
+    assert len(pids) == 2 and os.getpid() not in {int(p) for p in pids}           # two worker processes, neither is the parent
+    assert sorted(d for v in pids.values() for d in v) == ["0", "1"]              # each pinned to ONE device
+    assert {n for n, _, _ in prog} == {f.name for f in files} and all(b == 3 for _, _, b in prog)
+    rows = list(csv.DictReader(open(out / "transcode_log.csv")))
+    assert len(rows) == 5 and {x["device"] for x in rows} == {"0", "1"} and {x["method"] for x in rows} == {"MI355X"}

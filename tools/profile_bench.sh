@@ -7,11 +7,11 @@ root=$(pwd)
 out=$root/gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-python3 bench.py > $out/bench.json
+python3 bench.py --steps 5 > $out/bench.json
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/bench_under_rocprof.json
-rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o f --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null
-rocprofv3 --pmc WRITE_SIZE -d $out/write -o w --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > /dev/null
+rocprofv3 --kernel-trace --stats -d $out/kt -o kt --output-format csv -- python3 $root/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $out/bench_under_rocprof.json
+rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o f --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null
+rocprofv3 --pmc WRITE_SIZE -d $out/write -o w --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > /dev/null
 cd $root
 python3 tools/prof_summary.py stats $out/kt > $out/kernel_stats.txt
 cp $(find $out/kt -name '*kernel_stats.csv' | head -1) $out/kernel_stats.csv
