@@ -102,7 +102,11 @@ int  mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out);
 /* Caller-owned host planes (8-bit: 1 byte/sample, 10-bit: 2 bytes little endian), copied/uploaded before return. */
 int  mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const void *v,
                        int pitch_y, int pitch_c, int64_t pts);
-/* Frames already resident in device memory (same layout, device pointers): the benchmark path. */
+/* Frames already resident in device memory (same layout, device pointers): the benchmark path.  Stream ordering contract: the copy
+ * into the session's own pitch-aligned picture is ENQUEUED on the session's stream and the call returns before it has run, and it is not
+ * ordered against any stream of the caller.  So (1) the producer of y/u/v must have finished before the call (synchronise its stream or
+ * event first), and (2) the three planes must stay valid and unmodified until the picture's packet has been received, or mihevc_flush
+ * has returned, whichever comes first (host buffers of mihevc_send_frame may be reused as soon as that call returns). */
 int  mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, const void *v,
                               int pitch_y, int pitch_c, int64_t pts);
 /* One access unit (Annex-B NAL units) in session-owned memory, valid until the next receive/close. */
