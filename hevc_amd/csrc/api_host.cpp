@@ -65,6 +65,7 @@ void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_
     out->pre_search = 0;
     out->rdo_zero = 0;
     out->chroma_modes = 0;
+    out->mc_top = out->mc_bottom = 0;
 }
 
 static int copy_out(const std::vector<uint8_t> &v, uint8_t *buf, size_t cap)

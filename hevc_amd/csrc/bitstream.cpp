@@ -108,7 +108,7 @@ void write_vps(const mihevc_config &c, std::vector<uint8_t> &out)
 
 void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
 {
-    CodedSize cs = coded_size(c.width, c.height);
+    CodedSize cs = coded_size(c.width, picture_height(c));
     BitWriter w;
     w.put(0, 4);          // sps_video_parameter_set_id
     w.put(0, 3);          // sps_max_sub_layers_minus1
@@ -201,29 +201,76 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
     append_nal(out, 33, w.bytes());
 }
 
+TileGrid tile_grid(const mihevc_config &cfg);
+// Table A.8 (MaxTileCols / MaxTileRows) by general_level_idc
+static void level_tile_limits(int level_idc, int &max_cols, int &max_rows)
+{
+    max_cols = max_rows = 1;
+    if (level_idc >= 180) { max_cols = 20; max_rows = 22; }
+    else if (level_idc >= 150) { max_cols = 10; max_rows = 11; }
+    else if (level_idc >= 120) { max_cols = 5; max_rows = 5; }
+    else if (level_idc >= 93) { max_cols = 3; max_rows = 3; }
+    else if (level_idc >= 90) { max_cols = 2; max_rows = 2; }
+}
+int slice_first_row(const mihevc_config &cfg, int k)
+{
+    int r = 0;
+    for (int j = 0; j < k && j < 16; j++) r += cfg.slice_ctu_rows[j];
+    return r;
+}
+// sliced pictures: tiles at all?  Only when a column can be 256 luma samples wide (A.4.1) and the level's tile rows (Table A.8) reach
+// around the slices — every slice is at least one tile row then
+static bool sliced_tiles_allowed(const mihevc_config &cfg)
+{
+    int max_cols, max_rows;
+    level_tile_limits(cfg.level_idc, max_cols, max_rows);
+    return cfg.intra_tiles && ((cfg.width + 7) & ~7) >= 256 && max_rows >= cfg.slice_count;
+}
+// tile rows of slice k: the level's row budget shared evenly by the slices, every row >= 64 luma samples (A.4.1)
+int slice_tile_rows(const mihevc_config &cfg, int k)
+{
+    int max_cols, max_rows;
+    level_tile_limits(cfg.level_idc, max_cols, max_rows);
+    if (!sliced_tiles_allowed(cfg)) return 1;
+    return std::max(1, std::min(max_rows / std::max(1, cfg.slice_count), cfg.slice_ctu_rows[k] / (64 / kCtu)));
+}
+
+// does PPS 1 (IDR pictures) enable tiles for the PICTURE?  (a slice of it may still be a single tile)
+bool idr_tiles_on(const mihevc_config &cfg)
+{
+    TileGrid g = tile_grid(cfg);
+    if (!sliced(cfg)) return g.on();
+    if (!sliced_tiles_allowed(cfg)) return false;
+    int rows = 0;
+    for (int k = 0; k < cfg.slice_count; k++) rows += slice_tile_rows(cfg, k);
+    return g.cols > 1 || rows > 1;
+}
+
 TileGrid tile_grid(const mihevc_config &cfg)
 {
     TileGrid g;
     CodedSize cs = coded_size(cfg.width, cfg.height);
     g.wc = (cs.w + kCtu - 1) >> kCtuLog2; g.hc = (cs.h + kCtu - 1) >> kCtuLog2;
     if (!cfg.intra_tiles || cs.w < 256 || cs.h < 64) return g;     // A.4.1 bounds every tile, so small pictures stay untiled
-    // Table A.8 (MaxTileCols / MaxTileRows) by general_level_idc
-    int max_cols = 1, max_rows = 1;
-    if (cfg.level_idc >= 180) { max_cols = 20; max_rows = 22; }
-    else if (cfg.level_idc >= 150) { max_cols = 10; max_rows = 11; }
-    else if (cfg.level_idc >= 120) { max_cols = 5; max_rows = 5; }
-    else if (cfg.level_idc >= 93) { max_cols = 3; max_rows = 3; }
-    else if (cfg.level_idc >= 90) { max_cols = 2; max_rows = 2; }
+    if (sliced(cfg) && !sliced_tiles_allowed(cfg)) return g;
+    int max_cols, max_rows;
+    level_tile_limits(cfg.level_idc, max_cols, max_rows);
     // A.4.1: columns >= 256 and rows >= 64 luma samples; with uniform spacing the narrowest column is floor(wc / cols) CTBs
     g.cols = std::max(1, std::min(max_cols, g.wc / (256 / kCtu)));
-    g.rows = std::max(1, std::min(max_rows, g.hc / (64 / kCtu)));
+    g.rows = sliced(cfg) ? slice_tile_rows(cfg, cfg.slice_index) : std::max(1, std::min(max_rows, g.hc / (64 / kCtu)));
     return g;
 }
 
 void write_pps(const mihevc_config &cfg, int pps_id, std::vector<uint8_t> &out)
 {
     BitWriter w;
-    const TileGrid g = pps_id == 1 ? tile_grid(cfg) : TileGrid();
+    TileGrid g = pps_id == 1 ? tile_grid(cfg) : TileGrid();
+    int rows_total = g.rows;
+    if (pps_id == 1 && sliced(cfg)) {          // every slice splits ITS rows uniformly: the picture's grid is the concatenation, spelled out
+        rows_total = 0;
+        for (int k = 0; k < cfg.slice_count; k++) rows_total += slice_tile_rows(cfg, k);
+    }
+    const bool tiles_on = g.cols > 1 || rows_total > 1;
     w.ue((uint32_t)pps_id); // pps_pic_parameter_set_id
     w.ue(0);              // pps_seq_parameter_set_id
     w.put1(0);            // dependent_slice_segments_enabled_flag
@@ -243,15 +290,24 @@ void write_pps(const mihevc_config &cfg, int pps_id, std::vector<uint8_t> &out)
     w.put1(0);            // weighted_pred_flag
     w.put1(0);            // weighted_bipred_flag
     w.put1(0);            // transquant_bypass_enabled_flag
-    w.put1(g.on());       // tiles_enabled_flag
+    w.put1(tiles_on);     // tiles_enabled_flag
     w.put1(0);            // entropy_coding_sync_enabled_flag
-    if (g.on()) {
-        w.ue((uint32_t)g.cols - 1);   // num_tile_columns_minus1
-        w.ue((uint32_t)g.rows - 1);   // num_tile_rows_minus1
-        w.put1(1);                    // uniform_spacing_flag
-        w.put1(1);                    // loop_filter_across_tiles_enabled_flag
+    if (tiles_on) {
+        w.ue((uint32_t)g.cols - 1);       // num_tile_columns_minus1
+        w.ue((uint32_t)rows_total - 1);   // num_tile_rows_minus1
+        const bool uniform = !(pps_id == 1 && sliced(cfg));
+        w.put1(uniform);                  // uniform_spacing_flag
+        if (!uniform) {
+            for (int i = 0; i + 1 < g.cols; i++) w.ue((uint32_t)(g.col_bd(i + 1) - g.col_bd(i) - 1));          // column_width_minus1
+            int left = rows_total - 1;
+            for (int k = 0; k < cfg.slice_count && left > 0; k++) {
+                const int r = slice_tile_rows(cfg, k), n = cfg.slice_ctu_rows[k];
+                for (int j = 0; j < r && left > 0; j++, left--) w.ue((uint32_t)((j + 1) * n / r - j * n / r - 1));   // row_height_minus1
+            }
+        }
+        w.put1(1);                        // loop_filter_across_tiles_enabled_flag
     }
-    w.put1(1);            // pps_loop_filter_across_slices_enabled_flag
+    w.put1(!sliced(cfg)); // pps_loop_filter_across_slices_enabled_flag: slices of a picture live on different devices and never look at each other
     w.put1(0);            // deblocking_filter_control_present_flag
     w.put1(0);            // pps_scaling_list_data_present_flag
     w.put1(0);            // lists_modification_present_flag
@@ -352,7 +408,7 @@ void write_parameter_sets(const mihevc_config &c, std::vector<uint8_t> &out)
     write_vps(c, out);
     write_sps(c, out);
     write_pps(c, 0, out);
-    if (tile_grid(c).on()) write_pps(c, 1, out);
+    if (idr_tiles_on(c)) write_pps(c, 1, out);
     if (c.hdr10) write_sei_hdr10(c, out);
 }
 
@@ -998,10 +1054,19 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
     // slice_segment_header (7.3.6.1)
     BitWriter w;
     bool idr = pic.slice_type == 2;
-    w.put1(1);                       // first_slice_segment_in_pic_flag
+    const bool first = !sliced(cfg) || cfg.slice_index == 0;
+    w.put1(first);                   // first_slice_segment_in_pic_flag
     if (idr) w.put1(0);              // no_output_of_prior_pics_flag
     const TileGrid grid = idr ? tile_grid(cfg) : TileGrid();
-    w.ue(grid.on() ? 1 : 0);         // slice_pic_parameter_set_id: PPS 1 carries the IDR tile grid
+    const bool pps_tiles = idr && idr_tiles_on(cfg);
+    w.ue(pps_tiles ? 1 : 0);         // slice_pic_parameter_set_id: PPS 1 carries the IDR tile grid
+    if (!first) {                    // slice_segment_address: the slice's first CTB in raster order, Ceil(Log2(PicSizeInCtbsY)) bits
+        const CodedSize pc = coded_size(cfg.width, picture_height(cfg));
+        const int wc = (pc.w + kCtu - 1) >> kCtuLog2, hc = (pc.h + kCtu - 1) >> kCtuLog2;
+        int nb = 0;
+        while ((1 << nb) < wc * hc) nb++;
+        w.put((uint32_t)(slice_first_row(cfg, cfg.slice_index) * wc), nb);
+    }
     w.ue((uint32_t)pic.slice_type);  // 2 = I, 1 = P
     if (!idr) {
         w.put((uint32_t)pic.poc & 0xff, 8);   // slice_pic_order_cnt_lsb
@@ -1016,7 +1081,7 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
         w.ue(5 - kMaxMergeCand);     // five_minus_max_num_merge_cand
     }
     w.se(pic.qp - 26);               // slice_qp_delta
-    w.put1(1);                       // slice_loop_filter_across_slices_enabled_flag
+    if (!sliced(cfg)) w.put1(1);     // slice_loop_filter_across_slices_enabled_flag (present only when the PPS flag is set)
     SliceCoder coder(cfg, pic);
     const int n_tiles = grid.cols * grid.rows;
     std::vector<std::vector<uint8_t>> sub((size_t)n_tiles);
@@ -1025,7 +1090,7 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
         sub[(size_t)t].reserve(1 << 14);
         bins += coder.run_tile(t % grid.cols, t / grid.cols, sub[(size_t)t]);
     }
-    if (grid.on()) {
+    if (pps_tiles) {
         // entry points (7.4.7.1): substream sizes in bytes of the NAL payload, emulation prevention bytes included.  Every
         // substream (and the header) ends in a byte that holds its final '1' bit, so the zero run that triggers an 0x03
         // never crosses a boundary and each size can be counted on its own.
@@ -1045,8 +1110,10 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
         int len = 1;
         while (len < 32 && (max_off >> len)) len++;
         w.ue((uint32_t)n_tiles - 1);     // num_entry_point_offsets
-        w.ue((uint32_t)len - 1);         // offset_len_minus1
-        for (uint32_t e : esc) w.put(e - 1, len);   // entry_point_offset_minus1
+        if (n_tiles > 1) {
+            w.ue((uint32_t)len - 1);     // offset_len_minus1
+            for (uint32_t e : esc) w.put(e - 1, len);   // entry_point_offset_minus1
+        }
     }
     w.trailing();                    // byte_alignment(): same bit pattern as rbsp_trailing_bits
     std::vector<uint8_t> rbsp = std::move(w.bytes());

@@ -67,7 +67,13 @@ struct TileGrid {
     int row_of(int ctb_y) const { int j = 0; while (j + 1 < rows && row_bd(j + 1) <= ctb_y) j++; return j; }
     bool on() const { return cols > 1 || rows > 1; }
 };
-TileGrid tile_grid(const mihevc_config &cfg);
+TileGrid tile_grid(const mihevc_config &cfg);        // of what the session codes: the picture, or its slice (cfg.slice_count > 1)
+// sliced pictures (cfg.slice_count > 1): height of the whole picture, first CTU row of a slice, tile rows PPS 1 gives a slice
+inline bool sliced(const mihevc_config &c) { return c.slice_count > 1; }
+inline int picture_height(const mihevc_config &c) { return sliced(c) ? c.pic_height : c.height; }
+int slice_first_row(const mihevc_config &cfg, int k);
+int slice_tile_rows(const mihevc_config &cfg, int k);
+bool idr_tiles_on(const mihevc_config &cfg);          // does PPS 1 enable tiles for the picture (a slice of it may still be one tile)
 void write_sei_hdr10(const mihevc_config &cfg, std::vector<uint8_t> &out);
 void write_aud(int slice_type, std::vector<uint8_t> &out);
 // HRD signalling (cfg.hrd with a VBV): E.2.2 hrd_parameters in the VUI; D.2.2 buffering period at IRAP pictures, D.2.3 picture timing

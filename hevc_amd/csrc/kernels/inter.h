@@ -137,6 +137,26 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
     });
 }
 
+// ------------------------------------------------------------------------------------------ motion-constrained slices
+// oracle mv_rows_ok / clamp_center_y: may a block of n luma rows at picture row y use vertical motion my (quarter samples) when the top /
+// bottom edge of the picture is a slice boundary?  Its luma footprint (8-tap: rows -3 .. n + 4 around the integer part when my has a
+// fraction) and chroma footprint (4-tap: -1 .. n/2 + 2 when my & 7) must stay inside.
+DEV bool mv_rows_ok(int y, int n, int my, int h, int top, int bottom)
+{
+    const int ly0 = y + (my >> 2) - ((my & 3) ? 3 : 0), ly1 = y + n - 1 + (my >> 2) + ((my & 3) ? 4 : 0);
+    const int cy0 = (y >> 1) + (my >> 3) - ((my & 7) ? 1 : 0), cy1 = (y >> 1) + (n >> 1) - 1 + (my >> 3) + ((my & 7) ? 2 : 0);
+    if (top && (ly0 < 0 || cy0 < 0)) return false;
+    if (bottom && (ly1 > h - 1 || cy1 > (h >> 1) - 1)) return false;
+    return true;
+}
+DEV int clamp_center_y(int sy, int y0, int R, int h, int top, int bottom)
+{
+    const int ctu_h = h - y0 < CTU ? h - y0 : CTU;
+    if (bottom && sy > h - (y0 + ctu_h) - R) sy = h - (y0 + ctu_h) - R;
+    if (top && sy < R - y0) sy = R - y0;
+    return sy;
+}
+
 // ------------------------------------------------------------------------------------------ integer search
 // source tile and search window are held as the 8 most significant bits of every sample (8-bit input: the samples themselves), so
 // Main10 searches with the packed quad-SAD too; SADs are scaled back by the dropped bits (oracle: sad_msb8)
@@ -205,7 +225,9 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
 
     const int R = a.prm.me_range, spany = 2 * R + 1, spanx = me_spanx(R), quads = spanx >> 2, ws = me_win_stride(R), ww = me_win_w(R), wh = 32 + 2 * R;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
-    const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
+    const int mct = a.prm.mc_top, mcb = a.prm.mc_bottom;
+    const int sx = a.centers ? a.centers[2 * ctu] : 0, sy0 = a.centers ? a.centers[2 * ctu + 1] : 0;
+    const int sy = (mct || mcb) ? clamp_center_y(sy0, y0, R, a.h, mct, mcb) : sy0;
     ex.phase([&](int tid) {
         if (sizeof(T) == 1 && x0 + CTU <= a.w && y0 + CTU <= a.h) {      // whole 8-bit CTU: one dword per lane
             const uint32_t v = load_u32(a.src[0].p + (size_t)(y0 + (tid >> 3)) * a.src[0].stride + x0 + 4 * (tid & 7));
@@ -226,8 +248,13 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
     ex.phase([&](int tid) {
         // a node's candidate goes straight to the workgroup's LDS minimum (filtered by a plain read first), so no
         // per-thread table of 21 running minima has to stay in registers across the unrolled SAD code
-        auto consider = [&](int node, unsigned cost, unsigned p) {
+        auto consider = [&](int node, unsigned cost, unsigned p, int dy_total) {
             unsigned long long key = ((unsigned long long)cost << 16) | p;
+            if ((mct || mcb) && s.valid[node]) {      // a slice: the candidate must keep the node's rows inside it (all four positions of a quad share dy)
+                int nx, ny, nl;
+                node_geom(node, nx, ny, nl);
+                if (!mv_rows_ok(y0 + ny, 1 << nl, 4 * dy_total, a.h, mct, mcb)) return;
+            }
             if (s.valid[node] && key < s.best[node]) ex.atomic_min(&s.best[node], key);
         };
         for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
@@ -262,7 +289,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                             unsigned long long kj = ((unsigned long long)((o[b][j] << 4) + bits[j]) << 16) | pos[j];
                             k = kj < k ? kj : k;
                         }
-                        consider(node, (unsigned)(k >> 16), (unsigned)(k & 0xffff));
+                        consider(node, (unsigned)(k >> 16), (unsigned)(k & 0xffff), sy + dyi - R);
                     }
                 }
 #pragma unroll
@@ -274,7 +301,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                         unsigned long long kj = ((unsigned long long)((s16[h2][j] << 4) + bits[j]) << 16) | pos[j];
                         k = kj < k ? kj : k;
                     }
-                    consider(1 + half * 2 + h2, (unsigned)(k >> 16), (unsigned)(k & 0xffff));
+                    consider(1 + half * 2 + h2, (unsigned)(k >> 16), (unsigned)(k & 0xffff), sy + dyi - R);
                 }
             }
             unsigned long long k = ~0ull;
@@ -283,7 +310,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                 unsigned long long kj = ((unsigned long long)((s32[j] << 4) + bits[j]) << 16) | pos[j];
                 k = kj < k ? kj : k;
             }
-            consider(0, (unsigned)(k >> 16), (unsigned)(k & 0xffff));
+            consider(0, (unsigned)(k >> 16), (unsigned)(k & 0xffff), sy + dyi - R);
         }
     });
     ex.phase([&](int tid) {
@@ -680,7 +707,9 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
 {
     const int R0 = a.prm.me_range, R = R0 + 3, bd = a.prm.bit_depth, lam = a.prm.lambda_sad_q4;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
-    const int sx = a.centers ? a.centers[2 * ctu] : 0, sy = a.centers ? a.centers[2 * ctu + 1] : 0;
+    const int mct = a.prm.mc_top, mcb = a.prm.mc_bottom;
+    const int sx = a.centers ? a.centers[2 * ctu] : 0, sy0 = a.centers ? a.centers[2 * ctu + 1] : 0;
+    const int sy = (mct || mcb) ? clamp_center_y(sy0, y0, R0, a.h, mct, mcb) : sy0;
     const int wy = mc_win_y(R0), wys = mc_win_y_stride(R0), wc = mc_win_c(R0), wcs = mc_win_c_stride(R0);
     const int oy_x = x0 + sx - R - 4, oy_y = y0 + sy - R - 4;                                  // luma window origin
     const int oc_x = (x0 >> 1) + ((4 * sx - 4 * R - 3) >> 3) - 1, oc_y = (y0 >> 1) + ((4 * sy - 4 * R - 3) >> 3) - 1;
@@ -806,6 +835,11 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                 const unsigned satd = s.fsum[k - 1][tid];
                 s.fsum[k - 1][tid] = 0;                                   // ready for the next round
                 int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
+                if (mct || mcb) {                    // a slice: candidates whose filter taps would reach across its edge are out
+                    int nx, ny, nl;
+                    node_geom(tid, nx, ny, nl);
+                    if (!mv_rows_ok(y0 + ny, 1 << nl, my, a.h, mct, mcb)) continue;
+                }
                 unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
                 unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
                 if (key < best) best = key;

@@ -298,9 +298,12 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
     Packet pk;
     pk.pts = pts; pk.key = slice_type == 2;
     // access unit: AUD first (7.4.2.4.4), parameter sets (+ HDR10 SEI), buffering period at the IDR, picture timing, the slice
-    if (s->cfg.aud) write_aud(slice_type, pk.data);
-    if (slice_type == 2 && (first_of_stream || s->cfg.repeat_headers)) pk.data.insert(pk.data.end(), s->headers.begin(), s->headers.end());
-    if (s->cfg.hrd) {
+    // a picture's later slices (sessions on other devices, cfg.slice_index > 0) contribute their slice NAL unit only: the access unit's
+    // delimiter, parameter sets and SEI come with slice 0
+    const bool au_head = s->cfg.slice_count <= 1 || s->cfg.slice_index == 0;
+    if (s->cfg.aud && au_head) write_aud(slice_type, pk.data);
+    if (au_head && slice_type == 2 && (first_of_stream || s->cfg.repeat_headers)) pk.data.insert(pk.data.end(), s->headers.begin(), s->headers.end());
+    if (s->cfg.hrd && au_head) {
         if (slice_type == 2) write_sei_buffering_period(s->cfg, pk.data);
         // clock ticks since the previous buffering period: position in the GOP, or the previous GOP's length at an IDR
         write_sei_pic_timing(s->cfg, (uint32_t)(poc > 0 ? poc - 1 : (index > 0 ? s->keyint - 1 : 0)), pk.data);
@@ -351,7 +354,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto prm_for = [&](int qp) {
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
-        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0, s->cfg.pre_search != 0, s->cfg.rdo_zero != 0, s->cfg.chroma_modes != 0};
+        return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0, s->cfg.pre_search != 0, s->cfg.rdo_zero != 0, s->cfg.chroma_modes != 0,
+                          s->cfg.slice_count > 1 && s->cfg.slice_index > 0, s->cfg.slice_count > 1 && s->cfg.slice_index < s->cfg.slice_count - 1};
     };
     const int64_t first_index = s->frames_in - n;
     {
@@ -419,13 +423,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
     // most kIdrCpbShare of that, and its pictures together take at most kBudgetShare of what the channel delivers during the GOP — so the
     // level at the next IDR is at least the assumed one again (tests replay the produced sizes through the Annex C arrival / removal schedule).
     const double fps = (double)s->cfg.fps_num / s->cfg.fps_den;
+    // a slice of a picture (one device of several) plans with its share of the picture's rate and buffer
+    const double share = (s->cfg.slice_count > 1 && s->cfg.rate_share_q16 > 0) ? s->cfg.rate_share_q16 / 65536.0 : 1.0;
     std::vector<int> qp_prev(gops, s->qp_p), gop_len(gops, 0);
     std::vector<double> budget(gops, 0.0);
     for (int g = 0; g < gops; g++) {
         gop_len[g] = std::min(s->keyint, n - g * s->keyint);
-        budget[g] = kBudgetShare * s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
+        budget[g] = kBudgetShare * share * s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
     }
-    const double cpb_idr_cap = s->cfg.vbv_bufsize_kbits > 0 ? kIdrCpbShare * kCpbStart * s->cfg.vbv_bufsize_kbits * 1000.0 : 1e30;
+    const double cpb_idr_cap = s->cfg.vbv_bufsize_kbits > 0 ? kIdrCpbShare * kCpbStart * share * s->cfg.vbv_bufsize_kbits * 1000.0 : 1e30;
     const int p_slots = s->ring - 1;          // a P step's CABAC job is complete once its slot has been handed out again
     // P-picture QP of lane g at step t.  Every input is deterministic: CABAC sizes only of pictures whose ring slot has been
     // reused (steps <= t - p_slots), device estimates of steps <= t - 2 (the step loop waits for that copy), a model for the
@@ -751,6 +757,14 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 1) || (cfg->height & 1) || cfg->width > 8192 || cfg->height > 4352) return MIHEVC_EINVAL;
     if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return MIHEVC_EINVAL;
     if (cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->keyint < 1 || cfg->keyint > 240) return MIHEVC_EINVAL;
+    if (cfg->slice_count > 1) {        // one slice of a picture: a band of whole CTU rows (the last band takes the picture's remainder)
+        if (cfg->slice_count > 16 || cfg->slice_index < 0 || cfg->slice_index >= cfg->slice_count || cfg->pic_height < cfg->height) return MIHEVC_EINVAL;
+        int rows = 0;
+        for (int k = 0; k < cfg->slice_count; k++) { if (cfg->slice_ctu_rows[k] < 1) return MIHEVC_EINVAL; rows += cfg->slice_ctu_rows[k]; }
+        if (rows != (cfg->pic_height + 31) / 32) return MIHEVC_EINVAL;
+        const int y0 = 32 * slice_first_row(*cfg, cfg->slice_index), y1 = std::min(cfg->pic_height, y0 + 32 * cfg->slice_ctu_rows[cfg->slice_index]);
+        if (cfg->height != y1 - y0) return MIHEVC_EINVAL;
+    }
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return MIHEVC_ENODEV;
     if (device < 0 || device >= n) return MIHEVC_EINVAL;

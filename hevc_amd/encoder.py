@@ -278,6 +278,125 @@ class ShardedEncoder:
             e.close()
 
 
+def slice_rows(height: int, n: int):
+    """CTU rows of n full-width slices of a picture `height` high: as even as whole rows allow, the taller ones first."""
+    rows = (height + 31) // 32
+    n = max(1, min(n, rows, 16))
+    return [rows // n + (1 if k < rows % n else 0) for k in range(n)]
+
+
+class SlicedEncoder:
+    """One PICTURE over several MI355X (BASELINE configs[4]): the picture is cut into full-width bands of CTU rows, band k is coded by its own
+    session on devices[k] as one slice (own CABAC stream, slice_segment_address in its header), and the slices of a picture are put together
+    into one access unit.  Nothing is exchanged between the devices: motion vectors never reach across a band's edge, the in-loop filters
+    stop there (pps_loop_filter_across_slices_enabled_flag = 0) and every band runs its own rate controller on its share of the rate.  The
+    price is the prediction lost at the seams; the alternative — a halo of reconstructed rows copied between neighbours per picture — is
+    DESIGN.md's next step.  `devices` may name a device several times (tests: two slices on one GPU)."""
+
+    def __init__(self, cfg: _lib.Config, devices, keep_recon: bool = False):
+        import queue
+        self.cfg, self.devices = cfg, list(devices)
+        self.rows = slice_rows(cfg.height, len(self.devices))
+        self.devices = self.devices[:len(self.rows)]
+        self._bands, self._cfgs, y0 = [], [], 0
+        for k, r in enumerate(self.rows):
+            c = type(cfg).from_buffer_copy(bytes(cfg))
+            y1 = min(cfg.height, y0 + 32 * r)
+            c.pic_height, c.slice_count, c.slice_index, c.height = cfg.height, len(self.rows), k, y1 - y0
+            for i, rr in enumerate(self.rows):
+                c.slice_ctu_rows[i] = rr
+            c.rate_share_q16 = max(1, round(65536 * r / sum(self.rows)))
+            self._cfgs.append(c)
+            self._bands.append((y0, y1))
+            y0 = y1
+        self._encs = [Encoder(c, device=d, keep_recon=keep_recon) for c, d in zip(self._cfgs, self.devices)]
+        self._q = [queue.Queue(maxsize=8) for _ in self._encs]
+        self._out = [dict() for _ in self._encs]            # per slice: pts -> (data, key)
+        self._lock = threading.Lock()
+        self._err = []
+        self._aborted = False
+        self._threads = [threading.Thread(target=self._worker, args=(k,), daemon=True) for k in range(len(self._encs))]
+        for t in self._threads:
+            t.start()
+        self._n_in, self._next_out = 0, 0
+
+    def _worker(self, k):
+        enc, q = self._encs[k], self._q[k]
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                y, u, v, pts = item
+                enc.send(y, u, v, pts=pts)
+                self._collect(k)
+            if not self._aborted:
+                enc.flush()
+                self._collect(k)
+        except Exception as exc:
+            self._err.append(exc)
+
+    def _collect(self, k):
+        got = list(self._encs[k].packets())
+        if got:
+            with self._lock:
+                for data, pts, key in got:
+                    self._out[k][pts] = (data, key)
+
+    def send(self, y, u, v):
+        import queue
+        for k, (y0, y1) in enumerate(self._bands):
+            item = (y[y0:y1], u[y0 // 2:y1 // 2], v[y0 // 2:y1 // 2], self._n_in)
+            while True:
+                if self._err:
+                    raise self._err[0]
+                try:
+                    self._q[k].put(item, timeout=0.2)
+                    break
+                except queue.Full:
+                    continue
+        self._n_in += 1
+
+    def ready(self):
+        """Access units that are complete (every slice present) and next in order: (data, pts, key)."""
+        out = []
+        with self._lock:
+            while all(self._next_out in o for o in self._out):
+                parts = [o.pop(self._next_out) for o in self._out]
+                out.append((b"".join(p[0] for p in parts), self._next_out, parts[0][1]))
+                self._next_out += 1
+        return out
+
+    _stop_workers = ShardedEncoder._stop_workers
+
+    def finish(self):
+        self._stop_workers(drain=False)
+        if self._err:
+            raise self._err[0]
+        return self.ready()
+
+    def abort(self):
+        self._aborted = True
+        self._stop_workers(drain=True)
+
+    def headers(self) -> bytes:
+        return self._encs[0].headers()
+
+    def stats(self):
+        return [e.stats() for e in self._encs]
+
+    def recon(self, index: int):
+        """the picture's reconstruction: the bands' reconstructions stacked (sessions opened with keep_recon)"""
+        parts = [e.recon(index) for e in self._encs]
+        return tuple(np.vstack([p[i] for p in parts]) for i in range(3))
+
+    def close(self):
+        if any(t.is_alive() for t in self._threads):
+            self.abort()
+        for e in self._encs:
+            e.close()
+
+
 def remux_audio(video_mp4: Path, source: Path, out_path: Path, info: VideoInfo) -> bool:
     """The native path writes video only; the reference always carries the source's audio as AAC (core/transcoder.py:423-450,480-489).
     When the source has audio (only container inputs can, and those need ffmpeg to be decoded at all) the video track is copied and the
@@ -300,7 +419,7 @@ def remux_audio(video_mp4: Path, source: Path, out_path: Path, info: VideoInfo) 
 
 def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callback: Optional[Callable[[str, int, int], None]] = None,
                 total_frames: int = 1, stop_event: Optional[threading.Event] = None, device: Optional[int] = None, debug: bool = False,
-                devices=None) -> int:
+                devices=None, row_split: bool = False) -> int:
     """Encode `file_path` to `out_path` (MP4/hvc1) on an MI355X.  Returns 0 on success, 1 on failure/cancel —
     the same (returncode) shape `run_ffmpeg` gives `convert_video` (core/transcoder.py:497-535)."""
     from . import mp4, yuvio
@@ -328,8 +447,8 @@ def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callb
                 except Exception:
                     logger.debug("progress_callback raised", exc_info=True)
 
-        if devices and len(devices) > 1:            # one clip over several GPUs, GOP chunks round-robin
-            sh = ShardedEncoder(cfg, devices)
+        if devices and len(devices) > 1:            # one clip over several GPUs: GOP chunks round-robin, or every picture split by CTU rows
+            sh = SlicedEncoder(cfg, devices) if row_split else ShardedEncoder(cfg, devices)
             try:
                 for y, u, v in clip.frames():
                     if stop_event is not None and stop_event.is_set():

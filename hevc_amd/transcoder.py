@@ -344,13 +344,14 @@ def decide_encoder(info: Optional[VideoInfo], force_cpu: bool, force_gpu: bool) 
 def convert_video(file_path: Path, out_dir: Path, progress_callback: ProgressCb = None, debug: bool = False,
                   skip_validator: bool = False, force_cpu: bool = False, force_gpu: bool = False,
                   stop_event: Optional[threading.Event] = None, device: Optional[int] = None,
-                  devices: Optional[list] = None) -> Dict[str, Any]:
+                  devices: Optional[list] = None, row_split: bool = False) -> Dict[str, Any]:
     """Transcode one file to `out_dir/<stem>.mp4`; never raises for encode failures.
 
     Returns {"file","status","quality","retries","method","hdr"} — the six CSV columns of the
     reference (gui/mainwindow.py:351).  `method` is the path that produced the file: 'MI355X'
     or 'CPU'.  `device` (new, optional) pins the MI355X ordinal for the batch scheduler; `devices`
-    (new, optional) spreads ONE clip over several MI355X, GOP chunks round-robin (hevc_amd.encoder.ShardedEncoder)."""
+    (new, optional) spreads ONE clip over several MI355X: GOP chunks round-robin (hevc_amd.encoder.ShardedEncoder) or, with
+    `row_split`, every picture as one slice of CTU rows per device (hevc_amd.encoder.SlicedEncoder; BASELINE configs[4])."""
     file_path, out_dir = Path(file_path), Path(out_dir)
     info = probe_media(file_path)
     out_path = out_dir / (file_path.stem + '.mp4')
@@ -364,7 +365,7 @@ def convert_video(file_path: Path, out_dir: Path, progress_callback: ProgressCb 
         from . import encoder as native
         try:
             rc = native.encode_file(file_path, out_path, info, progress_callback=progress_callback,
-                                    total_frames=total_frames, stop_event=stop_event, device=device, debug=debug, devices=devices)
+                                    total_frames=total_frames, stop_event=stop_event, device=device, debug=debug, devices=devices, row_split=row_split)
         except Exception as exc:            # the native path must never take the caller down
             logger.warning('MI355X encode failed for %s: %s', file_path.name, exc, exc_info=debug)
             rc = 1

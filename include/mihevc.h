@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MIHEVC_ABI_VERSION 1
+#define MIHEVC_ABI_VERSION 2
 
 typedef enum {
     MIHEVC_OK = 0,
@@ -77,6 +77,15 @@ typedef struct mihevc_config {
                                        * coded as all-zero (-2.5 % bits at -0.01 dB on the bench clip's P pictures) */
     int32_t chroma_modes;             /* 1 (default): 2Nx2N intra CUs choose intra_chroma_pred_mode among DM / planar / vertical / horizontal /
                                        * DC by SATD over Cb + Cr; 0: always DM */
+    /* ---- one picture over several devices (BASELINE configs[4]): a session may code ONE SLICE — a full-width band of CTU rows — of
+     * pictures pic_height high.  `height` is then the band's own height (32 x its CTU rows, the last band takes what is left), the
+     * parameter sets describe the whole picture and are identical in every slice's session, the slice header carries the band's
+     * slice_segment_address, in-loop filters stop at slice boundaries (pps_loop_filter_across_slices_enabled_flag = 0) and motion
+     * vectors never reach across them (nothing is exchanged between the devices).  slice_count = 0 / 1: whole pictures. */
+    int32_t pic_height;               /* height of the whole picture (display); used when slice_count > 1 */
+    int32_t slice_count, slice_index;
+    int32_t slice_ctu_rows[16];       /* CTU rows of every slice, top to bottom (sum = ceil(pic_height / 32)) */
+    int32_t rate_share_q16;           /* share of vbv-maxrate / vbv-bufsize this slice plans with, 65536 = all (0 = all) */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -137,6 +146,8 @@ typedef struct mihevc_cost_params {
     int32_t pre_search;               /* 1: without explicit centres, mihevc_k_inter_frame derives them from the 1/4-size pictures */
     int32_t rdo_zero;                 /* 1: RD zero-out of inter TUs */
     int32_t chroma_modes;             /* 1: chroma intra mode decision (else DM) */
+    int32_t mc_top, mc_bottom;        /* 1: motion compensation must not read above row 0 / below the last row (the picture is a slice whose
+                                       * neighbour lives on another device); 0: the padded border is the picture's own */
 } mihevc_cost_params;
 void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, every analysis knob 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every

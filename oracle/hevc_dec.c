@@ -184,6 +184,8 @@ struct orc_decoder {
     orc_cu_rec *cu; uint8_t *depth8; uint8_t *skip8; orc_sao_ctu *sao;
     /* slice */
     int slice_type, slice_qp, sao_luma, sao_chroma, max_merge, ref_idx;
+    /* slices of the current picture: full-width bands of CTU rows [band_row0[k], band_row0[k + 1]); the slice being decoded starts at luma row slice_y0 */
+    int n_bands, band_row0[24], slice_y0, pic_sao, pic_lf_across;
     size_t *epb; int n_epb, cap_epb;   /* positions (escaped payload offsets after the NAL header) of the removed 0x03 bytes */
     int poc;
     cabac cb;
@@ -561,7 +563,7 @@ static inline int same_tile_d(const orc_decoder *d, int xa, int ya, int xb, int 
  * z-order comparison restricted to the same tile (6.4.1 with 6.5.1) */
 static inline int avail_z(const orc_decoder *d, int xc, int yc, int xn, int yn)
 {
-    return xn >= 0 && yn >= 0 && xn < d->w && yn < d->h && zaddr(d, xn, yn) <= zaddr(d, xc, yc) && same_tile_d(d, xn, yn, xc, yc);
+    return xn >= 0 && yn >= d->slice_y0 && xn < d->w && yn < d->h && zaddr(d, xn, yn) <= zaddr(d, xc, yc) && same_tile_d(d, xn, yn, xc, yc);
 }
 static inline orc_cu_rec *cu_at(orc_decoder *d, int x, int y) { return &d->cu[(y >> 3) * (d->w >> 3) + (x >> 3)]; }
 
@@ -724,8 +726,29 @@ static void intra_predict_block(orc_decoder *d, int c_idx, int x, int y, int log
 {
     pix ref[129], filt[129];
     int s = c_idx ? 1 : 0;
-    if (d->tiles && (d->col_bd[1] != 1 * ((d->w + 31) >> 5) / d->tile_cols || d->row_bd[1] != 1 * ((d->h + 31) >> 5) / d->tile_rows)) set_err(d, "non-uniform tile grids are parsed but not predicted");
-    orc_intra_build_ref_tiles(d->cur.pl[c_idx], d->cur.stride[c_idx], x, y, log2n, d->w >> s, d->h >> s, c_idx, d->bit_depth, d->tile_cols, d->tile_rows, ref);
+    /* 8.4.4.2.2 with 6.4.1: a neighbour is available when it lies in the picture, in the current slice and tile, and earlier in decoding
+     * order (avail_z: explicit tile boundaries, the slice's first row); then the substitution process */
+    {
+        const int n = 1 << log2n, total = 4 * n + 1, stride = d->cur.stride[c_idx];
+        const pix *rec = d->cur.pl[c_idx];
+        uint8_t av[4 * 32 + 1];
+        int first = -1;
+        for (int i = 0; i < total; i++) {
+            int xn, yn;
+            if (i < 2 * n) { xn = x - 1; yn = y + 2 * n - 1 - i; }
+            else if (i == 2 * n) { xn = x - 1; yn = y - 1; }
+            else { xn = x + (i - 2 * n - 1); yn = y - 1; }
+            int ok = xn >= 0 && yn >= 0 && avail_z(d, x << s, y << s, xn << s, yn << s) && zaddr(d, xn << s, yn << s) < zaddr(d, x << s, y << s);
+            av[i] = (uint8_t)ok;
+            ref[i] = ok ? rec[(size_t)yn * stride + xn] : 0;
+            if (ok && first < 0) first = i;
+        }
+        if (first < 0) for (int i = 0; i < total; i++) ref[i] = (pix)(1 << (d->bit_depth - 1));
+        else {
+            if (!av[0]) ref[0] = ref[first];
+            for (int i = 1; i < total; i++) if (!av[i]) ref[i] = ref[i - 1];
+        }
+    }
     orc_intra_filter_ref(ref, filt, log2n, mode, c_idx, d->bit_depth, d->strong_intra);
     orc_intra_pred(filt, d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x, d->cur.stride[c_idx], log2n, mode, c_idx, d->bit_depth);
 }
@@ -1024,7 +1047,7 @@ static void parse_sao(orc_decoder *d, int rx, int ry)
     memset(o, 0, sizeof *o);
     /* merge candidates must lie in the same slice and tile (7.3.8.3) */
     if (rx > d->col_bd[tile_col_of(d, rx)] && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[ry * wc + rx - 1]; goto mask; }
-    if (ry > d->row_bd[tile_row_of(d, ry)] && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[(ry - 1) * wc + rx]; goto mask; }
+    if (ry > d->row_bd[tile_row_of(d, ry)] && ry > (d->slice_y0 >> ORC_CTU_LOG2) && cb_decision(c, CX_SAO_MERGE)) { *o = d->sao[(ry - 1) * wc + rx]; goto mask; }   /* the CTB above must be in this slice and tile */
     for (int ci = 0; ci < 3; ci++) {
         if ((ci == 0 && !d->sao_luma) || (ci > 0 && !d->sao_chroma)) continue;
         int t = ci ? 1 : 0;
@@ -1055,17 +1078,51 @@ static size_t epb_before(const orc_decoder *d, size_t r)
     return k;
 }
 
+/* the picture under construction is complete: in-loop filters, then it becomes a reference.  Slices are independent bands of CTU rows
+ * (pps_loop_filter_across_slices_enabled_flag = 0 whenever a picture has more than one): deblocking leaves the edges on a slice boundary
+ * alone and SAO sees samples of another slice as absent (8.7.2 / 8.7.3), which is what filtering every band as a picture of its own does. */
+static void finish_picture(orc_decoder *d)
+{
+    if (!d->cur_valid) return;
+    const int wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2, w8 = d->w >> 3;
+    picture out; memset(&out, 0, sizeof out);
+    if (d->pic_sao) { alloc_pic(d, &out); out.poc = d->poc; }
+    for (int k = 0; k < d->n_bands; k++) {
+        const int r0 = d->band_row0[k], r1 = d->band_row0[k + 1];
+        const int y0 = r0 << ORC_CTU_LOG2, y1 = (r1 << ORC_CTU_LOG2) < d->h ? (r1 << ORC_CTU_LOG2) : d->h, bh = y1 - y0;
+        if (d->n_bands > 1 && d->pic_lf_across) { set_err(d, "several slices with loop filtering across them are parsed but not filtered"); break; }
+        pix *py = d->cur.pl[0] + (size_t)y0 * d->cur.stride[0], *pu = d->cur.pl[1] + (size_t)(y0 / 2) * d->cur.stride[1], *pv = d->cur.pl[2] + (size_t)(y0 / 2) * d->cur.stride[1];
+        orc_deblock_frame(py, pu, pv, d->cur.stride[0], d->cur.stride[1], d->w, bh, d->cu + (size_t)(y0 >> 3) * w8, d->bit_depth, d->cb_off);
+        if (d->pic_sao)
+            orc_sao_apply_frame(py, pu, pv, d->cur.stride[0], d->cur.stride[1], out.pl[0] + (size_t)y0 * out.stride[0], out.pl[1] + (size_t)(y0 / 2) * out.stride[1],
+                                out.pl[2] + (size_t)(y0 / 2) * out.stride[1], out.stride[0], out.stride[1], d->w, bh, d->bit_depth, d->sao + (size_t)r0 * wc);
+    }
+    if (d->pic_sao) { free_pic(&d->cur); d->cur = out; }
+    if (d->band_row0[d->n_bands] != ((d->h + ORC_CTU - 1) >> ORC_CTU_LOG2)) set_err(d, "picture incomplete: slices cover %d of %d CTU rows", d->band_row0[d->n_bands], (d->h + ORC_CTU - 1) >> ORC_CTU_LOG2);
+    if (d->n_pics == d->cap_pics) { d->cap_pics = d->cap_pics ? d->cap_pics * 2 : 16; d->pics = (picture *)realloc(d->pics, sizeof(picture) * d->cap_pics); }
+    d->pics[d->n_pics++] = d->cur; d->cur_valid = 0;
+}
+
 static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_type)
 {
     if (!d->have_sps || !d->have_pps) { set_err(d, "slice before parameter sets"); return -1; }
     bitrd b = {rbsp, n, 0, 0};
-    if (!br_bit(&b)) { set_err(d, "multiple slice segments unsupported"); return -1; }
+    const int first = br_bit(&b);        /* first_slice_segment_in_pic_flag */
     int irap = nal_type >= 16 && nal_type <= 23, idr = nal_type == 19 || nal_type == 20;
     if (irap) br_bit(&b);
     if (activate_pps(d, (int)br_ue(&b))) { set_err(d, "slice: pps id"); return -1; }
+    const int wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2, hc = (d->h + ORC_CTU - 1) >> ORC_CTU_LOG2;
+    int addr = 0;
+    if (!first) {                        /* dependent_slice_segments_enabled_flag is 0: slice_segment_address follows, Ceil(Log2(PicSizeInCtbsY)) bits */
+        int nb = 0;
+        while ((1 << nb) < wc * hc) nb++;
+        addr = (int)br_u(&b, nb);
+        if (!d->cur_valid) { set_err(d, "slice segment address %d without a first slice", addr); return -1; }
+        if (addr % wc || addr / wc != d->band_row0[d->n_bands]) { set_err(d, "slice at CTB %d: only consecutive slices of whole CTB rows are decoded", addr); return -1; }
+    } else finish_picture(d);
     d->slice_type = (int)br_ue(&b);
     if (d->slice_type == 0) { set_err(d, "B slices unsupported"); return -1; }
-    d->poc = 0;
+    int poc = 0;
     if (!idr) {
         int lsb = (int)br_u(&b, d->poc_bits);
         int prev = d->n_pics ? d->pics[d->n_pics - 1].poc : 0;   /* all pictures are reference pictures at TemporalId 0 */
@@ -1073,11 +1130,13 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
         if (lsb < prev_lsb && prev_lsb - lsb >= maxl / 2) msb = prev_msb + maxl;
         else if (lsb > prev_lsb && lsb - prev_lsb > maxl / 2) msb = prev_msb - maxl;
         else msb = prev_msb;
-        d->poc = msb + lsb;
+        poc = msb + lsb;
         if (!br_bit(&b)) { set_err(d, "slice: explicit RPS unsupported"); return -1; }
         if (d->num_strps > 1) { int nb = 0; while ((1 << nb) < d->num_strps) nb++; d->ref_idx = (int)br_u(&b, nb); } else d->ref_idx = 0;
         if (d->strps_neg[d->ref_idx] != 1 || d->strps_delta[d->ref_idx][0] != -1) { set_err(d, "slice: RPS is not {-1}"); return -1; }
     }
+    if (!first && poc != d->poc) { set_err(d, "slices of one picture disagree on the picture order count"); return -1; }
+    d->poc = poc;
     d->sao_luma = d->sao_chroma = 0;
     if (d->sao_on) { d->sao_luma = br_bit(&b); d->sao_chroma = br_bit(&b); }
     d->max_merge = 5;
@@ -1091,55 +1150,81 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
     uint32_t entry[20 * 22];
     if (d->tiles) {
         n_entry = (int)br_ue(&b);
-        if (n_entry != d->tile_cols * d->tile_rows - 1) { set_err(d, "slice: %d entry points for %d tiles", n_entry, d->tile_cols * d->tile_rows); return -1; }
-        int len = 1 + (int)br_ue(&b);
-        if (len > 32) { set_err(d, "slice: offset_len"); return -1; }
-        for (int i = 0; i < n_entry; i++) entry[i] = 1 + br_u(&b, len);
+        if (n_entry >= d->tile_cols * d->tile_rows || (n_entry + 1) % d->tile_cols) { set_err(d, "slice: %d entry points, tile grid %dx%d", n_entry, d->tile_cols, d->tile_rows); return -1; }
+        if (n_entry > 0) {
+            int len = 1 + (int)br_ue(&b);
+            if (len > 32) { set_err(d, "slice: offset_len"); return -1; }
+            for (int i = 0; i < n_entry; i++) entry[i] = 1 + br_u(&b, len);
+        }
     }
     if (!br_bit(&b)) { set_err(d, "slice: byte_alignment bit"); return -1; }
     while (b.pos & 7) if (br_bit(&b)) { set_err(d, "slice: alignment zero bits"); return -1; }
     if (b.err) { set_err(d, "slice header truncated"); return -1; }
     put_kv(d, "slice.last_qp", d->slice_qp); put_kv(d, "slice.last_type", d->slice_type); put_kv(d, "slice.max_merge", d->max_merge);
 
-    if (idr) { for (int i = 0; i < d->n_pics; i++) d->pics[i].poc = -1000000 - i; }  /* IDR: earlier pictures leave the DPB */
-    int w8 = d->w >> 3, h8 = d->h >> 3, wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2, hc = (d->h + ORC_CTU - 1) >> ORC_CTU_LOG2;
-    if (!d->cu) {
-        d->cu = (orc_cu_rec *)calloc((size_t)w8 * h8, sizeof(orc_cu_rec));
-        d->depth8 = (uint8_t *)calloc((size_t)w8 * h8, 1); d->skip8 = (uint8_t *)calloc((size_t)w8 * h8, 1);
-        d->sao = (orc_sao_ctu *)calloc((size_t)wc * hc, sizeof(orc_sao_ctu));
-    }
-    memset(d->cu, 0, sizeof(orc_cu_rec) * w8 * h8); memset(d->depth8, 0, (size_t)w8 * h8); memset(d->skip8, 0, (size_t)w8 * h8);
-    memset(d->sao, 0, sizeof(orc_sao_ctu) * wc * hc);
-    alloc_pic(d, &d->cur); d->cur_valid = 1; d->cur.poc = d->poc;
+    int w8 = d->w >> 3, h8 = d->h >> 3;
+    if (first) {
+        if (idr) { for (int i = 0; i < d->n_pics; i++) d->pics[i].poc = -1000000 - i; }  /* IDR: earlier pictures leave the DPB */
+        if (!d->cu) {
+            d->cu = (orc_cu_rec *)calloc((size_t)w8 * h8, sizeof(orc_cu_rec));
+            d->depth8 = (uint8_t *)calloc((size_t)w8 * h8, 1); d->skip8 = (uint8_t *)calloc((size_t)w8 * h8, 1);
+            d->sao = (orc_sao_ctu *)calloc((size_t)wc * hc, sizeof(orc_sao_ctu));
+        }
+        memset(d->cu, 0, sizeof(orc_cu_rec) * w8 * h8); memset(d->depth8, 0, (size_t)w8 * h8); memset(d->skip8, 0, (size_t)w8 * h8);
+        memset(d->sao, 0, sizeof(orc_sao_ctu) * wc * hc);
+        alloc_pic(d, &d->cur); d->cur_valid = 1; d->cur.poc = d->poc;
+        d->n_bands = 0; d->band_row0[0] = 0;
+        d->pic_sao = d->sao_luma || d->sao_chroma; d->pic_lf_across = d->lf_across;
+    } else if ((d->sao_luma || d->sao_chroma) != d->pic_sao) { set_err(d, "slices of one picture disagree on SAO"); return -1; }
+    if (d->n_bands >= 23) { set_err(d, "too many slices"); return -1; }
     build_scans();
-    int ok = -1;
+    const int row0 = addr / wc;
+    d->slice_y0 = row0 << ORC_CTU_LOG2;
+    int ok = -1, row_end = row0;
     /* slice_segment_data (7.3.8.1) in tile scan; every tile is one CABAC substream that starts at its entry point.
-     * Entry points count bytes of the NAL payload WITH emulation prevention bytes (7.4.7.1): map through epb[]. */
+     * Entry points count bytes of the NAL payload WITH emulation prevention bytes (7.4.7.1): map through epb[].
+     * The slice holds whole tile rows (with tiles) or whole CTB rows (one tile): tiles t_first .. t_first + n_entry. */
     size_t data0 = b.pos >> 3;            /* rbsp offset of the slice segment data */
     size_t sub_start = data0;             /* rbsp offset of the current substream */
-    int n_tiles = d->tile_cols * d->tile_rows;
-    for (int t = 0; t < n_tiles; t++) {
-        int tx = t % d->tile_cols, ty = t / d->tile_cols;
+    int t_first = 0;
+    if (d->tiles) {
+        int ty0 = tile_row_of(d, row0);
+        if (d->row_bd[ty0] != row0) { set_err(d, "slice at CTB row %d does not start a tile row", row0); goto done; }
+        t_first = ty0 * d->tile_cols;
+    }
+    const int n_sub = n_entry + 1;
+    for (int ti = 0; ti < n_sub; ti++) {
+        int t = t_first + ti, tx = t % d->tile_cols, ty = t / d->tile_cols;
         size_t sub_end = n;
-        if (t < n_entry) {
+        if (ti < n_entry) {
             /* escaped start of this substream = its rbsp start + EPBs before it; add the signalled size; map back */
-            size_t esc_start = sub_start + epb_before(d, sub_start), esc_end = esc_start + entry[t];
+            size_t esc_start = sub_start + epb_before(d, sub_start), esc_end = esc_start + entry[ti];
             size_t e = esc_end;           /* rbsp position r with r + epb_before(r) == esc_end */
             for (int k = 0; k < d->n_epb && d->epb[k] < esc_end; k++) e--;
             sub_end = e;
-            if (sub_end > n || sub_end <= sub_start) { set_err(d, "slice: entry point %d out of range", t); goto done; }
+            if (sub_end > n || sub_end <= sub_start) { set_err(d, "slice: entry point %d out of range", ti); goto done; }
         }
         cb_init(&d->cb, rbsp + sub_start, sub_end - sub_start, d->slice_type == 2 ? 0 : 1, d->slice_qp);
-        for (int ry = d->row_bd[ty]; ry < d->row_bd[ty + 1]; ry++)
+        /* one tile (no tiles in the PPS): CTB rows from row0 until end_of_slice_segment_flag */
+        const int ry0 = d->tiles ? d->row_bd[ty] : row0, ry1 = d->tiles ? d->row_bd[ty + 1] : hc;
+        int ended = 0;
+        for (int ry = ry0; ry < ry1 && !ended; ry++)
             for (int rx = d->col_bd[tx]; rx < d->col_bd[tx + 1]; rx++) {
                 if (d->sao_luma || d->sao_chroma) parse_sao(d, rx, ry);
                 if (coding_quadtree(d, rx << ORC_CTU_LOG2, ry << ORC_CTU_LOG2, ORC_CTU_LOG2, 0)) goto done;
                 int end = cb_terminate(&d->cb);
-                int last = t == n_tiles - 1 && ry == d->row_bd[ty + 1] - 1 && rx == d->col_bd[tx + 1] - 1;
-                if (end != last) { set_err(d, "end_of_slice_segment_flag=%d at ctu (%d,%d)", end, rx, ry); goto done;}
+                int tile_last = ry == ry1 - 1 && rx == d->col_bd[tx + 1] - 1;
+                if (end) {
+                    /* legal only at the end of a CTB row that ends the slice's last substream */
+                    if (ti != n_sub - 1 || rx != d->col_bd[tx + 1] - 1 || (d->tiles && !tile_last)) { set_err(d, "end_of_slice_segment_flag=1 at ctu (%d,%d)", rx, ry); goto done; }
+                    ended = 1; row_end = ry + 1;
+                    break;
+                }
+                if (tile_last && ti == n_sub - 1) { set_err(d, "end_of_slice_segment_flag=0 at ctu (%d,%d)", rx, ry); goto done; }
             }
         if (d->cb.err) { set_err(d, "slice data truncated (tile %d)", t); goto done; }
-        if (t < n_tiles - 1) {
+        if (ti < n_sub - 1) {
+            if (ended) { set_err(d, "slice ended before its last substream"); goto done; }
             /* end_of_subset_one_bit, then byte_alignment().  The encoder's flush (9.3.4.5: 7-bit renormalisation, put_bits(1),
              * write_bits(((low >> 7) & 3) | 1, 2)) puts its final '1' -- which IS alignment_bit_equal_to_one -- on the last bit of
              * the 9-bit window the arithmetic decoder holds when it decodes the terminating bin (no renormalisation follows a
@@ -1153,22 +1238,14 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
                 if (sp[last >> 3] & ((1u << (7 - (last & 7))) - 1)) { set_err(d, "tile %d: non-zero alignment bits", t); goto done; }
                 if ((last >> 3) + 1 != sub_end - sub_start) { set_err(d, "tile %d: substream is %zu bytes, entry point says %zu", t, (last >> 3) + 1, sub_end - sub_start); goto done; }
             }
-        }
+        } else if (!ended) { set_err(d, "slice data ends without end_of_slice_segment_flag"); goto done; }
         sub_start = sub_end;
     }
-    /* in-loop filters, then the picture becomes a reference */
-    orc_deblock_frame(d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1], d->w, d->h, d->cu, d->bit_depth, d->cb_off);
-    if (d->sao_luma || d->sao_chroma) {
-        picture out; memset(&out, 0, sizeof out); alloc_pic(d, &out); out.poc = d->poc;
-        orc_sao_apply_frame(d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1],
-                            out.pl[0], out.pl[1], out.pl[2], out.stride[0], out.stride[1], d->w, d->h, d->bit_depth, d->sao);
-        free_pic(&d->cur); d->cur = out;
-    }
-    if (d->n_pics == d->cap_pics) { d->cap_pics = d->cap_pics ? d->cap_pics * 2 : 16; d->pics = (picture *)realloc(d->pics, sizeof(picture) * d->cap_pics); }
-    d->pics[d->n_pics++] = d->cur; d->cur_valid = 0;
+    d->n_bands++;
+    d->band_row0[d->n_bands] = row_end;
     ok = 0;
 done:
-    if (d->cur_valid) { free_pic(&d->cur); d->cur_valid = 0; }
+    if (ok && d->cur_valid) { free_pic(&d->cur); d->cur_valid = 0; }
     return ok;
 }
 
@@ -1205,6 +1282,7 @@ int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
         /* 7.4.2.4.4: an access unit delimiter, when present, is the first NAL unit of its access unit (one slice per picture here) */
         if (type == 35 && au_open) { set_err(d, "access unit delimiter is not the first NAL unit of its access unit"); break; }
         au_open = !(type == 1 || type == 19 || type == 20);
+        if (au_open) finish_picture(d);          /* a non-VCL NAL unit after the slices: the picture before it is complete */
         if (type == 32) rc = parse_vps(d, &b);
         else if (type == 33) rc = parse_sps(d, &b);
         else if (type == 34) rc = parse_pps(d, &b);
@@ -1216,6 +1294,7 @@ int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
         i = e;
     }
 out:
+    if (!d->err[0]) finish_picture(d);
     free(rbsp);
     put_kv(d, "count.aud", n_aud); put_kv(d, "count.slices", n_slices);
     return d->err[0] ? -1 : d->n_pics;

@@ -662,6 +662,28 @@ void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *c
         }
 }
 
+/* One picture over several devices: the picture a session codes may be a SLICE whose upper / lower neighbour is reconstructed on another
+ * device and never seen (prm->mc_top / mc_bottom).  Motion compensation must then stay inside the slice: a block of n luma rows at row y
+ * with vertical motion my (quarter samples) reads luma rows y + (my >> 2) + [-3, n + 4] when my has a fraction (8-tap), else its own n rows,
+ * and chroma rows y/2 + (my >> 3) + [-1, n/2 + 2] when my & 7 (4-tap), else its n/2 rows. */
+static int mv_rows_ok(int y, int n, int my, int h, int top, int bottom)
+{
+    int ly0 = y + (my >> 2) - ((my & 3) ? 3 : 0), ly1 = y + n - 1 + (my >> 2) + ((my & 3) ? 4 : 0);
+    int cy0 = (y >> 1) + (my >> 3) - ((my & 7) ? 1 : 0), cy1 = (y >> 1) + (n >> 1) - 1 + (my >> 3) + ((my & 7) ? 2 : 0);
+    if (top && (ly0 < 0 || cy0 < 0)) return 0;
+    if (bottom && (ly1 > h - 1 || cy1 > (h >> 1) - 1)) return 0;
+    return 1;
+}
+/* the search centre of a CTU is pulled back so that the whole +-R window keeps the CTU's rows inside the slice: every node then has
+ * admissible integer candidates */
+static int clamp_center_y(int sy, int y0, int R, int h, int top, int bottom)
+{
+    int ctu_h = h - y0 < ORC_CTU ? h - y0 : ORC_CTU;
+    if (bottom && sy > h - (y0 + ctu_h) - R) sy = h - (y0 + ctu_h) - R;
+    if (top && sy < R - y0) sy = R - y0;
+    return sy;
+}
+
 /* 8x8 Hadamard "activity" of a source tile: the SATD it would have against a flat prediction of its own mean (the DC term
  * dropped) -- the yardstick a CTU's inter cost is held against before the intra second pass looks at it */
 static int hadamard8_ac(const pix *a, int as)
@@ -713,6 +735,8 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
         for (int cx = 0; cx < wc; cx++) {
             int ctu = cy * wc + cx, x0 = cx * ORC_CTU, y0 = cy * ORC_CTU;
             int sx = centers ? centers[2 * ctu] : 0, sy = centers ? centers[2 * ctu + 1] : 0;
+            const int mct = prm->mc_top, mcb = prm->mc_bottom;
+            if (mct || mcb) sy = clamp_center_y(sy, y0, R, h, mct, mcb);
             int valid[21], nx[21], ny[21], nl[21];
             for (int nd = 0; nd < 21; nd++) {
                 node_geom(nd, &nx[nd], &ny[nd], &nl[nd]);
@@ -738,6 +762,7 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                     for (int dx = -R; dx < -R + spanx; dx++) {
                         uint32_t s = 0;
                         int p = (dy + R) * spanx + dx + R;
+                        if ((mct || mcb) && !mv_rows_ok(y0 + ny[nd], 1 << nl[nd], 4 * (sy + dy), h, mct, mcb)) continue;
                         if (nd == 0) for (int b = 0; b < 16; b++) s += sad8[b * spanx * spany + p];
                         else if (nd < 5) for (int b = 0; b < 4; b++) s += sad8[((nd - 1) * 4 + b) * spanx * spany + p];
                         else s = sad8[(nd - 5) * spanx * spany + p];
@@ -799,6 +824,7 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                     uint64_t best = ((uint64_t)cbest << 4) | 0;
                     for (int k = 0; k < 8; k++) {
                         int tx = cmx + kFracOff[k][0] * step, ty = cmy + kFracOff[k][1] * step;
+                        if ((mct || mcb) && !mv_rows_ok(by, n, ty, h, mct, mcb)) continue;
                         orc_interp_luma(ref_y, ref_stride, bx, by, tx, ty, n, n, bd, pred, n);
                         uint32_t c = ((uint32_t)orc_satd(s, src_stride, pred, n, n, n) << 4) +
                                      (uint32_t)(lam * (orc_mvd_bits(tx - 4 * sx) + orc_mvd_bits(ty - 4 * sy)));

@@ -73,6 +73,7 @@ typedef struct {
     int pre_search;           /* 1: when no search centres are given, take them from a +-14 full search on the 1/4-size pictures (+-56 samples) */
     int rdo_zero;             /* 1: an inter TU whose levels cost more (lambda * bits) than the distortion they remove is coded as all-zero */
     int chroma_modes;         /* 1: 2Nx2N intra CUs choose intra_chroma_pred_mode among planar / vertical / horizontal / DC / DM by SATD */
+    int mc_top, mc_bottom;    /* 1: the picture is a slice whose upper / lower neighbour is coded elsewhere: motion compensation must not read across that edge */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */

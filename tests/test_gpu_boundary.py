@@ -111,3 +111,51 @@ def test_sharded_encode_cancel_and_worker_failure_leave_nothing_behind(lib, tmp_
     monkeypatch.undo()
     res = T.convert_video(p, tmp_path, skip_validator=True, devices=[0, 0])     # and the device is fine afterwards
     assert res["status"] == "SUCCESS" and res["method"] == "MI355X"
+
+
+@pytest.mark.parametrize("w,h,bd,n_slices,level,rc", [(544, 320, 8, 3, 120, 0), (320, 200, 10, 2, 93, 1), (160, 96, 8, 2, 63, 1)])
+def test_one_picture_as_slices_over_several_sessions(lib, w, h, bd, n_slices, level, rc):
+    """BASELINE configs[4] with the devices [0, 0(, 0)]: every picture is cut into bands of CTU rows, one session per band, one slice each; the
+    merged stream is decoded by the oracle decoder as ordinary pictures and must equal the bands' reconstructions stacked — which also proves
+    that no motion vector reached across a band's edge (the decoder would have read the neighbour's samples, the encoder its own border)."""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import SlicedEncoder, slice_rows
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.bit_depth, cfg.level_idc, cfg.keyint, cfg.min_keyint, cfg.me_range, cfg.gops_in_flight, cfg.aud = w, h, bd, level, 4, 2, 12, 2, 1
+    if rc:
+        cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = 20, -1, 400, 480
+    else:
+        cfg.qp = 27
+    n = 10
+    frames = [util.synth_frame(h, w, seed=5, shift=(2 * i, 7 * i), bit_depth=bd) for i in range(n)]      # 7 rows of vertical motion per picture
+    sl = SlicedEncoder(cfg, [0] * n_slices, keep_recon=True)
+    try:
+        assert sl.rows == slice_rows(h, n_slices) and len(sl.rows) == n_slices
+        got = []
+        for f in frames:
+            sl.send(*util.planes(f, bd))
+            got += sl.ready()
+        got += sl.finish()
+        recs = [O.Frame(*sl.recon(i)) for i in range(n)]
+        stats = sl.stats()
+    finally:
+        sl.close()
+    assert [p for _, p, _ in got] == list(range(n)) and [k for _, _, k in got] == [i % 4 == 0 for i in range(n)]
+    dec, info = O.decode(b"".join(d for d, _, _ in got))
+    assert len(dec) == n and info["count.slices"] == n * n_slices and info["count.aud"] == n and (info["width"], info["conf_height"]) == (w, h)
+    for i in range(n):
+        d = O.Frame(dec[i].y[:recs[i].y.shape[0]], dec[i].u[:recs[i].u.shape[0]], dec[i].v[:recs[i].v.shape[0]])
+        assert d.same(recs[i]), f"picture {i}: decoded picture != the slices' reconstructions"
+        assert util.psnr(dec[i].y[:h], frames[i].y, peak=(1 << bd) - 1.0) > 24.0          # sanity only: 400 kb/s caps
+    assert all(st.frames_out == n for st in stats)
+    if w >= 512:
+        assert info["pps.tile_cols"] == 2 and info["pps.tile_rows"] >= n_slices        # IDR pictures: tiles inside every slice
+
+
+def test_convert_video_with_row_split(lib, tmp_path):
+    from hevc_amd import mp4, transcoder as T
+    p, frames = _clip(tmp_path, "rows.y4m", 320, 192, 9)
+    res = T.convert_video(p, tmp_path, skip_validator=True, devices=[0, 0], row_split=True)
+    assert res["status"] == "SUCCESS" and res["method"] == "MI355X"
+    top = mp4.parse_boxes((tmp_path / "rows.mp4").read_bytes())
+    assert [b[0] for b in top] == ["ftyp", "moov", "mdat"]
