@@ -18,7 +18,7 @@ from hevc_amd.yuvio import SyntheticClip                     # noqa: E402
 def run(w, h, n, hdr, repeats=2):
     tags = ("bt2020", "smpte2084", "bt2020nc", "yuv420p10le") if hdr else ("bt709", "bt709", "bt709", "yuv420p")
     info = VideoInfo(w, h, 30.0, *tags, "", "", 0, hdr, "eng", n, n / 30.0)
-    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info, use_nvenc=False)
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info)
     level, tier = calculate_apple_hevc_level(info)
     cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
     cfg.profile_stages = 1
@@ -46,8 +46,34 @@ def run(w, h, n, hdr, repeats=2):
     return best
 
 
+def run_sliced(w, h, n, n_slices):
+    """BASELINE configs[4] geometry with every slice's session on device 0: functional and a one-GPU time, NOT a scaling number"""
+    from hevc_amd.encoder import SlicedEncoder
+    info = VideoInfo(w, h, 30.0, "bt2020", "smpte2084", "bt2020nc", "yuv420p10le", "", "", 0, True, "eng", n, n / 30.0)
+    crf, _cq, maxrate, bufsize, gop = calculate_dynamic_values(info)
+    level, tier = calculate_apple_hevc_level(info)
+    cfg = config_for(info, crf, maxrate, bufsize, gop, level, tier)
+    frames = list(SyntheticClip("motion", 0, w, h, n, bit_depth=10).frames())
+    t0 = time.perf_counter()
+    sl = SlicedEncoder(cfg, [0] * n_slices)
+    try:
+        nbytes = 0
+        for y, u, v in frames:
+            sl.send(y, u, v)
+            nbytes += sum(len(d) for d, _p, _k in sl.ready())
+        nbytes += sum(len(d) for d, _p, _k in sl.finish())
+        sse = sum(st.sse_y for st in sl.stats())
+    finally:
+        sl.close()
+    dt = time.perf_counter() - t0
+    psnr = 10 * np.log10(1023.0 ** 2 / (sse / (n * w * h)))
+    return {"size": f"{w}x{h}", "slices": sl.rows, "frames": n, "fps_pcie_inclusive_all_slices_on_one_gpu": round(n / dt, 1),
+            "bitrate_kbps": round(nbytes * 8 / (n / 30.0) / 1e3, 1), "target_kbps": maxrate, "psnr_y_db": round(float(psnr), 2)}
+
+
 out = {"720p8_host_buffers": run(1280, 720, 300, False), "1080p8_host_buffers": run(1920, 1080, 300, False),
        "2160p10_hdr10_host_buffers": run(3840, 2160, 120, True)}
 if len(sys.argv) > 1 and sys.argv[1] == "8k":
     out["4320p10_hdr10_host_buffers_one_gpu"] = run(7680, 4320, 60, True, repeats=1)
+    out["4320p10_hdr10_8_slices_on_ONE_gpu"] = run_sliced(7680, 4320, 30, 8)
 print(json.dumps(out))
