@@ -39,6 +39,10 @@ constexpr int MAX_LANES = 16;
 struct StepParams { CostParams prm[MAX_LANES]; };      // one P step's cost parameters per lane, passed by value
 template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch);
 
+// scene-cut detector input: luma plane of one source picture
+template <typename T> struct ScenePic { const T *p; int stride; };
+template <typename T> hipError_t launch_scene_diff(hipStream_t st, const ScenePic<T> *pics, unsigned long long *out, int w, int h, int n);
+
 template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p, int sw, int sh, int pw, int ph);
 
 int gfx950_device_count();

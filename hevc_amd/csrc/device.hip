@@ -163,6 +163,29 @@ template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p
     return hipGetLastError();
 }
 
+// scene-cut detector: sum of |a - b| over every 4th sample of every 4th row of the luma planes of pictures blockIdx.y - 1... the pair
+// (blockIdx.y, blockIdx.y + 1) -> out[blockIdx.y + 1]; wave reduction by shuffles, one atomic per wave
+template <typename T> __global__ __launch_bounds__(256) void k_scene_diff(const ScenePic<T> *pics, unsigned long long *out, int w, int h)
+{
+    const ScenePic<T> a = pics[blockIdx.y], b = pics[blockIdx.y + 1];
+    const int qw = (w + 3) >> 2, nq = qw * ((h + 3) >> 2);
+    unsigned acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+        const int x = (i % qw) * 4, y = (i / qw) * 4;
+        const int d = (int)a.p[(ptrdiff_t)y * a.stride + x] - (int)b.p[(ptrdiff_t)y * b.stride + x];
+        acc += (unsigned)(d < 0 ? -d : d);
+    }
+    unsigned long long v = acc;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out + blockIdx.y + 1, v);
+}
+template <typename T> hipError_t launch_scene_diff(hipStream_t st, const ScenePic<T> *pics, unsigned long long *out, int w, int h, int n)
+{
+    if (n < 2) return hipSuccess;
+    hipLaunchKernelGGL(k_scene_diff<T>, dim3(32, (unsigned)(n - 1)), dim3(256), 0, st, pics, out, w, h);
+    return hipGetLastError();
+}
+
 // sum of squared error between source and final reconstruction, per plane (encoder PSNR statistics)
 template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const SaoArgs<T> *args)
 {
@@ -348,6 +371,7 @@ int gfx950_device_count()
     template hipError_t launch_frame_sse<T>(hipStream_t, const SaoArgs<T> *, int);                                       \
     template hipError_t launch_begin_p_step<T>(hipStream_t, IntraArgs<T> *, InterArgs<T> *, SaoArgs<T> *, const StepParams &, int); \
     template hipError_t launch_extend_margin<T>(hipStream_t, Plane<T>, int, int, int, int);                             \
+    template hipError_t launch_scene_diff<T>(hipStream_t, const ScenePic<T> *, unsigned long long *, int, int, int);            \
     template hipError_t alloc_plane<T>(DevPlane<T> &, int, int, int);                                                   \
     template void free_plane<T>(DevPlane<T> &);
 INSTANTIATE(uint8_t)

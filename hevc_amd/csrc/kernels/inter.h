@@ -164,6 +164,7 @@ template <typename T> struct MeShared {
     uint8_t src[32 * 32];
     unsigned long long best[21];
     uint8_t valid[21];
+    unsigned nodeok[2 * MAX_RANGE + 1];   // motion-constrained slices: bit n of word dy = vertical displacement index dy keeps node n's rows inside the slice
     // followed in LDS by the search window: uint8_t win[(32 + 2R) * wstride]
 };
 HDI int me_spanx(int R) { return ((2 * R + 1) + 3) & ~3; }   // horizontal positions, rounded up to whole quads
@@ -244,21 +245,28 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
             s.valid[tid] = x0 + nx + (1 << nl) <= a.w && y0 + ny + (1 << nl) <= a.h;
             s.best[tid] = ~0ull;
         }
+        if (mct || mcb)
+            for (int dyi = tid; dyi < spany; dyi += NT) {
+                unsigned bits = 0;
+                for (int n = 0; n < 21; n++) {
+                    int nx, ny, nl;
+                    node_geom(n, nx, ny, nl);
+                    if (mv_rows_ok(y0 + ny, 1 << nl, 4 * (sy + dyi - R), a.h, mct, mcb)) bits |= 1u << n;
+                }
+                s.nodeok[dyi] = bits;
+            }
     });
     ex.phase([&](int tid) {
         // a node's candidate goes straight to the workgroup's LDS minimum (filtered by a plain read first), so no
         // per-thread table of 21 running minima has to stay in registers across the unrolled SAD code
-        auto consider = [&](int node, unsigned cost, unsigned p, int dy_total) {
+        auto consider = [&](int node, unsigned cost, unsigned p, unsigned ok) {
             unsigned long long key = ((unsigned long long)cost << 16) | p;
-            if ((mct || mcb) && s.valid[node]) {      // a slice: the candidate must keep the node's rows inside it (all four positions of a quad share dy)
-                int nx, ny, nl;
-                node_geom(node, nx, ny, nl);
-                if (!mv_rows_ok(y0 + ny, 1 << nl, 4 * dy_total, a.h, mct, mcb)) return;
-            }
+            if (!((ok >> node) & 1)) return;       // a slice: the candidate must keep the node's rows inside it (all four positions of a quad share dy)
             if (s.valid[node] && key < s.best[node]) ex.atomic_min(&s.best[node], key);
         };
         for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
             const int q = item % quads, dyi = item / quads;
+            const unsigned ok = (mct || mcb) ? s.nodeok[dyi] : ~0u;
             const int by = mvd_bits(4 * (dyi - R));
             const uint8_t *srcp = s.src + opaque_zero();      // keep the 1 KiB source tile in LDS (hoisted into 256 VGPRs otherwise)
             unsigned bits[4], pos[4], s32[4] = {0, 0, 0, 0};
@@ -289,7 +297,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                             unsigned long long kj = ((unsigned long long)((o[b][j] << 4) + bits[j]) << 16) | pos[j];
                             k = kj < k ? kj : k;
                         }
-                        consider(node, (unsigned)(k >> 16), (unsigned)(k & 0xffff), sy + dyi - R);
+                        consider(node, (unsigned)(k >> 16), (unsigned)(k & 0xffff), ok);
                     }
                 }
 #pragma unroll
@@ -301,7 +309,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                         unsigned long long kj = ((unsigned long long)((s16[h2][j] << 4) + bits[j]) << 16) | pos[j];
                         k = kj < k ? kj : k;
                     }
-                    consider(1 + half * 2 + h2, (unsigned)(k >> 16), (unsigned)(k & 0xffff), sy + dyi - R);
+                    consider(1 + half * 2 + h2, (unsigned)(k >> 16), (unsigned)(k & 0xffff), ok);
                 }
             }
             unsigned long long k = ~0ull;
@@ -310,7 +318,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                 unsigned long long kj = ((unsigned long long)((s32[j] << 4) + bits[j]) << 16) | pos[j];
                 k = kj < k ? kj : k;
             }
-            consider(0, (unsigned)(k >> 16), (unsigned)(k & 0xffff), sy + dyi - R);
+            consider(0, (unsigned)(k >> 16), (unsigned)(k & 0xffff), ok);
         }
     });
     ex.phase([&](int tid) {

@@ -40,6 +40,8 @@ constexpr int kIdrRedo = 2;
 constexpr double kBudgetShare = 0.985;   // a GOP is planned to 98.5 % of vbv-maxrate x its duration: the estimate-to-CABAC ratio is known to ~1 %
 constexpr double kCpbStart = 0.9;        // CPB fullness every closed GOP may assume at its IDR (= the buffering period SEI's initial delay)
 constexpr double kIdrCpbShare = 0.85;    // an IDR picture may take at most this share of that fullness
+constexpr double kCutAbs = 8.0;          // scene cut: mean absolute difference of consecutive pictures above this many grey levels (8-bit scale) ...
+constexpr double kCutRatio = 1.8;        // ... and this many times the running mean over the ordinary pictures before it
 
 class ThreadPool {
 public:
@@ -154,7 +156,7 @@ struct mihevc_session {
     std::string err;
     hipStream_t st_compute = nullptr, st_copy = nullptr;
     // source pictures of the current chunk (device), in display order
-    struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; };
+    struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; bool borrowed; };      // borrowed: the caller's device planes, not copied
     size_t plane_bytes[2][3] = {{0}};   // [padded][plane] allocation sizes (for the buffer cache)
     std::vector<Src> pending;
     std::vector<Src> free_src;
@@ -194,6 +196,9 @@ struct mihevc_session {
     bool rho_measured = false;                // the session's first chunk measures rho with a trial analysis of the GOPs' first P picture
     double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
     int idr_qp_hint = -1;                     // mean IDR QP the last chunk settled on: where the next chunk's IDR analysis starts
+    int last_gop_len = 0;                     // length of the stream's previous GOP (picture timing SEI at the next IDR)
+    double scene_avg = 0;                     // running mean of the picture-to-picture difference over ordinary pictures (scene-cut detector)
+    void *d_scene = nullptr; size_t scene_cap = 0;   // per chunk: picture pointers / pitches in, difference sums out (k_scene_diff)
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
     std::atomic<long long> entropy_ns{0};
@@ -285,7 +290,7 @@ template <typename T> Plane<T> mk(void *p, int stride) { return Plane<T>{(T *)p,
 template <typename T> Plane<const T> mkc(void *p, int stride) { return Plane<const T>{(const T *)p, stride}; }
 
 // CABAC job: wait for the step's copy, code the picture, publish the packet
-void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t pts, int slice_type, int poc, int qp, bool first_of_stream)
+void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t pts, int slice_type, int poc, int qp, bool first_of_stream, int prev_gop_len)
 {
     auto t0 = std::chrono::steady_clock::now();
     SymLayout sl(s->w, s->h);
@@ -306,7 +311,7 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
     if (s->cfg.hrd && au_head) {
         if (slice_type == 2) write_sei_buffering_period(s->cfg, pk.data);
         // clock ticks since the previous buffering period: position in the GOP, or the previous GOP's length at an IDR
-        write_sei_pic_timing(s->cfg, (uint32_t)(poc > 0 ? poc - 1 : (index > 0 ? s->keyint - 1 : 0)), pk.data);
+        write_sei_pic_timing(s->cfg, (uint32_t)(poc > 0 ? poc - 1 : (index > 0 ? prev_gop_len - 1 : 0)), pk.data);
     }
     encode_picture(s->cfg, pic, pk.data, false);
     const unsigned long long *sse = (const unsigned long long *)(b + sl.sse);
@@ -330,14 +335,64 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
     s->cv.notify_all();
 }
 
+// sum of |a - b| over every 4th sample of every 4th row of consecutive pending source pictures: out[i] for the pair (i - 1, i), out[0] = 0
+template <typename T> int scene_differences(mihevc_session *s, int n, std::vector<unsigned long long> &out)
+{
+    const size_t in_bytes = (size_t)n * sizeof(ScenePic<T>), need = ((in_bytes + 255) & ~(size_t)255) + (size_t)n * sizeof(unsigned long long);
+    if (need > s->scene_cap) {
+        if (s->d_scene) (void)hipFree(s->d_scene);
+        HIPCK(s, hipMalloc(&s->d_scene, need));
+        s->scene_cap = need;
+    }
+    std::vector<ScenePic<T>> pics((size_t)n);
+    for (int i = 0; i < n; i++) pics[(size_t)i] = ScenePic<T>{(const T *)s->pending[(size_t)i].p[0], s->pending[(size_t)i].stride[0]};
+    unsigned long long *d_out = (unsigned long long *)((uint8_t *)s->d_scene + ((in_bytes + 255) & ~(size_t)255));
+    HIPCK(s, hipMemcpyAsync(s->d_scene, pics.data(), in_bytes, hipMemcpyHostToDevice, s->st_compute));
+    HIPCK(s, hipMemsetAsync(d_out, 0, (size_t)n * sizeof(unsigned long long), s->st_compute));
+    HIPCK(s, launch_scene_diff<T>(s->st_compute, (const ScenePic<T> *)s->d_scene, d_out, s->w, s->h, n));
+    HIPCK(s, hipMemcpyAsync(out.data(), d_out, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st_compute));
+    HIPCK(s, hipStreamSynchronize(s->st_compute));
+    return 0;
+}
+
 template <typename T> int encode_chunk(mihevc_session *s)
 {
     const int n = (int)s->pending.size();
     if (!n) return 0;
-    const int gops = (n + s->keyint - 1) / s->keyint;
+    // ---- GOP layout of the chunk: an IDR every keyint pictures, and earlier where the picture changes (x265 scenecut + min-keyint, reference
+    //      core/transcoder.py:401).  The cut detector is the mean absolute difference of every 4th sample of every 4th row between consecutive
+    //      source pictures (k_scene_diff, one launch for the chunk): a cut is a difference above kCutAbs grey levels that is also kCutRatio times the
+    //      running mean over the ordinary pictures before it, at least min-keyint pictures after the last IDR.  Closed GOPs stay independent, so a GOP simply ends there.
+    std::vector<int> gstart_stream{0};
+    if (s->cfg.scenecut && n > 1 && s->cfg.min_keyint < s->keyint) {
+        std::vector<unsigned long long> diff((size_t)n, 0);
+        if (int e = scene_differences<T>(s, n, diff)) return e;
+        const double per = (double)((s->w + 3) / 4) * ((s->h + 3) / 4) * (1 << (s->cfg.bit_depth - 8));
+        for (int i = 1; i < n; i++) {
+            const double d = (double)diff[(size_t)i] / per;
+            const int since = i - gstart_stream.back();
+            const bool jump = d > kCutAbs && s->scene_avg > 0 && d > kCutRatio * s->scene_avg;
+            const bool cut = jump && since >= std::max(1, s->cfg.min_keyint) && (int)gstart_stream.size() < MAX_LANES - (n - i + s->keyint - 1) / s->keyint;
+            if (cut || since >= s->keyint) gstart_stream.push_back(i);
+            if (!jump) s->scene_avg = s->scene_avg > 0 ? 0.8 * s->scene_avg + 0.2 * d : d;      // ordinary pictures only: a jump says nothing about the new scene's motion
+        }
+    } else
+        for (int i = s->keyint; i < n; i += s->keyint) gstart_stream.push_back(i);
+    const int gops = (int)gstart_stream.size();
+    // lanes by GOP length, longest first: the lanes that still have a picture at step t are then a prefix [0, batch[t])
+    std::vector<int> order((size_t)gops), gstart((size_t)gops), glen((size_t)gops), prev_len((size_t)gops);
+    for (int g = 0; g < gops; g++) order[(size_t)g] = g;
+    auto len_of = [&](int k) { return (k + 1 < gops ? gstart_stream[(size_t)k + 1] : n) - gstart_stream[(size_t)k]; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return len_of(a) > len_of(b); });
+    for (int g = 0; g < gops; g++) {
+        const int k = order[(size_t)g];
+        gstart[(size_t)g] = gstart_stream[(size_t)k]; glen[(size_t)g] = len_of(k);
+        prev_len[(size_t)g] = k > 0 ? len_of(k - 1) : s->last_gop_len;
+    }
+    s->last_gop_len = len_of(gops - 1);
     if (int e = ensure_lanes(s, gops)) return e;
     SymLayout sl(s->w, s->h);
-    const int steps = std::min(n, s->keyint);
+    const int steps = glen[0];
     const int ring = s->ring;
     auto slot_of = [ring](int t) { return t == 0 ? 0 : 1 + (t - 1) % (ring - 1); };
     // ---- build every step's argument blocks, upload once ----
@@ -365,9 +420,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
     std::vector<int> batch(steps, 0);
     for (int t = 0; t < steps; t++)
         for (int g = 0; g < gops; g++) {
-            int fi = g * s->keyint + t;
-            if (fi >= n) continue;
-            // lanes with a picture at step t are a prefix [0, batch) because only the last GOP can be short
+            if (t >= glen[(size_t)g]) continue;
+            int fi = gstart[(size_t)g] + t;
+            // lanes with a picture at step t are a prefix [0, batch): they are sorted by GOP length
             batch[t] = g + 1;
             mihevc_session::Lane &L = s->lane[g];
             mihevc_session::Src &src = s->pending[fi];
@@ -428,7 +483,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     std::vector<int> qp_prev(gops, s->qp_p), gop_len(gops, 0);
     std::vector<double> budget(gops, 0.0);
     for (int g = 0; g < gops; g++) {
-        gop_len[g] = std::min(s->keyint, n - g * s->keyint);
+        gop_len[g] = glen[(size_t)g];
         budget[g] = kBudgetShare * share * s->cfg.vbv_maxrate_kbps * 1000.0 * gop_len[g] / fps;
     }
     const double cpb_idr_cap = s->cfg.vbv_bufsize_kbits > 0 ? kIdrCpbShare * kCpbStart * share * s->cfg.vbv_bufsize_kbits * 1000.0 : 1e30;
@@ -439,7 +494,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     // it (+3 / -1 per picture, dead band 0.75): a constant QP is what the budget buys the most PSNR with.
     auto decide_p = [&](int g, int t) -> int {
         std::lock_guard<std::mutex> l(s->m);
-        auto frame = [&](int j) -> mihevc_session::FrameRec & { return s->frames[(size_t)(first_index + g * s->keyint + j)]; };
+        auto frame = [&](int j) -> mihevc_session::FrameRec & { return s->frames[(size_t)(first_index + gstart[(size_t)g] + j)]; };
         // CABAC / estimate ratio of this GOP's finished P pictures, seeded with two pictures' worth of the session ratio
         double sum_b = 0, sum_e = 0, seed = 0;
         for (int j = 1; j <= t - p_slots; j++)
@@ -484,7 +539,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         hv.intra[g].prm = hv.inter[g].prm = hv.sao[g].prm = prm_for(qp);
         if (t > 0) { hv.intra[g].prm.tile_cols = hv.intra[g].prm.tile_rows = 1; }
         std::lock_guard<std::mutex> l(s->m);
-        auto &fr = s->frames[(size_t)(first_index + g * s->keyint + t)];
+        auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + t)];
         fr.qp = qp; fr.type = t == 0 ? 2 : 1;
     };
     // ---- lock-step over the GOPs ----
@@ -517,7 +572,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             {
                 std::lock_guard<std::mutex> l(s->m);
                 for (int g = 0; g < batch[j]; g++) {
-                    auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
+                    auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + j)];
                     if (!fr.est_known) { fr.est_q4 = *(const unsigned long long *)(s->lane[g].sym_host[slot_of(j)] + sl.est); fr.est_known = true; }
                 }
             }
@@ -626,7 +681,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     qp_prev[g] = qp_step[g];
                     sum_q += qp_step[g];
                     std::lock_guard<std::mutex> l(s->m);
-                    auto &fr = s->frames[(size_t)(first_index + g * s->keyint)];
+                    auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g])];
                     fr.est_q4 = ev[(size_t)g]; fr.est_known = true;
                 }
                 s->idr_qp_hint = (sum_q + B / 2) / B;
@@ -660,7 +715,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         if (s->keep_recon) {
             for (int g = 0; g < B; g++) {
-                int fi = g * s->keyint + t;
+                int fi = gstart[(size_t)g] + t;
                 std::vector<uint16_t> &dst = s->recon[s->frames_in - n + fi];
                 dst.assign((size_t)s->w * s->h * 3 / 2, 0);
                 std::vector<uint8_t> tmp((size_t)s->w * s->h * 3 / 2 * esize(s));
@@ -681,16 +736,17 @@ template <typename T> int encode_chunk(mihevc_session *s)
             for (int g = 0; g < B; g++) s->jobs_open[lane_slot[g]]++;
         }
         for (int g = 0; g < B; g++) {
-            int fi = g * s->keyint + t;
+            int fi = gstart[(size_t)g] + t;
             int64_t index = s->frames_in - n + fi, pts = s->pending[fi].pts;
+            const int pgl = prev_len[(size_t)g];
             const int slot = lane_slot[g];
             hipEvent_t ev = s->ev_copy[slot];
             int st = t == 0 ? 2 : 1, qp = qp_step[g];
             bool first = index == 0;
-            s->pool->submit([s, slot, g, index, pts, st, t, qp, first, ev] {
+            s->pool->submit([s, slot, g, index, pts, st, t, qp, first, ev, pgl] {
                 (void)hipSetDevice(s->device);          // worker threads start on device 0: wait on the event in its own device's context
                 (void)hipEventSynchronize(ev);
-                entropy_job(s, slot, g, index, pts, st, t, qp, first);
+                entropy_job(s, slot, g, index, pts, st, t, qp, first, pgl);
             });
         }
     }
@@ -720,11 +776,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
         double bi = 0, ei = 0, bp = 0, ep = 0, lg = 0;
         int np = 0;
         for (int g = 0; g < gops; g++) {
-            const auto &idr = s->frames[(size_t)(first_index + g * s->keyint)];
+            const auto &idr = s->frames[(size_t)(first_index + gstart[(size_t)g])];
             if (idr.bits < 0 || !idr.est_q4) continue;
             bi += (double)idr.bits; ei += (double)idr.est_q4 / 16.0;
             for (int j = 1; j < gop_len[g]; j++) {
-                const auto &fr = s->frames[(size_t)(first_index + g * s->keyint + j)];
+                const auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + j)];
                 if (fr.bits <= 0 || !fr.est_q4) continue;
                 bp += (double)fr.bits; ep += (double)fr.est_q4 / 16.0;
                 lg += std::log2((double)fr.bits / (double)idr.bits) + (fr.qp - idr.qp) / 6.0;
@@ -735,7 +791,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (ep > 0) s->ratio_p = 0.5 * s->ratio_p + 0.5 * bp / ep;
         if (np) s->rho_pi = std::min(1.0, std::max(1.0 / 256, 0.5 * s->rho_pi + 0.5 * std::exp2(lg / np)));
     }
-    for (auto &src : s->pending) s->free_src.push_back(src);
+    for (auto &src : s->pending) if (!src.borrowed) s->free_src.push_back(src);
     s->pending.clear();
     return 0;
 }
@@ -811,10 +867,23 @@ static int ingest(mihevc_session *s, const void *y, const void *u, const void *v
     if (s->flushed) return MIHEVC_ESTATE;
     if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
     mihevc_session::Src src;
-    if (int e = get_src(s, src)) return e;
-    src.pts = pts;
     const void *in[3] = {y, u, v};
     const size_t es = esize(s);
+    // Device planes whose size already is the coded size (no margin to fill) are used where they are: the header's contract keeps them valid and
+    // unmodified until the picture's packet is out.  Saves three 2-D copies per frame (4 % of the device time of a 1080p clip, and most of the
+    // wall time of handing 300 frames over).
+    if (device_src && s->cfg.width == s->w && s->cfg.height == s->h && pitch_y >= s->w && pitch_c >= s->w / 2 &&
+        ((uintptr_t)y & 3) == 0 && ((uintptr_t)u & 3) == 0 && ((uintptr_t)v & 3) == 0 && (pitch_y * es) % 4 == 0 && (pitch_c * es) % 4 == 0) {
+        for (int i = 0; i < 3; i++) { src.base[i] = nullptr; src.p[i] = const_cast<void *>(in[i]); src.stride[i] = i ? pitch_c : pitch_y; }
+        src.pts = pts; src.borrowed = true;
+        s->pending.push_back(src);
+        s->frames_in++;
+        s->stats.frames_in = s->frames_in;
+        if ((int)s->pending.size() >= s->lanes * s->keyint) return run_chunk(s);
+        return MIHEVC_OK;
+    }
+    if (int e = get_src(s, src)) return e;
+    src.pts = pts; src.borrowed = false;
     for (int i = 0; i < 3; i++) {
         int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h;               // coded plane size
         int sw = i ? s->cfg.width / 2 : s->cfg.width, sh = i ? s->cfg.height / 2 : s->cfg.height, pitch = i ? pitch_c : pitch_y;
@@ -942,7 +1011,7 @@ void mihevc_close(mihevc_session *s)
     BufferCache &bc = BufferCache::get();
     SymLayout sl(s->w, s->h);
     auto free3 = [&](void *b[3], int padded) { for (int i = 0; i < 3; i++) bc.release(s->device, s->plane_bytes[padded][i], false, b[i]); };
-    for (auto &x : s->pending) free3(x.base, 0);
+    for (auto &x : s->pending) if (!x.borrowed) free3(x.base, 0);
     for (auto &x : s->free_src) free3(x.base, 0);
     for (auto &L : s->lane) {
         free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
@@ -955,6 +1024,7 @@ void mihevc_close(mihevc_session *s)
         for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     if (s->d_args) (void)hipFree(s->d_args);
+    if (s->d_scene) (void)hipFree(s->d_scene);
     if (s->h_args) (void)hipHostFree(s->h_args);
     for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);

@@ -106,9 +106,9 @@ class Encoder:
         dt = np.uint8 if c.bit_depth == 8 else np.uint16
         if y.shape != (c.height, c.width) or u.shape != (c.height // 2, c.width // 2) or v.shape != u.shape:
             raise ValueError(f"plane shapes {y.shape}/{u.shape}/{v.shape} do not match the session's {c.width}x{c.height} 4:2:0")
-        for p in (y, u, v):
-            if p.dtype.itemsize > np.dtype(dt).itemsize:
-                raise ValueError(f"{p.dtype} samples handed to a {c.bit_depth}-bit session (open it with bit_depth 10 or down-convert first)")
+        for p in (y, u, v):            # a wider container is fine as long as the VALUES fit (tests keep 8-bit pictures in uint16 arrays)
+            if p.dtype.itemsize > np.dtype(dt).itemsize and p.size and int(p.max()) >> c.bit_depth:
+                raise ValueError(f"{p.dtype} samples up to {int(p.max())} handed to a {c.bit_depth}-bit session (open it with bit_depth 10 or down-convert first)")
         y, u, v = (np.ascontiguousarray(p, dtype=dt) for p in (y, u, v))
         pts = self._pts if pts is None else pts
         self._pts = pts + 1

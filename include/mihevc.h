@@ -86,6 +86,8 @@ typedef struct mihevc_config {
     int32_t slice_count, slice_index;
     int32_t slice_ctu_rows[16];       /* CTU rows of every slice, top to bottom (sum = ceil(pic_height / 32)) */
     int32_t rate_share_q16;           /* share of vbv-maxrate / vbv-bufsize this slice plans with, 65536 = all (0 = all) */
+    int32_t scenecut;                 /* 1 (default): an IDR picture where the picture changes (mean absolute difference of consecutive source pictures),
+                                       * at least min_keyint pictures after the last one (x265 scenecut / min-keyint); 0: IDR every keyint pictures only */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -115,7 +117,8 @@ int  mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const vo
  * into the session's own pitch-aligned picture is ENQUEUED on the session's stream and the call returns before it has run, and it is not
  * ordered against any stream of the caller.  So (1) the producer of y/u/v must have finished before the call (synchronise its stream or
  * event first), and (2) the three planes must stay valid and unmodified until the picture's packet has been received, or mihevc_flush
- * has returned, whichever comes first (host buffers of mihevc_send_frame may be reused as soon as that call returns). */
+ * has returned, whichever comes first (host buffers of mihevc_send_frame may be reused as soon as that call returns).  When the display size
+ * already is the coded size (multiples of 8) and planes / pitches are 4-byte aligned the session codes straight from the caller's planes. */
 int  mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, const void *v,
                               int pitch_y, int pitch_c, int64_t pts);
 /* One access unit (Annex-B NAL units) in session-owned memory, valid until the next receive/close. */

@@ -159,3 +159,46 @@ def test_convert_video_with_row_split(lib, tmp_path):
     assert res["status"] == "SUCCESS" and res["method"] == "MI355X"
     top = mp4.parse_boxes((tmp_path / "rows.mp4").read_bytes())
     assert [b[0] for b in top] == ["ftyp", "moov", "mdat"]
+
+
+def test_scene_cuts_start_a_gop_and_min_keyint_holds(lib):
+    """x265 scenecut + min-keyint (reference core/transcoder.py:401: keyint / min-keyint reach the encoder): IDR pictures where the content changes,
+    never closer than min_keyint to the last one, and every keyint pictures otherwise; the stream still decodes to the encoder reconstruction, and
+    the cut costs far fewer bits as an IDR than as a P picture predicted from the wrong scene."""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder
+    w, h, n = 192, 128, 40
+    cuts = [7, 9, 22]                       # 9 is 2 pictures after 7: inside min_keyint, must stay a P picture
+    frames, scene = [], 0
+    for i in range(n):
+        if i in cuts:
+            scene += 1
+        frames.append(util.synth_frame(h, w, seed=40 + scene, shift=(i, i // 2)))
+
+    def encode(scenecut):
+        cfg = _lib.default_config()
+        cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.me_range, cfg.gops_in_flight, cfg.qp, cfg.scenecut = w, h, 16, 4, 8, 2, 28, scenecut
+        stream = b""
+        with Encoder(cfg, device=0, keep_recon=True) as enc:
+            for f in frames:
+                enc.send(*util.planes(f, 8))
+            enc.flush()
+            sizes = []
+            for data, pts, key in enc.packets():
+                stream += data
+                sizes.append(len(data))
+            types = [enc.frame_info(i)[1] for i in range(n)]
+            recs = [O.Frame(*enc.recon(i)) for i in range(n)]
+        dec, _ = O.decode(stream)
+        assert len(dec) == n and all(d.same(r) for d, r in zip(dec, recs))
+        return [i for i, t in enumerate(types) if t == 2], sum(sizes), recs
+
+    idr_on, bytes_on, recs_on = encode(1)
+    idr_off, bytes_off, recs_off = encode(0)
+    # chunks are gops_in_flight x keyint = 32 pictures: IDR at 0 (chunk), 7 (cut), 22 (cut: 9 is too close to 7), 23 = 7 + 16 is not needed
+    # because the cut at 22 restarted the count; 32 opens the next chunk
+    assert idr_off == [0, 16, 32]
+    assert idr_on == [0, 7, 22, 32], idr_on
+    assert bytes_on < 0.95 * bytes_off
+    psnr = lambda recs: float(np.mean([util.psnr(r.y, f.y) for r, f in zip(recs, frames)]))     # noqa: E731
+    assert psnr(recs_on) > psnr(recs_off) - 0.1
