@@ -923,7 +923,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             }
             for (int sb = tid; sb < 96; sb += NT) {       // level bits per 4x4 sub-block, summed per TU
                 int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
-                int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
+                int per = pl ? 4 : 8, bx = (k & (per - 1)) * 4, by = (k >> (pl ? 2 : 3)) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
                 SampleLoc l = locate(s.rs, base + by * stride + bx);
                 if (!l.log2n || !((s.rs.cbf[l.plane] >> l.tile0) & 1)) continue;
                 int b = subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
@@ -969,7 +969,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             unsigned e = 0;
             for (int sb = tid; sb < 96; sb += NT) {
                 int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
-                int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0, sh = pl ? 2 : 3;
+                int per = pl ? 4 : 8, bx = (k & (per - 1)) * 4, by = (k >> (pl ? 2 : 3)) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0, sh = pl ? 2 : 3;
                 if (s.rs.tu_log2[(by >> sh) * 4 + (bx >> sh)]) e += (unsigned)subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
             }
             if (tid < 16 && s.rs.tu_log2[tid]) {

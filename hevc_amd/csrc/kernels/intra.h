@@ -582,7 +582,7 @@ DEV void intra_plan_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, in
             }
             for (int sb = tid; sb < 96; sb += NT) {       // 64 luma + 16 + 16 chroma 4x4 sub-blocks
                 const int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
-                const int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0, sh = pl ? 2 : 3;
+                const int per = pl ? 4 : 8, bx = (k & (per - 1)) * 4, by = (k >> (pl ? 2 : 3)) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0, sh = pl ? 2 : 3;
                 const int tile = (by >> sh) * 4 + (bx >> sh);
                 if (!s.rs.tu_log2[tile]) continue;
                 const int b = subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
@@ -726,7 +726,7 @@ DEV void intra_code_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0,
         if (sse) ex.atomic_add(&s.sse, sse);
         for (int sb = tid; sb < 96; sb += NT) {       // 64 luma + 16 + 16 chroma 4x4 sub-blocks
             int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
-            int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
+            int per = pl ? 4 : 8, bx = (k & (per - 1)) * 4, by = (k >> (pl ? 2 : 3)) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
             int sh = pl ? 2 : 3;
             if (!s.rs.tu_log2[(by >> sh) * 4 + (bx >> sh)]) continue;
             int b = subblock_bits_q4(s.rs.lvl + base + by * stride + bx, stride);
@@ -1053,7 +1053,7 @@ DEV void intra_code_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, in
             unsigned e = 0;
             for (int sb = tid; sb < 96; sb += NT) {
                 int pl = sb < 64 ? 0 : 1 + ((sb - 64) >> 4), k = sb < 64 ? sb : (sb - 64) & 15;
-                int per = pl ? 4 : 8, bx = (k % per) * 4, by = (k / per) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
+                int per = pl ? 4 : 8, bx = (k & (per - 1)) * 4, by = (k >> (pl ? 2 : 3)) * 4, stride = pl ? 16 : 32, base = pl ? 1024 + (pl - 1) * 256 : 0;
                 int lx = pl ? bx * 2 : bx, ly = pl ? by * 2 : by;
                 if (x0 + lx < a.w && y0 + ly < a.h) e += (unsigned)subblock_bits_q4(s.coef_acc + base + by * stride + bx, stride);
             }

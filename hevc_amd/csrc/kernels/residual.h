@@ -285,14 +285,26 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
     });
 }
 
+// the pair tables, built at compile time: every CTU program used to rebuild them from the byte matrix with a runtime division per entry
+// (~400 VALU instructions per lane of every workgroup: 7 % of k_inter_ctu's instruction count, profiles/r02_a phase table)
+struct PairTables { uint32_t mp[680], mq[680]; };
+constexpr PairTables make_pair_tables()
+{
+    PairTables t{};
+    const Tables m = make_tables();
+    for (int i = 0; i < 680; i++) {
+        const int lg = i < 8 ? 2 : i < 40 ? 3 : i < 168 ? 4 : 5, n = 1 << lg, off = lg == 2 ? 0 : lg == 3 ? 8 : lg == 4 ? 40 : 168, k = i - off, p = k / n, c = k % n, st = 5 - lg;
+        t.mp[i] = (uint32_t)(uint16_t)(int16_t)m.mat[c << st][2 * p] | (uint32_t)(uint16_t)(int16_t)m.mat[c << st][2 * p + 1] << 16;
+        t.mq[i] = (uint32_t)(uint16_t)(int16_t)m.mat[(2 * p) << st][c] | (uint32_t)(uint16_t)(int16_t)m.mat[(2 * p + 1) << st][c] << 16;
+    }
+    return t;
+}
+DEVCONST PairTables g_pair = make_pair_tables();
+
 template <class Ex> DEV void residual_init(Ex &ex, ResidualShared &s)
 {
     ex.phase([&](int tid) {
-        for (int i = tid; i < 680; i += NT) {
-            const int lg = i < 8 ? 2 : i < 40 ? 3 : i < 168 ? 4 : 5, n = 1 << lg, k = i - pair_off(lg), p = k / n, c = k % n, st = 5 - lg;
-            s.mp[i] = (uint32_t)(uint16_t)(int16_t)g_tab.mat[c << st][2 * p] | (uint32_t)(uint16_t)(int16_t)g_tab.mat[c << st][2 * p + 1] << 16;
-            s.mq[i] = (uint32_t)(uint16_t)(int16_t)g_tab.mat[(2 * p) << st][c] | (uint32_t)(uint16_t)(int16_t)g_tab.mat[(2 * p + 1) << st][c] << 16;
-        }
+        for (int i = tid; i < 680; i += NT) { s.mp[i] = g_pair.mp[i]; s.mq[i] = g_pair.mq[i]; }
         if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
         if (tid < 6) { s.quant_scale[tid] = g_tab.quant_scale[tid]; s.level_scale[tid] = g_tab.level_scale[tid]; }
         if (tid < 3) s.cbf[tid] = 0;

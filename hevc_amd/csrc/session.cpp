@@ -43,20 +43,16 @@ constexpr double kIdrCpbShare = 0.85;    // an IDR picture may take at most this
 constexpr double kCutAbs = 8.0;          // scene cut: mean absolute difference of consecutive pictures above this many grey levels (8-bit scale) ...
 constexpr double kCutRatio = 1.8;        // ... and this many times the running mean over the ordinary pictures before it
 
+// Host worker pool for the CABAC jobs.  ONE pool per process, shared by every session and grown to the largest size a session asks for: a batch
+// codes many clips back to back, and starting / joining 16 threads per clip was 2 ms of every 80 ms 1080p clip (bench step_phases open + close).
+// The threads live until the process exits (they are parked on a condition variable); a session waits for ITS jobs, never for the threads.
 class ThreadPool {
 public:
-    explicit ThreadPool(int n)
+    static ThreadPool &shared(int n)
     {
-        for (int i = 0; i < n; i++) threads_.emplace_back([this] { run(); });
-    }
-    ~ThreadPool()
-    {
-        {
-            std::lock_guard<std::mutex> l(m_);
-            stop_ = true;
-        }
-        cv_.notify_all();
-        for (auto &t : threads_) t.join();
+        static ThreadPool *p = new ThreadPool();      // never destroyed: no join at process exit, the threads hold no session state
+        p->grow(n);
+        return *p;
     }
     void submit(std::function<void()> f)
     {
@@ -68,14 +64,18 @@ public:
     }
 
 private:
+    void grow(int n)
+    {
+        std::lock_guard<std::mutex> l(m_);
+        while ((int)threads_.size() < n) { threads_.emplace_back([this] { run(); }); threads_.back().detach(); }
+    }
     void run()
     {
         for (;;) {
             std::function<void()> f;
             {
                 std::unique_lock<std::mutex> l(m_);
-                cv_.wait(l, [this] { return stop_ || !q_.empty(); });
-                if (q_.empty()) return;
+                cv_.wait(l, [this] { return !q_.empty(); });
                 f = std::move(q_.front());
                 q_.pop_front();
             }
@@ -86,7 +86,6 @@ private:
     std::deque<std::function<void()>> q_;
     std::mutex m_;
     std::condition_variable cv_;
-    bool stop_ = false;
 };
 
 // Process-wide cache of device / pinned-host allocations keyed by (device, size): a batch transcodes many clips of
@@ -331,8 +330,8 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
         s->packets[index] = std::move(pk);
         s->frames_done++;
         s->jobs_open[slot]--;
+        s->cv.notify_all();      // under the lock: mihevc_close may delete the session as soon as its last job has let go of the mutex
     }
-    s->cv.notify_all();
 }
 
 // sum of |a - b| over every 4th sample of every 4th row of consecutive pending source pictures: out[i] for the pair (i - 1, i), out[0] = 0
@@ -855,7 +854,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
              hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { delete s; return MIHEVC_EDEVICE; }
     int threads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
-    s->pool = new ThreadPool(threads);
+    s->pool = &ThreadPool::shared(threads);
     *out = s;
     return MIHEVC_OK;
 }
@@ -1005,7 +1004,10 @@ void mihevc_close(mihevc_session *s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
-    delete s->pool;      // joins workers
+    {   // the session's CABAC jobs still in flight (an abandoned session): they hold pointers into it
+        std::unique_lock<std::mutex> l(s->m);
+        s->cv.wait(l, [&] { int n = 0; for (int k = 0; k < kRing; k++) n += s->jobs_open[k]; return n == 0; });
+    }
     if (s->st_compute) (void)hipStreamSynchronize(s->st_compute);
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
     BufferCache &bc = BufferCache::get();
