@@ -297,7 +297,7 @@ def main():
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
     ap.add_argument("--profile-stages", type=int, default=2, help="HIP events in the timed steps: 2 = around the dominant kernel (inter_ctu) only, 1 = every stage, 0 = none")
     ap.add_argument("--stub", action="store_true", help="tests only: no GPU, no encoder — exercises the rank spawn / rendezvous / JSON path (tests/test_bench_ranks.py)")
-    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes"):
+    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes", "gop-balance", "scenecut"):
         ap.add_argument("--" + name, type=int, default=None, help="experiments only: override cfg." + name.replace("-", "_"))
     args = ap.parse_args()
 
@@ -353,7 +353,7 @@ def main():
     cfg.me_range, cfg.profile_stages = args.me_range, args.profile_stages
     cfg.qp = args.qp
     cfg.host_threads = args.host_threads
-    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes"):
+    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes", "gop_balance", "scenecut"):
         if getattr(args, name) is not None:
             setattr(cfg, name, getattr(args, name))
 
@@ -463,7 +463,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{W}x{H}@30 SDR 8-bit Main, crf {crf} capped by VBV maxrate {maxrate} kbps / bufsize {bufsize} kbit "
                                    f"(the reference's libx265 operating point), {N}-frame synthetic 'motion' clip per GPU, "
-                                   f"keyint {gop}, IPPP, full-search +-{args.me_range}, one clip per GPU, input resident in HBM"},
+                                   f"keyint {gop} ({(N + gop - 1) // gop} closed GOPs" + (" of equal length" if cfg.gop_balance else "") + f"), IPPP, full-search +-{args.me_range}, one clip per GPU, input resident in HBM"},
             "per_rank_fps": [round(args.steps * N / d, 2) for d in own],
             "stream_ok": bool(all(o == 1.0 for o in oks)) if not args.no_extras else None,
             "stream_check": check,

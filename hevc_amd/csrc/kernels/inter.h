@@ -164,7 +164,7 @@ template <typename T> struct MeShared {
     uint8_t src[32 * 32];
     unsigned long long best[21];
     uint8_t valid[21];
-    unsigned nodeok[2 * MAX_RANGE + 1];   // motion-constrained slices: bit n of word dy = vertical displacement index dy keeps node n's rows inside the slice
+    unsigned nodeok[2 * MAX_RANGE + 1];   // bit n of word dy: node n lies inside the picture and (motion-constrained slices) vertical displacement index dy keeps its rows inside the slice
     // followed in LDS by the search window: uint8_t win[(32 + 2R) * wstride]
 };
 HDI int me_spanx(int R) { return ((2 * R + 1) + 3) & ~3; }   // horizontal positions, rounded up to whole quads
@@ -222,7 +222,7 @@ DEV void copy_window_msb(uint8_t *lds, int ls, const uint8_t *plane, int pstride
 template <typename T, class Ex>
 DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs<T> &a, int ctu)
 {
-    const int msb = a.prm.bit_depth - 8;       // bits dropped from every sample for the search
+    const int msb = sizeof(T) == 1 ? 0 : a.prm.bit_depth - 8;       // bits dropped from every sample for the search
 
     const int R = a.prm.me_range, spany = 2 * R + 1, spanx = me_spanx(R), quads = spanx >> 2, ws = me_win_stride(R), ww = me_win_w(R), wh = 32 + 2 * R;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
@@ -245,36 +245,39 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
             s.valid[tid] = x0 + nx + (1 << nl) <= a.w && y0 + ny + (1 << nl) <= a.h;
             s.best[tid] = ~0ull;
         }
-        if (mct || mcb)
-            for (int dyi = tid; dyi < spany; dyi += NT) {
-                unsigned bits = 0;
-                for (int n = 0; n < 21; n++) {
-                    int nx, ny, nl;
-                    node_geom(n, nx, ny, nl);
-                    if (mv_rows_ok(y0 + ny, 1 << nl, 4 * (sy + dyi - R), a.h, mct, mcb)) bits |= 1u << n;
-                }
-                s.nodeok[dyi] = bits;
+        // per vertical displacement: the nodes that lie inside the picture and (a slice) whose rows the displacement keeps inside the slice
+        for (int dyi = tid; dyi < spany; dyi += NT) {
+            unsigned bits = 0;
+            for (int n = 0; n < 21; n++) {
+                int nx, ny, nl;
+                node_geom(n, nx, ny, nl);
+                const bool in_pic = x0 + nx + (1 << nl) <= a.w && y0 + ny + (1 << nl) <= a.h;
+                if (in_pic && (!(mct || mcb) || mv_rows_ok(y0 + ny, 1 << nl, 4 * (sy + dyi - R), a.h, mct, mcb))) bits |= 1u << n;
             }
+            s.nodeok[dyi] = bits;
+        }
     });
     ex.phase([&](int tid) {
-        // a node's candidate goes straight to the workgroup's LDS minimum (filtered by a plain read first), so no
-        // per-thread table of 21 running minima has to stay in registers across the unrolled SAD code
-        auto consider = [&](int node, unsigned cost, unsigned p, unsigned ok) {
-            unsigned long long key = ((unsigned long long)cost << 16) | p;
-            if (!((ok >> node) & 1)) return;       // a slice: the candidate must keep the node's rows inside it (all four positions of a quad share dy)
-            if (s.valid[node] && key < s.best[node]) ex.atomic_min(&s.best[node], key);
-        };
+        // A lane's four candidates of a node (one quad of dx at one dy) are ranked in 32 bits, (cost << 2) | j -- at equal cost the lower j is the
+        // earlier raster position, as the 64-bit (cost << 16) | position key ranks them -- and only the winner is widened and goes to the workgroup's
+        // LDS minimum (filtered by a plain read first): no per-thread table of 21 running minima stays in registers across the unrolled SAD code,
+        // and the 84 candidates of an item cost two VALU operations each instead of six with 64-bit compares
         for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
             const int q = item % quads, dyi = item / quads;
-            const unsigned ok = (mct || mcb) ? s.nodeok[dyi] : ~0u;
-            const int by = mvd_bits(4 * (dyi - R));
+            const unsigned ok = s.nodeok[dyi], pos0 = (unsigned)(dyi * spanx + 4 * q);
+            const int by = mvd_bits(4 * (dyi - R)), ksh = 6 + msb;
             const uint8_t *srcp = s.src + opaque_zero();      // keep the 1 KiB source tile in LDS (hoisted into 256 VGPRs otherwise)
-            unsigned bits[4], pos[4], s32[4] = {0, 0, 0, 0};
+            unsigned bitsj[4], s32[4] = {0, 0, 0, 0};
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                pos[j] = (unsigned)(dyi * spanx + 4 * q + j);
-                bits[j] = (unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * (4 * q + j - R)) + by));
-            }
+            for (int j = 0; j < 4; j++) bitsj[j] = ((unsigned)(a.prm.lambda_sad_q4 * (mvd_bits(4 * (4 * q + j - R)) + by)) << 2) | (unsigned)j;
+            auto consider = [&](int node, const unsigned (&sad)[4]) {
+                unsigned k = (sad[0] << ksh) + bitsj[0];
+#pragma unroll
+                for (int j = 1; j < 4; j++) { const unsigned kj = (sad[j] << ksh) + bitsj[j]; k = kj < k ? kj : k; }
+                if (!((ok >> node) & 1)) return;
+                const unsigned long long key = ((unsigned long long)(k >> 2) << 16) | (pos0 + (k & 3));
+                if (key < s.best[node]) ex.atomic_min(&s.best[node], key);
+            };
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 unsigned s16[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -284,41 +287,20 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                     unsigned o[4][4];
                     quad_block_row(srcp + br * 8 * 32, win + (br * 8 + dyi) * ws + 4 * q, ws, o);
 #pragma unroll
-                    for (int b = 0; b < 4; b++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) o[b][j] <<= msb;
-#pragma unroll
                     for (int b = 0; b < 4; b++) {
-                        const int node = 5 + (half * 2 + (b >> 1)) * 4 + r2 * 2 + (b & 1);
-                        unsigned long long k = ~0ull;
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            s16[b >> 1][j] += o[b][j];
-                            unsigned long long kj = ((unsigned long long)((o[b][j] << 4) + bits[j]) << 16) | pos[j];
-                            k = kj < k ? kj : k;
-                        }
-                        consider(node, (unsigned)(k >> 16), (unsigned)(k & 0xffff), ok);
+                        for (int j = 0; j < 4; j++) s16[b >> 1][j] += o[b][j];
+                        consider(5 + (half * 2 + (b >> 1)) * 4 + r2 * 2 + (b & 1), o[b]);
                     }
                 }
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
-                    unsigned long long k = ~0ull;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        s32[j] += s16[h2][j];
-                        unsigned long long kj = ((unsigned long long)((s16[h2][j] << 4) + bits[j]) << 16) | pos[j];
-                        k = kj < k ? kj : k;
-                    }
-                    consider(1 + half * 2 + h2, (unsigned)(k >> 16), (unsigned)(k & 0xffff), ok);
+                    for (int j = 0; j < 4; j++) s32[j] += s16[h2][j];
+                    consider(1 + half * 2 + h2, s16[h2]);
                 }
             }
-            unsigned long long k = ~0ull;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                unsigned long long kj = ((unsigned long long)((s32[j] << 4) + bits[j]) << 16) | pos[j];
-                k = kj < k ? kj : k;
-            }
-            consider(0, (unsigned)(k >> 16), (unsigned)(k & 0xffff), ok);
+            consider(0, s32);
         }
     });
     ex.phase([&](int tid) {
@@ -696,6 +678,31 @@ DEV void luma_quad(const T *win, int i00, int ws, int fx, int fy, int bit_depth,
     for (int i = 0; i < 4; i++) out[i] = (T)clip3(0, maxv, ((acc[i] >> 6) + (1 << (shift3 - 1))) >> shift3);
 }
 
+// 8-bit form of luma_quad: the horizontal 8-tap filter of a row's four outputs is 8 v_dot4_i32_i8 on byte-realigned dwords (samples biased to
+// signed bytes, the taps of every fraction sum to 64), as in luma_half_diff; same results as the generic form
+DEV void luma_quad(const uint8_t *win, int i00, int ws, int fx, int fy, int, uint8_t *out)
+{
+    const uint32_t tlo = load_u32(&g_tab.luma_tap[fx][0]), thi = load_u32(&g_tab.luma_tap[fx][4]);
+    const int8_t *ty = g_tab.luma_tap[fy];
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int idx = i00 + (r - 3) * ws - 3, off = idx & 3;
+        const uint8_t *p = win + (idx - off);
+        uint32_t d[4], q[3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = load_u32_aligned(p + 4 * k);
+#pragma unroll
+        for (int k = 0; k < 3; k++) q[k] = align_bytes(d[k + 1], d[k], off) ^ 0x80808080u;
+        const int t = ty[r];
+        acc[0] += t * dot4_i8(q[0], tlo, dot4_i8(q[1], thi, 128 * 64));
+#pragma unroll
+        for (int i = 1; i < 4; i++) acc[i] += t * dot4_i8(align_bytes(q[1], q[0], i), tlo, dot4_i8(align_bytes(q[2], q[1], i), thi, 128 * 64));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = (uint8_t)clip3(0, 255, ((acc[i] >> 6) + 32) >> 6);
+}
+
 template <typename T>
 DEV int chroma_sample(const T *p00, int ws, int fx, int fy, int bit_depth)
 {
@@ -885,7 +892,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             if (s.rs.tu_log2[t]) {
                 int mx = s.tile_mvx[t], my = s.tile_mvy[t];
                 int px = x0 + txp * 8 + hx + (mx >> 2) - oy_x, py = y0 + typ * 8 + j + (my >> 2) - oy_y;
-                luma_quad<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, s.pred + (typ * 8 + j) * 32 + txp * 8 + hx);
+                luma_quad(win_y, py * wys + px, wys, mx & 3, my & 3, bd, s.pred + (typ * 8 + j) * 32 + txp * 8 + hx);
             }
         }
         for (int i = tid; i < 512; i += NT) {

@@ -358,25 +358,39 @@ template <typename T> int encode_chunk(mihevc_session *s)
 {
     const int n = (int)s->pending.size();
     if (!n) return 0;
-    // ---- GOP layout of the chunk: an IDR every keyint pictures, and earlier where the picture changes (x265 scenecut + min-keyint, reference
-    //      core/transcoder.py:401).  The cut detector is the mean absolute difference of every 4th sample of every 4th row between consecutive
-    //      source pictures (k_scene_diff, one launch for the chunk): a cut is a difference above kCutAbs grey levels that is also kCutRatio times the
-    //      running mean over the ordinary pictures before it, at least min-keyint pictures after the last IDR.  Closed GOPs stay independent, so a GOP simply ends there.
-    std::vector<int> gstart_stream{0};
-    if (s->cfg.scenecut && n > 1 && s->cfg.min_keyint < s->keyint) {
+    // ---- GOP layout of the chunk.  Scene cuts (x265 scenecut + min-keyint, reference core/transcoder.py:401) divide the chunk into segments; every
+    //      segment is coded as the FEWEST closed GOPs keyint allows (the IDR count of an IDR-every-keyint layout), of near-equal length when
+    //      cfg.gop_balance is set: the lanes of the lock-step pipeline then run out together instead of idling behind a short last GOP (a 300-picture
+    //      clip at keyint 90 is 4 x 75 steps, not 90 steps of which 60 drive three lanes).  With gop_balance 0 a segment's IDRs sit every keyint pictures.
+    //      The cut detector is the mean absolute difference of every 4th sample of every 4th row between consecutive source pictures (k_scene_diff, one
+    //      launch for the chunk): a cut is a difference above kCutAbs grey levels that is also kCutRatio times the running mean over the ordinary
+    //      pictures before it, taken when every GOP of the segment it closes keeps at least min-keyint pictures.  A session that codes one slice of
+    //      the picture sees only its band, and the slices of a picture must agree on its type: no cut detection there.
+    const int keyint = s->keyint;
+    auto gops_of = [keyint](int len) { return (len + keyint - 1) / keyint; };
+    std::vector<int> seg{0};                  // segment starts
+    if (s->cfg.scenecut && s->cfg.slice_count <= 1 && n > 1 && s->cfg.min_keyint < keyint) {
         std::vector<unsigned long long> diff((size_t)n, 0);
         if (int e = scene_differences<T>(s, n, diff)) return e;
         const double per = (double)((s->w + 3) / 4) * ((s->h + 3) / 4) * (1 << (s->cfg.bit_depth - 8));
+        int total = 0;                        // GOPs of the closed segments
         for (int i = 1; i < n; i++) {
             const double d = (double)diff[(size_t)i] / per;
-            const int since = i - gstart_stream.back();
+            const int len = i - seg.back(), g = gops_of(len);
             const bool jump = d > kCutAbs && s->scene_avg > 0 && d > kCutRatio * s->scene_avg;
-            const bool cut = jump && since >= std::max(1, s->cfg.min_keyint) && (int)gstart_stream.size() < MAX_LANES - (n - i + s->keyint - 1) / s->keyint;
-            if (cut || since >= s->keyint) gstart_stream.push_back(i);
+            const int shortest = s->cfg.gop_balance ? len / g : (len % keyint ? len % keyint : keyint);
+            if (jump && shortest >= std::max(1, s->cfg.min_keyint) && total + g + gops_of(n - i) <= MAX_LANES) { total += g; seg.push_back(i); }
             if (!jump) s->scene_avg = s->scene_avg > 0 ? 0.8 * s->scene_avg + 0.2 * d : d;      // ordinary pictures only: a jump says nothing about the new scene's motion
         }
-    } else
-        for (int i = s->keyint; i < n; i += s->keyint) gstart_stream.push_back(i);
+    }
+    std::vector<int> gstart_stream;
+    for (size_t k = 0; k < seg.size(); k++) {
+        const int a0 = seg[k], len = (k + 1 < seg.size() ? seg[k + 1] : n) - a0, g = gops_of(len);
+        if (s->cfg.gop_balance)
+            for (int j = 0, at = a0; j < g; at += len / g + (j < len % g), j++) gstart_stream.push_back(at);
+        else
+            for (int at = a0; at < a0 + len; at += keyint) gstart_stream.push_back(at);
+    }
     const int gops = (int)gstart_stream.size();
     // lanes by GOP length, longest first: the lanes that still have a picture at step t are then a prefix [0, batch[t])
     std::vector<int> order((size_t)gops), gstart((size_t)gops), glen((size_t)gops), prev_len((size_t)gops);

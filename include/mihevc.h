@@ -88,6 +88,9 @@ typedef struct mihevc_config {
     int32_t rate_share_q16;           /* share of vbv-maxrate / vbv-bufsize this slice plans with, 65536 = all (0 = all) */
     int32_t scenecut;                 /* 1 (default): an IDR picture where the picture changes (mean absolute difference of consecutive source pictures),
                                        * at least min_keyint pictures after the last one (x265 scenecut / min-keyint); 0: IDR every keyint pictures only */
+    int32_t gop_balance;              /* 1 (default): a run of pictures between scene cuts / chunk ends is coded as the fewest GOPs keyint allows, of
+                                       * near-equal length (300 pictures at keyint 90: IDR at 0, 75, 150, 225), so the GOP lanes of the device pipeline finish
+                                       * together; 0: IDR every keyint pictures (0, 90, 180, 270).  The number of IDR pictures is the same either way */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;

@@ -188,6 +188,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     cfg = _lib.default_config()
     cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint = w, h, bd, keyint, 2
     cfg.qp, cfg.me_range, cfg.gops_in_flight, cfg.aud, cfg.intra_nxn, cfg.intra_in_p = 27, 8, 2, 1, nxn, ipass
+    cfg.scenecut = 0                         # IDR pictures by keyint alone: on 64x64 the detector's 256 samples see a cut in this clip's fourth step
     if bd == 10:
         cfg.hdr10, cfg.colour_primaries, cfg.transfer, cfg.matrix, cfg.chroma_loc, cfg.repeat_headers, cfg.hrd = 1, 9, 16, 9, 0, 1, 1
         cfg.level_idc = 150                  # level 5: the session uses the deeper (12-slot) symbol ring
@@ -212,15 +213,16 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_i.chroma_modes = prm_p.chroma_modes = cfg.chroma_modes   # default 1
     prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero   # session defaults: pre-search and RD zero-out on
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
+    idr = util.idr_positions(n, keyint, cfg.gops_in_flight)       # (132, 76, keyint 5, 7 pictures): GOPs of 4 + 3, not 5 + 2
     ref = None
     for i, f in enumerate(frames):
         pad = O.Frame(np.pad(f.y, ((0, ch - h), (0, cw - w)), mode="edge"), np.pad(f.u, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"),
                       np.pad(f.v, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"))
-        if i % keyint == 0:
+        if i in idr:
             a = O.analyze_intra(pad, prm_i)
         else:
             a = O.analyze_inter(pad, ref, prm_p)
-        prm = prm_i if i % keyint == 0 else prm_p
+        prm = prm_i if i in idr else prm_p
         ref, _ = O.sao(pad, O.deblock(a.rec, a.cu, bd), prm)
         enc_rec = O.Frame(*recs[i])
         assert enc_rec.same(ref), f"frame {i}: session reconstruction != oracle pipeline"
@@ -228,10 +230,10 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     if bd == 10:
         assert info["sei.mdcv.gx"] == 13250 and info["sei.cll.max_cll"] == 1000 and info["sps.profile_idc"] == 2
         # hrd=1: a buffering period SEI at every IDR, a picture timing SEI in every access unit, AUD leading each of them
-        assert info["vui.hrd_present"] == 1 and info["count.sei_bp"] == (n + keyint - 1) // keyint and info["count.sei_pt"] == n
+        assert info["vui.hrd_present"] == 1 and info["count.sei_bp"] == len(idr) and info["count.sei_pt"] == n
         full = 90000 * cfg.vbv_bufsize_kbits // cfg.vbv_maxrate_kbps
         assert abs(info["sei.bp.initial_delay"] - full * 9 // 10) <= 1 and abs(info["sei.bp.initial_delay"] + info["sei.bp.initial_offset"] - full) <= 1
-        assert info["sei.pt.au_cpb_removal_delay_minus1"] == (n - 1) % keyint - 1 if (n - 1) % keyint else True
+        assert info["sei.pt.au_cpb_removal_delay_minus1"] == (n - 1 - idr[-1]) - 1 if n - 1 > idr[-1] else True
 
 
 def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
@@ -258,7 +260,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     dec, _ = O.decode(stream)
     assert len(dec) == n and all(d.same(r) for d, r in zip(dec, recs))
     qps = [q for q, _, _ in infos]
-    assert all(t == (2 if i % keyint == 0 else 1) for i, (_, t, _) in enumerate(infos))
+    assert [i for i, (_, t, _) in enumerate(infos) if t == 2] == util.idr_positions(n, keyint, cfg.gops_in_flight) == [0, 20]
     assert min(qps[1:keyint]) >= cfg.crf + 2 and max(qps) > cfg.crf + 2          # the cap had to raise QP on this clip
     budget = cfg.vbv_maxrate_kbps * 1000 * keyint / 30.0
     for g in range(n // keyint):

@@ -154,3 +154,18 @@ def run_pipeline(api_or_oracle, srcs, prm_i, prm_p, bd=8):
         out.append((a, d, f, sp))
         ref = f
     return out
+
+
+def idr_positions(n, keyint, lanes=4, balance=True):
+    """IDR pictures of a session without scene cuts (hevc_amd/csrc/session.cpp encode_chunk): chunks of lanes x keyint pictures, every chunk coded as the
+    fewest GOPs keyint allows, of near-equal length (cfg.gop_balance, the default) or with an IDR every keyint pictures."""
+    out, pos = [], 0
+    while pos < n:
+        m = min(lanes * keyint, n - pos)
+        g = (m + keyint - 1) // keyint
+        at = pos
+        for j in range(g):
+            out.append(at)
+            at += (m // g + (j < m % g)) if balance else keyint
+        pos += m
+    return out
