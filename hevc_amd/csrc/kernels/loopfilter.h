@@ -7,6 +7,8 @@
 // per pass.  SAO gathers per-CTU statistics with LDS atomics, decides offsets (oracle sao_eval, exactly), then a
 // second kernel applies them while writing the final reference picture.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace mihevc {
@@ -103,15 +105,17 @@ template <typename T> struct SaoArgs {
     unsigned long long *sse;     // optional: 3 x u64 sum of squared error (source vs out), see k_frame_sse
 };
 
+constexpr int SAO_TS_Y = 40, SAO_TS_C = 24;      // tile row strides in samples
 struct SaoShared {
     int eo_n[3][4][5], eo_s[3][4][5], bo_n[3][32], bo_s[3][32];     // (these four first: zeroed as one int run)
     int8_t bo_off[3][32];
     long long bo_cost[3][32];
     int8_t eo_off[3][4][4];
     long long eo_cost[3][4];
-    // deblocked CTB + 1-sample halo, staged once with row-contiguous loads: every sample's 8 neighbours are then LDS reads
-    uint16_t tile_y[34 * 36];
-    uint16_t tile_c[2][18 * 20];
+    // deblocked CTB + 1-sample halo, staged once: every sample's 8 neighbours are then LDS reads.  Tile column tx (picture column x0 - 1 + tx)
+    // sits at index tx + 3 of its row, so the CTB's own aligned quads of four samples are 8-byte aligned LDS stores
+    alignas(8) uint16_t tile_y[34 * SAO_TS_Y];
+    alignas(8) uint16_t tile_c[2][18 * SAO_TS_C];
     alignas(4) uint16_t src[1536];   // the source CTB (Y, U, V as in the CTU kernels), held as T samples
     // 16 private copies of the statistics (copy = lane & 15, odd stride -> distinct banks): neighbouring samples mostly
     // fall in the same category/band, and 64 lanes hitting one LDS word serialise (SQ_LDS_BANK_CONFLICT, r01 profiles)
@@ -134,21 +138,22 @@ template <typename T> DEV int eo_category(const Plane<const T> &p, int x, int y,
     return e == 2 ? 0 : e < 2 ? e + 1 : e;
 }
 
-// offset minimising (n o^2 - 2 o s) * 16 + lambda * rate, walking from the rounded mean toward 0 (oracle sao_offset_rd)
+// offset minimising (n o^2 - 2 o s) * 16 + lambda * rate, walking from the rounded mean toward 0 (oracle sao_offset_rd).  A CTB plane has n <= 1024
+// samples of |difference| < 1024 and |o| <= 31: every intermediate fits 32 bits ((1024 * 961 + 62 * 2^20) * 16 + lambda * 32 < 2^31), so the device
+// form divides and multiplies in 32 bits (the 64-bit division alone was ~150 instructions on 108 lanes of every CTU)
 DEV int sao_offset_rd(int n, int s, int sign_rule, int lam_q4, int band, int maxoff, long long &cost)
 {
     if (n == 0) { cost += lam_q4; return 0; }
-    int o = (int)((2 * (long long)iabs(s) + n) / (2 * n));
+    int o = (int)((2u * (unsigned)iabs(s) + (unsigned)n) / (2u * (unsigned)n));
     if (s < 0) o = -o;
     if (sign_rule > 0 && o < 0) o = 0;
     if (sign_rule < 0 && o > 0) o = 0;
     o = clip3(-maxoff, maxoff, o);
-    int best_o = 0;
-    long long best = lam_q4;
+    int best_o = 0, best = lam_q4;
     int step = o > 0 ? 1 : -1;
     for (int t = step; o != 0 && t != o + step; t += step) {
         int av = iabs(t), rate = (av < maxoff ? av + 1 : maxoff) + (band ? 1 : 0);
-        long long c = (((long long)n * t * t - 2 * (long long)t * s) << 4) + (long long)lam_q4 * rate;
+        int c = (n * t * t - 2 * t * s) * 16 + lam_q4 * rate;
         if (c < best) { best = c; best_o = t; }
     }
     cost += best;
@@ -163,54 +168,92 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
         int *z = &s.eo_n[0][0][0];
         for (int i = tid; i < 3 * (20 + 20 + 32 + 32); i += NT) z[i] = 0;
         for (int i = tid; i < 3 * 16 * 53; i += NT) (&s.priv[0][0][0])[i] = 0;
-        // deblocked CTB + halo and the source CTB: all of a lane's loads are issued before its first LDS store (one wait for memory per
-        // lane instead of one per sample: these two loops were 60k-cycle chains of dependent round trips, profiles/r02 phase table)
-        constexpr int NH = 34 * 34 + 2 * 18 * 18, ITH = (NH + NT - 1) / NT;
-        T hv[ITH];
+        // deblocked CTB + halo and the source CTB.  The tiles are loaded as whole quads of four samples (the CTB's own columns: 34 x 8 luma and
+        // 2 x 18 x 4 chroma quads) plus the two halo columns sample by sample, at most three items a lane, and all of a lane's loads are issued
+        // before its first LDS store.  Rows and columns outside the picture are read from clamped addresses: the statistics never look at them.
+        // (One sample per item with its plane and position taken by division was half of this kernel's VALU work, profiles/r02_b.)
+        const int x0 = cx * 32, y0 = cy * 32, wc = a.w >> 1, hc = a.h >> 1;
+        auto quad_at = [&](int it, int &pl, int &ty, int &q) {       // item -> plane, tile row, quad of the row
+            if (it < 34 * 8) { pl = 0; ty = it >> 3; q = it & 7; return; }
+            it -= 34 * 8;
+            pl = 1 + it / 72; it %= 72; ty = it >> 2; q = it & 3;
+        };
+        auto halo_at = [&](int it, int &pl, int &ty, int &side) {    // item -> plane, tile row, left / right column
+            if (it < 68) { pl = 0; ty = it >> 1; side = it & 1; return; }
+            it -= 68;
+            pl = 1 + it / 36; it %= 36; ty = it >> 1; side = it & 1;
+        };
+        T qv[2][4] = {}, hvl = 0;
 #pragma unroll
-        for (int k = 0; k < ITH; k++) {
-            const int i = tid + k * NT;
-            if (i < NH) {
-                int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), kk = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
-                int tx = kk % dim, ty = kk / dim, pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h;
-                int gx = clip3(0, pw - 1, (pl ? cx * 16 : cx * 32) + tx - 1), gy = clip3(0, ph - 1, (pl ? cy * 16 : cy * 32) + ty - 1);
-                hv[k] = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+        for (int k = 0; k < 2; k++) {
+            const int it = tid + k * NT;
+            if (it < 34 * 8 + 2 * 72) {
+                int pl, ty, q;
+                quad_at(it, pl, ty, q);
+                const int pw = pl ? wc : a.w, ph = pl ? hc : a.h;
+                const int gx = imin((pl ? x0 >> 1 : x0) + 4 * q, pw - 4), gy = clip3(0, ph - 1, (pl ? y0 >> 1 : y0) + ty - 1);
+                __builtin_memcpy(qv[k], a.dbk[pl].p + (ptrdiff_t)gy * a.dbk[pl].stride + gx, sizeof qv[k]);
             }
         }
-        load_ctu_source<T>((T *)s.src, a.src, cx * 32, cy * 32, a.w, a.h, tid);
+        if (tid < 68 + 72) {
+            int pl, ty, side;
+            halo_at(tid, pl, ty, side);
+            const int pw = pl ? wc : a.w, ph = pl ? hc : a.h, n = pl ? 16 : 32;
+            const int gx = clip3(0, pw - 1, (pl ? x0 >> 1 : x0) + (side ? n : -1)), gy = clip3(0, ph - 1, (pl ? y0 >> 1 : y0) + ty - 1);
+            hvl = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
+        }
+        load_ctu_source<T>((T *)s.src, a.src, x0, y0, a.w, a.h, tid);
 #pragma unroll
-        for (int k = 0; k < ITH; k++) {
-            const int i = tid + k * NT;
-            if (i < NH) {
-                int pl = i < 34 * 34 ? 0 : 1 + (i - 34 * 34) / (18 * 18), kk = pl ? (i - 34 * 34) % (18 * 18) : i, dim = pl ? 18 : 34;
-                int tx = kk % dim, ty = kk / dim;
-                if (pl) s.tile_c[pl - 1][ty * 20 + tx] = (uint16_t)hv[k]; else s.tile_y[ty * 36 + tx] = (uint16_t)hv[k];
+        for (int k = 0; k < 2; k++) {
+            const int it = tid + k * NT;
+            if (it < 34 * 8 + 2 * 72) {
+                int pl, ty, q;
+                quad_at(it, pl, ty, q);
+                uint16_t *d = pl ? &s.tile_c[pl - 1][ty * SAO_TS_C + 4 + 4 * q] : &s.tile_y[ty * SAO_TS_Y + 4 + 4 * q];
+                store4(d, (int)qv[k][0], (int)qv[k][1], (int)qv[k][2], (int)qv[k][3]);
             }
+        }
+        if (tid < 68 + 72) {
+            int pl, ty, side;
+            halo_at(tid, pl, ty, side);
+            if (pl) s.tile_c[pl - 1][ty * SAO_TS_C + 3 + (side ? 17 : 0)] = (uint16_t)hvl; else s.tile_y[ty * SAO_TS_Y + 3 + (side ? 33 : 0)] = (uint16_t)hvl;
         }
     });
     ex.phase([&](int tid) {
-        for (int i = tid; i < 1536; i += NT) {
-            int pl, x, y;
-            if (i < 1024) { pl = 0; x = i & 31; y = i >> 5; } else { int k = i - 1024; pl = 1 + (k >> 8); k &= 255; x = k & 15; y = k >> 4; }
-            int pw = pl ? a.w >> 1 : a.w, ph = pl ? a.h >> 1 : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
-            if (gx >= pw || gy >= ph) continue;
+        // a lane owns a strip of horizontally adjacent samples: four luma (row tid >> 3, quad tid & 7) and two chroma (plane tid >> 7): the three tile rows
+        // around the strip are read once, and the horizontal differences are shared between neighbours
+        auto strip = [&](auto count, int pl, int x, int y) {
+            constexpr int N = decltype(count)::value;
+            const int pw = pl ? (a.w >> 1) : a.w, ph = pl ? (a.h >> 1) : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
+            if (gx >= pw || gy >= ph) return;                      // plane widths are multiples of 4: a strip is inside or outside as a whole
             const uint16_t *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
-            const int ts = pl ? 20 : 36, ti = (y + 1) * ts + x + 1;
-            int r = tp[ti];
-            int d = (int)((const T *)s.src)[i] - r;
-            int b = r >> (bd - 5);
+            const int ts = pl ? SAO_TS_C : SAO_TS_Y, ti = (y + 1) * ts + x + 3;      // tile sample left of the strip
+            int up[N + 2], mid[N + 2], dn[N + 2], h[N + 1];
+#pragma unroll
+            for (int j = 0; j < N + 2; j++) { up[j] = tp[ti - ts + j]; mid[j] = tp[ti + j]; dn[j] = tp[ti + ts + j]; }
+#pragma unroll
+            for (int j = 0; j < N + 1; j++) h[j] = sgn3(mid[j + 1] - mid[j]);
+            const T *sp = (const T *)s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
             unsigned *pv = s.priv[pl][tid & 15];
-            const unsigned one = (1u << 20) + (unsigned)(d + (1 << bd));      // count 1, sum d + bias
-            ex.atomic_add(&pv[20 + b], one);
-            for (int c = 0; c < 4; c++) {
-                int xa = gx + kEoDx[c][0], ya = gy + kEoDy[c][0], xb = gx + kEoDx[c][1], yb = gy + kEoDy[c][1], k = 0;
-                if (!(xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph)) {
-                    int e = 2 + sgn3(r - tp[ti + kEoDy[c][0] * ts + kEoDx[c][0]]) + sgn3(r - tp[ti + kEoDy[c][1] * ts + kEoDx[c][1]]);
-                    k = e == 2 ? 0 : e < 2 ? e + 1 : e;
-                }
-                ex.atomic_add(&pv[c * 5 + k], one);
+            const bool yin = gy > 0 && gy < ph - 1;
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int r = mid[i + 1], d = (int)sp[i] - r;
+                const unsigned one = (1u << 20) + (unsigned)(d + (1 << bd));      // count 1, sum d + bias
+                const bool xin = gx + i > 0 && gx + i < pw - 1;
+                const int e0 = 2 + h[i] - h[i + 1], e1 = 2 + sgn3(r - up[i + 1]) + sgn3(r - dn[i + 1]);
+                const int e2 = 2 + sgn3(r - up[i]) + sgn3(r - dn[i + 2]), e3 = 2 + sgn3(r - up[i + 2]) + sgn3(r - dn[i]);
+                // edgeIdx of 8.7.3.2 remapped to the SaoOffsetVal index (0, 1, 2, 3, 4 -> 1, 2, 0, 3, 4); 0 when a neighbour lies outside the picture
+                auto cat = [](int e, bool in) { return in ? (0x43021 >> (4 * e)) & 7 : 0; };
+                ex.atomic_add(&pv[20 + (r >> (bd - 5))], one);
+                ex.atomic_add(&pv[0 + cat(e0, xin)], one);
+                ex.atomic_add(&pv[5 + cat(e1, yin)], one);
+                ex.atomic_add(&pv[10 + cat(e2, xin && yin)], one);
+                ex.atomic_add(&pv[15 + cat(e3, xin && yin)], one);
             }
-        }
+        };
+        strip(std::integral_constant<int, 4>{}, 0, (tid & 7) * 4, tid >> 3);
+        strip(std::integral_constant<int, 2>{}, 1 + (tid >> 7), (tid & 7) * 2, (tid & 127) >> 3);
     });
     ex.phase([&](int tid) {          // fold the private copies
         for (int i = tid; i < 3 * 52; i += NT) {
