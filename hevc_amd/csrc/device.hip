@@ -16,7 +16,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (b & 7) * chunk + (b >> 3);
 }
 
-template <typename T> __global__ __launch_bounds__(NT, 3) void k_me_search(const InterArgs<T> *args, int n_ctu)
+template <typename T> __global__ __launch_bounds__(NT, 5) void k_me_search(const InterArgs<T> *args, int n_ctu)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ctu = xcd_remap(blockIdx.x, n_ctu);

@@ -185,6 +185,7 @@ HDI int me_win_elems(int R) { return (32 + 2 * R) * me_win_stride(R) + 16; }
 DEV void quad_block_row(const uint8_t *src, const uint8_t *ref, int ws, unsigned (&out)[4][4])
 {
     uint64_t acc[4] = {0, 0, 0, 0};
+#pragma unroll 2
     for (int r = 0; r < 8; r++) {
         uint32_t rr[9], cc[8];
 #pragma unroll
