@@ -119,6 +119,32 @@ private:
     size_t bytes_ = 0;
 };
 
+// the same for the sessions' two streams (create + destroy: about a millisecond per session)
+class StreamCache {
+public:
+    static StreamCache &get() { static StreamCache c; return c; }
+    hipError_t acquire(int dev, hipStream_t *out)
+    {
+        {
+            std::lock_guard<std::mutex> l(m_);
+            auto &v = free_[dev];
+            if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+        }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    void release(int dev, hipStream_t st)
+    {
+        if (!st) return;
+        std::lock_guard<std::mutex> l(m_);
+        auto &v = free_[dev];
+        if (v.size() >= 16) { (void)hipStreamDestroy(st); return; }
+        v.push_back(st);
+    }
+private:
+    std::mutex m_;
+    std::map<int, std::vector<hipStream_t>> free_;
+};
+
 struct Packet {
     std::vector<uint8_t> data;
     int64_t pts = 0;
@@ -339,9 +365,12 @@ template <typename T> int scene_differences(mihevc_session *s, int n, std::vecto
 {
     const size_t in_bytes = (size_t)n * sizeof(ScenePic<T>), need = ((in_bytes + 255) & ~(size_t)255) + (size_t)n * sizeof(unsigned long long);
     if (need > s->scene_cap) {
-        if (s->d_scene) (void)hipFree(s->d_scene);
-        HIPCK(s, hipMalloc(&s->d_scene, need));
-        s->scene_cap = need;
+        BufferCache &bc = BufferCache::get();
+        bc.release(s->device, s->scene_cap, false, s->d_scene);
+        s->d_scene = nullptr; s->scene_cap = 0;
+        const size_t cap = (need + 0xfff) & ~(size_t)0xfff;
+        HIPCK(s, bc.alloc(s->device, cap, false, &s->d_scene));
+        s->scene_cap = cap;
     }
     std::vector<ScenePic<T>> pics((size_t)n);
     for (int i = 0; i < n; i++) pics[(size_t)i] = ScenePic<T>{(const T *)s->pending[(size_t)i].p[0], s->pending[(size_t)i].stride[0]};
@@ -412,11 +441,13 @@ template <typename T> int encode_chunk(mihevc_session *s)
     const StepLayout<T> lay(gops);
     const size_t need = (size_t)(steps + 1) * lay.total;      // + one block for the rho trial (below)
     if (need > s->args_cap) {
-        if (s->d_args) (void)hipFree(s->d_args);
-        if (s->h_args) (void)hipHostFree(s->h_args);
-        HIPCK(s, hipMalloc(&s->d_args, need));
-        HIPCK(s, hipHostMalloc((void **)&s->h_args, need, hipHostMallocDefault));
-        s->args_cap = need;
+        BufferCache &bc = BufferCache::get();
+        bc.release(s->device, s->args_cap, false, s->d_args); bc.release(s->device, s->args_cap, true, s->h_args);
+        s->d_args = nullptr; s->h_args = nullptr; s->args_cap = 0;
+        const size_t cap = (need + 0xffff) & ~(size_t)0xffff;      // whole 64 KiB: the next session's chunk finds the block in the cache
+        HIPCK(s, bc.alloc(s->device, cap, false, &s->d_args));
+        HIPCK(s, bc.alloc(s->device, cap, true, (void **)&s->h_args));
+        s->args_cap = cap;
     }
     uint8_t *ha = s->h_args, *da = (uint8_t *)s->d_args;
     auto prm_for = [&](int qp) {
@@ -861,8 +892,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->stats.last_qp = s->qp_p;
     s->rc_on = cfg->qp < 0 && cfg->vbv_maxrate_kbps > 0;
     write_parameter_sets(s->cfg, s->headers);
-    bool ok = hipStreamCreateWithFlags(&s->st_compute, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking) == hipSuccess;
+    bool ok = StreamCache::get().acquire(s->device, &s->st_compute) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_copy) == hipSuccess;
     for (int i = 0; ok && i < kRing; i++)
         ok = hipEventCreateWithFlags(&s->ev_compute[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
@@ -1039,13 +1069,13 @@ void mihevc_close(mihevc_session *s)
         bc.release(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, L.centers);
         for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
-    if (s->d_args) (void)hipFree(s->d_args);
-    if (s->d_scene) (void)hipFree(s->d_scene);
-    if (s->h_args) (void)hipHostFree(s->h_args);
+    bc.release(s->device, s->args_cap, false, s->d_args);
+    bc.release(s->device, s->scene_cap, false, s->d_scene);
+    bc.release(s->device, s->args_cap, true, s->h_args);
     for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
-    if (s->st_compute) (void)hipStreamDestroy(s->st_compute);
-    if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
+    StreamCache::get().release(s->device, s->st_compute);       // both idle: synchronised above
+    StreamCache::get().release(s->device, s->st_copy);
     delete s;
 }
 
