@@ -51,10 +51,10 @@ def one_case(rng, it):
         if LARGE:
             n = int(rng.integers(1, 40)) if w < 3000 else int(rng.integers(1, 8))
         cfg = _lib.default_config()
-        cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight = w, h, bd, keyint, 1, lanes
+        cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight = w, h, bd, keyint, int(rng.integers(1, 4)), lanes
         cfg.me_range = int(rng.choice([4, 8, 15, 24]))
         cfg.level_idc = int(rng.choice([93, 120, 150, 180]))
-        for name in ("intra_nxn", "intra_in_p", "chroma_modes", "rdo_zero", "pre_search", "intra_tiles", "sao", "aud", "hrd", "repeat_headers"):
+        for name in ("intra_nxn", "intra_in_p", "chroma_modes", "rdo_zero", "pre_search", "intra_tiles", "sao", "aud", "hrd", "repeat_headers", "gop_balance", "scenecut"):
             setattr(cfg, name, int(rng.random() < 0.5))
         if rng.random() < 0.5:
             cfg.qp = int(rng.integers(10, 45))
