@@ -27,7 +27,7 @@ def synth_frame(h, w, seed=0, shift=(0, 0), bit_depth=8, detail=True) -> O.Frame
             y[ry:ry + rh, rx:rx + rw] = r2.integers(16, 235)
         # a high-frequency checker patch
         y[h // 2:h // 2 + 16, 8:40] = np.where(((xx[:16, :32] // 2) + (yy[:16, :32] // 2)) % 2 == 0, 40, 210)
-    g = np.random.default_rng(seed * 1000 + shift[0] * 31 + shift[1] + 1)
+    g = np.random.default_rng((seed * 1000 + shift[0] * 31 + shift[1] + 1) % (1 << 32))      # negative shifts with seed 0: numpy takes non-negative seeds only
     y = np.clip(y + g.normal(0, 1.5, (h, w)), 0, 255)
     u = np.clip(128 + 30 * np.sin(yy[::2, ::2] / 9.0) + 20 * big[oy:oy + h:2, ox:ox + w:2] + g.normal(0, 1, (h // 2, w // 2)), 0, 255)
     v = np.clip(128 + 30 * np.cos(xx[::2, ::2] / 11.0) - 20 * big[oy:oy + h:2, ox:ox + w:2] + g.normal(0, 1, (h // 2, w // 2)), 0, 255)
