@@ -17,9 +17,9 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
 done
 cd $root
 { echo "# mean per dispatch of the SQ counters rocprofv3 wrote for each kernel (three separate --pmc passes of tests/prof_clip.py 24 12)."
-  echo "# The SQ block is sampled on a subset of the shader engines on this pool (SQ_WAVES ~ 1/20 of the launched waves): read RATIOS of"
-  echo "# counters of one pass, e.g. SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both quad-cycles) = VALU issue share per resident wave;"
-  echo "# x waves per SIMD (launch bounds) = share of SIMD issue slots: pmc.json, tools/prof_summary.py."
+  echo "# Every value is the MEAN PER DISPATCH (not the sum over the run): k_inter_ctu's SQ_WAVES 16320 = 2 pictures x 2040 CTUs x 4 waves, all the"
+  echo "# waves of a launch.  Read RATIOS of counters of one pass, e.g. SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in units of 4 cycles) = share of a"
+  echo "# resident wave's life spent issuing VALU work; x waves per SIMD (occupancy) = share of SIMD issue slots: pmc.json, tools/prof_summary.py."
   python3 tools/prof_summary.py pmc $out/p1 $out/p2 $out/p3; } > $out/pmc_summary.txt
 python3 tools/prof_summary.py pmcjson $out/pmc.json $out/p1 $out/p2 $out/p3 > /dev/null
 rm -rf $out/p1 $out/p2 $out/p3

@@ -81,7 +81,7 @@ def traffic(fd, wd, outp):
 
 
 # workgroups (= waves per SIMD: 256 threads = 4 waves over 4 SIMDs) per CU from the kernels' __launch_bounds__ in csrc/device.hip
-WAVES_PER_SIMD = {"k_inter_ctu": 4, "k_intra_plan": 3, "k_intra_diag": 2, "k_me_search": 3, "k_sao_decide": 8, "k_intra_p": 2, "k_pre_search": 8}
+WAVES_PER_SIMD = {"k_inter_ctu": 4, "k_intra_plan": 3, "k_intra_diag": 2, "k_me_search": 5, "k_sao_decide": 8, "k_intra_p": 2, "k_pre_search": 8}
 
 
 def pmcjson(outp, dirs):
