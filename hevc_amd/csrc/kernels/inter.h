@@ -52,9 +52,13 @@ template <typename T> DEV void lowres_sample(const PreArgs<T> &a, int i)
     const Plane<const T> &p = i < n ? a.src : a.ref;
     const int k = i < n ? i : i - n, x = k % lw, y = k / lw;
     int s = 8 << sh;
+#pragma unroll
     for (int j = 0; j < 4; j++) {
         const T *row = p.p + (ptrdiff_t)(4 * y + j) * p.stride + 4 * x;
-        s += (int)row[0] + (int)row[1] + (int)row[2] + (int)row[3];
+        if (sizeof(T) == 1) {              // four samples in one dword, summed by one SAD against zero
+            s = (int)sad_packed_u8(load_u32(row), 0u, (uint32_t)s);
+        } else
+            s += (int)row[0] + (int)row[1] + (int)row[2] + (int)row[3];
     }
     (i < n ? a.lsrc : a.lref)[k] = (uint8_t)(s >> (4 + sh));
 }
@@ -74,7 +78,22 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
     const int bw = lw - 8 * cx < 8 ? lw - 8 * cx : 8, bh = lh - 8 * cy < 8 ? lh - 8 * cy : 8;
     ex.phase([&](int tid) {
         if (tid < 64) { const int x = tid & 7, y = tid >> 3; s.blk[tid] = (x < bw && y < bh) ? a.lsrc[(8 * cy + y) * lw + 8 * cx + x] : (uint8_t)0; }
-        {   // the window: every lane's loads are issued before its first LDS store (this loop was a 95k-cycle chain of dependent loads)
+        // the window: every lane's loads are issued before its first LDS store (this loop was a 95k-cycle chain of dependent loads).  A window that
+        // lies inside the low-resolution picture is fetched as dwords (two a lane); the clamped sample-by-sample form is for the CTUs at the picture's edge
+        if (8 * cx - R >= 0 && 8 * cx - R + PRE_WIN_W <= lw && 8 * cy - R >= 0 && 8 * cy + 8 + R <= lh) {
+            constexpr int DPR = PRE_WIN_W / 4, ND = (8 + 2 * PRE_RANGE) * DPR, IT = (ND + NT - 1) / NT;
+            uint32_t v[IT];
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                const int i = tid + k * NT;
+                if (i < ND) v[k] = load_u32(a.lref + (size_t)(8 * cy - R + i / DPR) * lw + 8 * cx - R + 4 * (i % DPR));
+            }
+#pragma unroll
+            for (int k = 0; k < IT; k++) {
+                const int i = tid + k * NT;
+                if (i < ND) store_u32_aligned(s.win + (i / DPR) * PRE_WIN_STRIDE + 4 * (i % DPR), v[k]);
+            }
+        } else {
             constexpr int NW = (8 + 2 * PRE_RANGE) * PRE_WIN_W, IT = (NW + NT - 1) / NT;
             uint8_t v[IT];
 #pragma unroll

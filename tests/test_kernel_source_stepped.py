@@ -99,7 +99,7 @@ def test_stepped_intra_second_pass_of_p_pictures(emu, w, h, qp, bd, nxn):
         ref = O.sao(srcs[i], O.deblock(want.rec, want.cu, bd), prm)[0]
 
 
-@pytest.mark.parametrize("w,h,bd,shift", [(192, 128, 8, (38, -22)), (136, 104, 10, (-50, 17)), (160, 96, 8, (3, 1))])
+@pytest.mark.parametrize("w,h,bd,shift", [(192, 128, 8, (38, -22)), (136, 104, 10, (-50, 17)), (160, 96, 8, (3, 1)), (384, 320, 8, (22, -13))])   # the last: CTUs whose window is fetched as dwords
 def test_stepped_pre_search_finds_fast_motion(emu, w, h, bd, shift):
     """Search centres from the 1/4-size pictures: +-8 integer search around them follows a global shift far outside +-8."""
     prm = O.default_params(27, bit_depth=bd, me_range=8)
