@@ -386,7 +386,7 @@ DEV void intra_plan_program(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, in
             int cx, cy, l2, xn, yn;
             node_geom(nd, cx, cy, l2);
             ref_pos(pl ? cx >> 1 : cx, pl ? cy >> 1 : cy, pl ? n >> 1 : n, i, xn, yn);
-            const int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;
+            const int sh = pl ? 1 : 0, lx = xn * (1 << sh) + x0, ly = yn * (1 << sh) + y0;
             const bool ok = lx >= tb.x_lo && ly >= tb.y_lo && lx < a.w && lx < tb.x_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(x0 + cx, y0 + cy, a.ctus_w);
             const T v = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;
             if (pl) s.p_refc[nd][pl - 1][i] = v; else s.p_ref[nd][i] = v;
@@ -644,7 +644,7 @@ DEV void intra_code_cu(Ex &ex, IntraShared<T> &s, const IntraArgs<T> &a, int x0,
             if (i >= 4 * np + 1) continue;
             int xn, yn;
             ref_pos(pl ? cx >> 1 : cx, pl ? cy >> 1 : cy, np, i, xn, yn);
-            const int sh = pl ? 1 : 0, lx = (xn << sh) + x0, ly = (yn << sh) + y0;      // luma picture position of the neighbour
+            const int sh = pl ? 1 : 0, lx = xn * (1 << sh) + x0, ly = yn * (1 << sh) + y0;      // luma picture position of the neighbour
             const bool ok = lx >= tb.x_lo && ly >= tb.y_lo && lx < a.w && lx < tb.x_hi && ly < a.h && zaddr(lx, ly, a.ctus_w) < zaddr(gx, gy, a.ctus_w);
             if (ok) ex.atomic_or(&s.avmask[pl][i >> 5], 1u << (i & 31));
             s.ref_raw[pl][i] = ok ? (pl ? s.rec_c[pl - 1][(yn + 1) * RC_STRIDE + xn + 1] : s.rec_y[(yn + 1) * RY_STRIDE + xn + 1]) : (T)0;

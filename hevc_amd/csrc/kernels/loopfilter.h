@@ -86,7 +86,7 @@ template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_
             for (int k = 0; k < 2; k++) {
                 T *c = e + k * (ptrdiff_t)t;
                 int p0 = c[-1 * (ptrdiff_t)s], p1 = c[-2 * (ptrdiff_t)s], q0 = c[0], q1 = c[s];
-                int delta = clip3(-tcc, tcc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+                int delta = clip3(-tcc, tcc, (((q0 - p0) * 4 + p1 - q1 + 4) >> 3));
                 c[-1 * (ptrdiff_t)s] = (T)clip3(0, maxv, p0 + delta);
                 c[0] = (T)clip3(0, maxv, q0 - delta);
             }

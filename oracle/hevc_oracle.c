@@ -1387,7 +1387,7 @@ void orc_deblock_frame(pix *rec_y, pix *rec_u, pix *rec_v, int stride, int cstri
                         int s = dir == 0 ? 1 : cstride, t = dir == 0 ? cstride : 1;
                         for (int k = 0; k < 4; k++) {
                             int p0 = c[-s + k * t], p1 = c[-2 * s + k * t], q0 = c[k * t], q1 = c[s + k * t];
-                            int delta = CLIP3(-tcc, tcc, ((((q0 - p0) << 2) + p1 - q1 + 4) >> 3));
+                            int delta = CLIP3(-tcc, tcc, (((q0 - p0) * 4 + p1 - q1 + 4) >> 3));
                             c[-s + k * t] = (pix)CLIP3(0, maxv, p0 + delta);
                             c[k * t] = (pix)CLIP3(0, maxv, q0 - delta);
                         }
@@ -1428,7 +1428,7 @@ static int sao_offset_rd(int n, int s, int sign_rule, int lam_q4, int band, int 
     for (int t = step; o != 0 && t != o + step; t += step) {
         int a = iabs(t);
         int rate = (a < maxoff ? a + 1 : maxoff) + (band ? 1 : 0);
-        int64_t c = (((int64_t)n * t * t - 2 * (int64_t)t * s) << 4) + (int64_t)lam_q4 * rate;
+        int64_t c = (((int64_t)n * t * t - 2 * (int64_t)t * s) * 16) + (int64_t)lam_q4 * rate;
         if (c < best) { best = c; best_o = t; }
     }
     *cost += best;
