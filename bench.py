@@ -35,6 +35,8 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 METRIC = "encoded 1080p30 frames/sec/GPU; PSNR-Y parity vs libx265 at matched bitrate"
+# MIHEVC_BENCH_SHARE_GPU=1: rehearsal only — lets `--gpus N` run on fewer than N devices (ranks share them; the JSON line carries "shared_gpu_rehearsal": true and is no scaling number)
+SHARE_GPU = os.environ.get("MIHEVC_BENCH_SHARE_GPU") == "1"
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
@@ -225,7 +227,7 @@ def spawn_ranks(args):
     else:
         import torch
         n_dev = torch.cuda.device_count()          # counts devices without initialising the GPU runtime in this process
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and not (SHARE_GPU and n_dev >= 1):
         raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} MI355X visible on this host — one process per GPU needs {args.gpus} devices "
                          "(there is no CPU fallback and ranks never share a device)")
     port = free_port()
@@ -261,7 +263,18 @@ class Ranks:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            # gloo announces its connections on STDOUT ("[Gloo] Rank 0 is connected to ..."): the bench's stdout is ONE JSON line, so file
+            # descriptor 1 points at stderr while the group comes up (the first collective opens the full mesh)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
             self.dist = dist
 
     def barrier(self):
@@ -330,7 +343,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback exists)")
     if local >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible")
+        if not SHARE_GPU:
+            raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible")
+        local %= torch.cuda.device_count()      # rehearsal of the multi-rank path on a box with fewer devices: ranks share them, the line says so
     torch.cuda.set_device(local)
     ranks = Ranks(rank, world)
 
@@ -466,7 +481,7 @@ def main():
             "config": {"workload": f"{W}x{H}@30 SDR 8-bit Main, crf {crf} capped by VBV maxrate {maxrate} kbps / bufsize {bufsize} kbit "
                                    f"(the reference's libx265 operating point), {N}-frame synthetic 'motion' clip per GPU, "
                                    f"keyint {gop} ({(N + gop - 1) // gop} closed GOPs" + (" of equal length" if cfg.gop_balance else "") + f"), IPPP, full-search +-{args.me_range}, one clip per GPU, input resident in HBM"},
-            "per_rank_fps": [round(args.steps * N / d, 2) for d in own],
+            "per_rank_fps": [round(args.steps * N / d, 2) for d in own], **({"shared_gpu_rehearsal": True} if SHARE_GPU else {}),
             "stream_ok": bool(all(o == 1.0 for o in oks)) if not args.no_extras else None,
             "stream_check": check,
             "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1), "vbv_maxrate_kbps": maxrate,

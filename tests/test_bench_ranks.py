@@ -20,8 +20,8 @@ def _free_port():
 
 
 def _one_json_line(stdout):
-    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, stdout
+    lines = [ln for ln in stdout.splitlines() if ln.strip()]         # nothing else may reach stdout (gloo's connection notes go to stderr)
+    assert len(lines) == 1 and lines[0].startswith("{"), stdout
     return json.loads(lines[0])
 
 
