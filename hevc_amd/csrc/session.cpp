@@ -200,7 +200,7 @@ struct mihevc_session {
     void *d_args = nullptr;           // argument blocks of a whole chunk
     uint8_t *h_args = nullptr;        // pinned staging for the same
     size_t args_cap = 0;
-    hipEvent_t ev_compute[kRing], ev_copy[kRing];
+    hipEvent_t ev_compute[kRing] = {}, ev_copy[kRing] = {};
     std::vector<hipEvent_t> ev_pool;   // profile_stages: start/stop pairs
     struct Mark { int stage, pictures; size_t ev; };
     std::vector<Mark> marks;
@@ -896,7 +896,13 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     for (int i = 0; ok && i < kRing; i++)
         ok = hipEventCreateWithFlags(&s->ev_compute[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) { delete s; return MIHEVC_EDEVICE; }
+    if (!ok) {               // give back what was acquired (event handles of the slots never reached stay null)
+        for (int i = 0; i < kRing; i++) { if (s->ev_compute[i]) (void)hipEventDestroy(s->ev_compute[i]); if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]); }
+        StreamCache::get().release(s->device, s->st_compute);
+        StreamCache::get().release(s->device, s->st_copy);
+        delete s;
+        return MIHEVC_EDEVICE;
+    }
     int threads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
     s->pool = &ThreadPool::shared(threads);
     *out = s;
