@@ -53,7 +53,7 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     cfg.width, cfg.height = width, height
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and NxN trial the device path runs
     prm_i.intra_nxn, prm_i.chroma_modes = cfg.intra_nxn, cfg.chroma_modes
-    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero
+    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
     t0 = time.perf_counter()
     ref = None
     for i, (y, u, v) in enumerate(clip.frames()):
@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
     ap.add_argument("--profile-stages", type=int, default=2, help="HIP events in the timed steps: 2 = around the dominant kernel (inter_ctu) only, 1 = every stage, 0 = none")
     ap.add_argument("--stub", action="store_true", help="tests only: no GPU, no encoder — exercises the rank spawn / rendezvous / JSON path (tests/test_bench_ranks.py)")
-    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes", "gop-balance", "scenecut"):
+    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes", "gop-balance", "scenecut", "rdo-cg"):
         ap.add_argument("--" + name, type=int, default=None, help="experiments only: override cfg." + name.replace("-", "_"))
     args = ap.parse_args()
 
@@ -368,7 +368,7 @@ def main():
     cfg.me_range, cfg.profile_stages = args.me_range, args.profile_stages
     cfg.qp = args.qp
     cfg.host_threads = args.host_threads
-    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes", "gop_balance", "scenecut"):
+    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes", "gop_balance", "scenecut", "rdo_cg"):
         if getattr(args, name) is not None:
             setattr(cfg, name, getattr(args, name))
 

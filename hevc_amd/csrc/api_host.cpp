@@ -40,7 +40,7 @@ void mihevc_config_default(mihevc_config *c)
     memcpy(c->md_primaries, prim, sizeof prim);
     c->md_white[0] = 15635; c->md_white[1] = 16450; c->md_max_lum = 10000000; c->md_min_lum = 50;
     c->max_cll = 1000; c->max_fall = 400;
-    c->me_range = 0; c->gops_in_flight = 0; c->host_threads = 0; c->sao = 1; c->intra_tiles = 1; c->intra_nxn = 0; c->intra_in_p = 0; c->pre_search = 1; c->rdo_zero = 1; c->chroma_modes = 1; c->scenecut = 1; c->gop_balance = 1;
+    c->me_range = 0; c->gops_in_flight = 0; c->host_threads = 0; c->sao = 1; c->intra_tiles = 1; c->intra_nxn = 0; c->intra_in_p = 0; c->pre_search = 1; c->rdo_zero = 1; c->chroma_modes = 1; c->scenecut = 1; c->gop_balance = 1; c->rdo_cg = 0;
 }
 
 // lambda_mode = 0.57 * 2^((qp-12)/3) (the usual HM/x265 relation); SAD/SATD-domain lambda is its square root.
@@ -66,6 +66,7 @@ void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_
     out->rdo_zero = 0;
     out->chroma_modes = 0;
     out->mc_top = out->mc_bottom = 0;
+    out->rdo_cg = 0;
 }
 
 static int copy_out(const std::vector<uint8_t> &v, uint8_t *buf, size_t cap)

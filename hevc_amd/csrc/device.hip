@@ -505,7 +505,7 @@ template <typename T> struct Planes3 {
     ~Planes3() { for (auto &x : p) free_plane<T>(x); }
 };
 
-CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search, p->rdo_zero, p->chroma_modes, p->mc_top, p->mc_bottom}; }
+CostParams to_prm(const mihevc_cost_params *p) { return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search, p->rdo_zero, p->chroma_modes, p->mc_top, p->mc_bottom, p->rdo_cg}; }
 
 bool geometry_ok(int w, int h) { return w >= 16 && h >= 16 && !(w & 7) && !(h & 7) && w <= 8192 && h <= 4352; }
 

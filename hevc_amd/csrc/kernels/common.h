@@ -56,6 +56,7 @@ struct CostParams {
     int rdo_zero;                 // 1: inter TUs whose levels cost more than the distortion they remove are zeroed (inter_ctu_program)
     int chroma_modes;             // 1: 2Nx2N intra CUs choose among DM / planar / 26 / 10 / DC for chroma (intra_cu)
     int mc_top, mc_bottom;        // 1: the picture is a slice whose upper / lower neighbour lives on another device: motion compensation stays inside
+    int rdo_cg;                   // k > 0: RD zero-out of the 4x4 coefficient groups of inter TUs with lambda x k / 2 (residual_pipeline); 0: off
 };
 // rate model in 1/16 bit (oracle/hevc_oracle.c ORC_R_*, fitted to the host CABAC): a level, a 4x4 sub-block with a level, a TU with a level,
 // an inter CU, an intra CU

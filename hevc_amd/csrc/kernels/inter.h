@@ -931,7 +931,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         if (tid < 48) { s.tu_dc[tid >> 4][tid & 15] = 0; s.tu_dz[tid >> 4][tid & 15] = 0; s.tu_bits[tid >> 4][tid & 15] = 0; }
         if (tid < 3) s.tu_zero[tid] = 0;
     });
-    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, whole_ctu());
+    residual_pipeline(ex, s.rs, a.prm.qp, a.prm.qp_c, bd, whole_ctu(), a.prm.rdo_cg > 0 ? (int)(((long long)a.prm.lambda_q4 * a.prm.rdo_cg) >> 1) : 0);
     // RD zero-out (oracle: code_tu_inter): a TU keeps its levels only if SSE_zero << 4 > (SSE_coded << 4) + (lambda * bits >> 4)
     if (a.prm.rdo_zero) {
         ex.phase([&](int tid) {

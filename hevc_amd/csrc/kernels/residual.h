@@ -29,6 +29,7 @@ struct ResidualShared {
     uint32_t desc[1536];       // per sample: TU geometry, written by the caller while it forms the residual
     };
     alignas(16) uint32_t scratch[4608];    // the same 18 KB for a caller's own use while no residual is in flight (k_inter_ctu: fractional search)
+    struct { alignas(16) long long d[192]; int b[192]; } cg;      // over `res`, which is idle between the forward and the inverse transform: per 2x4 block, its share of a coefficient group's distortion and bits
     };
     uint8_t tu_log2[16];       // per 8x8 luma tile: log2 of the TU (= CU) size, 0 = none
     uint8_t tu_intra[16];      // per tile: 1 = intra rounding
@@ -109,9 +110,15 @@ DEV void store_x2(void *p, const uint32_t (&v)[2]) { __builtin_memcpy(__builtin_
 // TU): a matrix operand fetched once (ds_read_b128 / b64) feeds 8 v_dot2_i32_i16, the sample operands come as b128 rows or as the
 // row-pair dwords of `tmp`, results leave as b64 / b128 stores.  The one-output-per-lane form spent two ds_read_b32 per dot2 and was
 // LDS-issue bound (a third of k_inter_ctu's instructions, profiles/r02 phase table); a CTU is 192 blocks = one pass of the workgroup.
-template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth, Region rg)
+// cg_lam_q4 > 0 (inter CTUs): RD zero-out of 4x4 coefficient groups, oracle cg_zero_out — dropping a group adds D = sum r (2c - r) of squared
+// coefficient error (c coefficient, r its reconstruction) and saves its levels' bits + one sub-block; drop <=> 16 D < ((cg_lam_q4 * bits) >> 4) << 2 (15 - bitDepth - log2n).
+// A group is two vertically adjacent 2x4 blocks, i.e. two lanes: both leave their partial sums in LDS (`res` is free between the forward and the
+// inverse transform) and the next phase lets each decide for its own half.
+template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp, int qp_c, int bit_depth, Region rg, int cg_lam_q4 = 0)
 {
     const int nblk = rg.count() >> 3;
+    long long *cg_d = s.cg.d;
+    int *cg_b = s.cg.b;
     // row stages (forward 1, inverse 2): out(y, u) = sum_p M-pair(p, u) . in(y, 2p..2p+1); column stages (forward 2, inverse 1):
     // out(v, x) = sum_p M-pair(p, v) . in-row-pair(p, x), the row pairs of `tmp` being single dwords
     auto row_stage = [&](const uint32_t *mat, const int16_t *in, const SampleLoc &l, int (&acc)[2][4]) {
@@ -225,7 +232,9 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
             const long long add = (long long)(l.intra ? 171 : 85) << (qbits - 9);
             const long long scale = (long long)16 * s.level_scale[q % 6] << (q / 6);
             const int qs = s.quant_scale[q % 6];
-            int any = 0;
+            const bool cg = cg_lam_q4 > 0 && !l.intra;
+            int any = 0, bits = 0;
+            long long dsum = 0;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 uint32_t c2[2];
@@ -240,11 +249,29 @@ template <class Ex> DEV void residual_pipeline(Ex &ex, ResidualShared &s, int qp
                     any |= lv;
                     const long long d = (lv * scale + ((long long)1 << (bd_shift - 1))) >> bd_shift;
                     deq[j][i] = (int)(d < -32768 ? -32768 : d > 32767 ? 32767 : d);
+                    if (cg && lv) { bits += rate_level((int)a); dsum += (long long)deq[j][i] * (2 * c - deq[j][i]); }
                 }
             }
             store_rows(s.lvl, l, lev);
-            if (any) ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
             store_pairs(l, deq);
+            if (cg) { cg_d[k] = dsum; cg_b[k] = bits; }          // the TU's cbf bit waits for the group decision
+            else if (any) ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
+        }
+    });
+    if (cg_lam_q4 > 0) ex.phase([&](int tid) {      // coefficient groups: keep or drop
+        const int nbl = 1 << (2 * rg.log2n - 3), per_l = 1 << (rg.log2n - 2), per_c = per_l >> 1;
+        for (int k = tid; k < nblk; k += NT) {
+            const int idx = rg.block_index(k);
+            SampleLoc l = unpack_loc(s.desc[idx], idx);
+            if (!l.log2n || l.intra || !cg_b[k]) continue;
+            const int mate = k ^ (k < nbl ? per_l : per_c);          // the block above / below in the same 4x4 group
+            const long long d = cg_d[k] + cg_d[mate];
+            const int bits = cg_b[k] + cg_b[mate] + R_SB, tsh = 2 * (15 - bit_depth - l.log2n);
+            if (16 * d < ((((long long)cg_lam_q4 * bits) >> 4) << tsh)) {
+                const int zero[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                store_rows(s.lvl, l, zero);
+                store_pairs(l, zero);
+            } else ex.atomic_or(&s.cbf[l.plane], 1u << l.tile0);
         }
     });
     ex.phase([&](int tid) {      // inverse stage 1: columns, shift 7, clip to 16 bit (8.6.4.2)

@@ -454,7 +454,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
         return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0, s->cfg.pre_search != 0, s->cfg.rdo_zero != 0, s->cfg.chroma_modes != 0,
-                          s->cfg.slice_count > 1 && s->cfg.slice_index > 0, s->cfg.slice_count > 1 && s->cfg.slice_index < s->cfg.slice_count - 1};
+                          s->cfg.slice_count > 1 && s->cfg.slice_index > 0, s->cfg.slice_count > 1 && s->cfg.slice_index < s->cfg.slice_count - 1, std::max(0, s->cfg.rdo_cg)};
     };
     const int64_t first_index = s->frames_in - n;
     {

@@ -91,6 +91,9 @@ typedef struct mihevc_config {
     int32_t gop_balance;              /* 1 (default): a run of pictures between scene cuts / chunk ends is coded as the fewest GOPs keyint allows, of
                                        * near-equal length (300 pictures at keyint 90: IDR at 0, 75, 150, 225), so the GOP lanes of the device pipeline finish
                                        * together; 0: IDR every keyint pictures (0, 90, 180, 270).  The number of IDR pictures is the same either way */
+    int32_t rdo_cg;                   /* k > 0: RD zero-out of the 4x4 coefficient groups of inter TUs ("RDOQ-lite"): a group of levels is dropped when the
+                                       * squared error it removes is worth less than lambda x k / 2 x its bits.  Default 0 (off): over whole GOPs of the bench
+                                       * clip it buys nothing that a higher QP would not (k = 2: -0.6 % bits / -0.006 dB, k = 5: -8.5 % / -0.16 dB at QP 27) */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -154,6 +157,7 @@ typedef struct mihevc_cost_params {
     int32_t chroma_modes;             /* 1: chroma intra mode decision (else DM) */
     int32_t mc_top, mc_bottom;        /* 1: motion compensation must not read above row 0 / below the last row (the picture is a slice whose
                                        * neighbour lives on another device); 0: the padded border is the picture's own */
+    int32_t rdo_cg;                   /* k > 0: RD zero-out of 4x4 coefficient groups of inter TUs with lambda x k / 2; 0: off */
 } mihevc_cost_params;
 void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_params *out);   /* tile grid 1x1, every analysis knob 0 */
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every

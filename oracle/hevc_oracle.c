@@ -435,9 +435,42 @@ void orc_pad_plane(pix *p, int stride, int w, int h, int pad)
 /* ------------------------------------------------------------------------------------------------
  * Residual coding of one TU (shared by intra and inter): returns cbf, writes levels + reconstruction.
  * ------------------------------------------------------------------------------------------------ */
+/* RD zero-out of 4x4 coefficient groups ("RDOQ-lite"), inter TUs only, cg_lam_q4 > 0: a group of levels is dropped when the
+ * distortion it removes does not pay for its bits.  Everything is decided in the coefficient domain from what the quantiser already holds: with
+ * c the transform coefficient and r its reconstruction (orc_dequant), dropping the group adds  D = sum r (2c - r)  (= sum c^2 - (c - r)^2) of
+ * squared coefficient error, which is  D >> 2 (15 - bitDepth - log2n)  of squared sample error (the transform's gain), and saves the rate model's
+ * bits = sum level bits + one sub-block (ORC_R_*, 1/16 bit).  Drop  <=>  16 D < ((cg_lam_q4 * bits) >> 4) << 2 (15 - bitDepth - log2n).
+ * No context modelling and no last-position search: every group decides alone, which is what makes it one short phase on the GPU. */
+static int cg_zero_out(const int16_t *coef, int16_t *lvl, int log2n, int qp, int bit_depth, int cg_lam_q4)
+{
+    int n = 1 << log2n, tsh = 2 * (15 - bit_depth - log2n), nnz = 0;
+    int16_t deq[32 * 32];
+    orc_dequant(lvl, deq, log2n, qp, bit_depth);
+    for (int sy = 0; sy < n; sy += 4)
+        for (int sx = 0; sx < n; sx += 4) {
+            int64_t d = 0;
+            int bits = 0, cnt = 0;
+            for (int y = 0; y < 4; y++)
+                for (int x = 0; x < 4; x++) {
+                    int i = (sy + y) * n + sx + x, a = iabs(lvl[i]);
+                    if (!a) continue;
+                    cnt++;
+                    bits += ORC_R_LEVEL(a);
+                    d += (int64_t)deq[i] * (2 * (int64_t)coef[i] - deq[i]);
+                }
+            if (!cnt) continue;
+            bits += ORC_R_SB;
+            if (16 * d < ((((int64_t)cg_lam_q4 * bits) >> 4) << tsh)) {
+                for (int y = 0; y < 4; y++)
+                    for (int x = 0; x < 4; x++) lvl[(sy + y) * n + sx + x] = 0;
+            } else nnz += cnt;
+        }
+    return nnz;
+}
+
 static int code_tu(const pix *src, int sstride, const pix *pred, int pstride, pix *rec, int rstride,
                    int16_t *coef_out, int cstride, int log2n, int qp, int bit_depth, int intra, int dst,
-                   int64_t *sse_out, int *bits_q4_out)
+                   int64_t *sse_out, int *bits_q4_out, int cg_lam_q4)
 {
     int n = 1 << log2n, maxv = (1 << bit_depth) - 1;
     int16_t res[32 * 32], coef[32 * 32], lvl[32 * 32], rc[32 * 32];
@@ -445,6 +478,7 @@ static int code_tu(const pix *src, int sstride, const pix *pred, int pstride, pi
         for (int x = 0; x < n; x++) res[y * n + x] = (int16_t)(src[y * sstride + x] - pred[y * pstride + x]);
     orc_fwd_transform(res, n, coef, log2n, dst, bit_depth);
     int nnz = orc_quant(coef, lvl, log2n, qp, bit_depth, intra);
+    if (nnz && cg_lam_q4 > 0 && !intra) nnz = cg_zero_out(coef, lvl, log2n, qp, bit_depth, cg_lam_q4);
     for (int y = 0; y < n; y++)
         for (int x = 0; x < n; x++) coef_out[y * cstride + x] = lvl[y * n + x];
     if (nnz) {
@@ -490,7 +524,8 @@ static int code_tu_inter(const pix *src, int sstride, const pix *pred, int pstri
 {
     int64_t sse;
     int bits;
-    int cbf = code_tu(src, sstride, pred, pstride, rec, rstride, coef_out, cstride, log2n, qp, bit_depth, 0, 0, &sse, &bits);
+    int cbf = code_tu(src, sstride, pred, pstride, rec, rstride, coef_out, cstride, log2n, qp, bit_depth, 0, 0, &sse, &bits,
+                      prm->rdo_cg > 0 ? (int)(((int64_t)prm->lambda_q4 * prm->rdo_cg) >> 1) : 0);
     if (!cbf || !prm->rdo_zero) return cbf;
     int n = 1 << log2n;
     int64_t sse0 = 0;
@@ -1031,13 +1066,13 @@ static void intra_plan_ctu(const intra_ctx *c, int x0, int y0, intra_plan *pl)
                 int bits, bits_total = 16 * intra_mode_bits(cand, mode) + 16 + 24 + (cmode != mode ? 32 : 0);
                 orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
                 orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
-                code_tu(s, c->sstride[0], pred, n, rec_tmp, n, coef_tmp, n, log2n, prm->qp, bd, 1, 0, &sse, &bits);
+                code_tu(s, c->sstride[0], pred, n, rec_tmp, n, coef_tmp, n, log2n, prm->qp, bd, 1, 0, &sse, &bits, 0);
                 sse_total += sse; bits_total += bits;
                 for (int ci = 1; ci < 3; ci++) {
                     int xc = x >> 1, yc = y >> 1, l2 = log2n - 1, nc = n >> 1;
                     orc_intra_build_ref_tiles(c->src[ci], c->sstride[ci], xc, yc, l2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
                     orc_intra_pred(ref, pred, nc, l2, cmode, ci, bd);
-                    code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc, rec_tmp, nc, coef_tmp, nc, l2, prm->qp_c, bd, 1, 0, &sse, &bits);
+                    code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc, rec_tmp, nc, coef_tmp, nc, l2, prm->qp_c, bd, 1, 0, &sse, &bits, 0);
                     sse_total += sse; bits_total += bits;
                 }
                 J[nd] = ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);
@@ -1082,7 +1117,7 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n, int mode, int cm
     orc_intra_filter_ref(ref, filt, log2n, mode, 0, bd, 1);
     orc_intra_pred(filt, pred, n, log2n, mode, 0, bd);
     if (code_tu(s, c->sstride[0], pred, n, c->rec[0] + y * c->rstride[0] + x, c->rstride[0],
-                c->coef[0] + y * c->w + x, c->w, log2n, prm->qp, bd, 1, 0, &sse, &bits)) flags |= ORC_F_CBF_Y;
+                c->coef[0] + y * c->w + x, c->w, log2n, prm->qp, bd, 1, 0, &sse, &bits, 0)) flags |= ORC_F_CBF_Y;
     sse_total += sse; bits_total += bits;
     /* intra_chroma_pred_mode (7.4.9.6 / Table 8-2) other than DM: 2 more bits in the rate estimate */
     if (cmode != mode) bits_total += 32;
@@ -1092,7 +1127,7 @@ static uint64_t intra_cu(intra_ctx *c, int x, int y, int log2n, int mode, int cm
         orc_intra_pred(ref, pred, nc, l2, cmode, ci, bd);
         if (code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, nc,
                     c->rec[ci] + yc * c->rstride[ci] + xc, c->rstride[ci], c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1,
-                    l2, prm->qp_c, bd, 1, 0, &sse, &bits)) flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
+                    l2, prm->qp_c, bd, 1, 0, &sse, &bits, 0)) flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
         sse_total += sse; bits_total += bits;
     }
     for (int yy = 0; yy < n; yy += 8)
@@ -1138,7 +1173,7 @@ static uint64_t intra_cu_nxn(intra_ctx *c, int x, int y)
         orc_intra_filter_ref(ref, filt, 2, mode, 0, bd, 1);
         orc_intra_pred(filt, pred, 4, 2, mode, 0, bd);
         if (code_tu(s, c->sstride[0], pred, 4, c->rec[0] + yp * c->rstride[0] + xp, c->rstride[0], c->coef[0] + yp * c->w + xp, c->w,
-                    2, prm->qp, bd, 1, 1 /* DST-VII */, &sse, &bits)) { r->cbf_y4 |= (uint8_t)(1 << k); r->flags |= ORC_F_CBF_Y; }
+                    2, prm->qp, bd, 1, 1 /* DST-VII */, &sse, &bits, 0)) { r->cbf_y4 |= (uint8_t)(1 << k); r->flags |= ORC_F_CBF_Y; }
         sse_total += sse; bits_total += 16 * intra_mode_bits(cand, mode) + bits;
     }
     int cmode = r->intra_mode[0];
@@ -1148,7 +1183,7 @@ static uint64_t intra_cu_nxn(intra_ctx *c, int x, int y)
         orc_intra_build_ref_tiles(c->rec[ci], c->rstride[ci], xc, yc, 2, c->w >> 1, c->h >> 1, ci, bd, prm->tile_cols, prm->tile_rows, ref);
         orc_intra_pred(ref, pred, 4, 2, cmode, ci, bd);
         if (code_tu(c->src[ci] + yc * c->sstride[ci] + xc, c->sstride[ci], pred, 4, c->rec[ci] + yc * c->rstride[ci] + xc, c->rstride[ci],
-                    c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1, 2, prm->qp_c, bd, 1, 0, &sse, &bits)) r->flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
+                    c->coef[ci] + yc * (c->w >> 1) + xc, c->w >> 1, 2, prm->qp_c, bd, 1, 0, &sse, &bits, 0)) r->flags |= ci == 1 ? ORC_F_CBF_CB : ORC_F_CBF_CR;
         sse_total += sse; bits_total += bits;
     }
     return ((uint64_t)sse_total << 4) + (((uint64_t)prm->lambda_q4 * (uint64_t)bits_total) >> 4);

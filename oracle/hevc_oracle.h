@@ -74,6 +74,7 @@ typedef struct {
     int rdo_zero;             /* 1: an inter TU whose levels cost more (lambda * bits) than the distortion they remove is coded as all-zero */
     int chroma_modes;         /* 1: 2Nx2N intra CUs choose intra_chroma_pred_mode among planar / vertical / horizontal / DC / DM by SATD */
     int mc_top, mc_bottom;    /* 1: the picture is a slice whose upper / lower neighbour is coded elsewhere: motion compensation must not read across that edge */
+    int rdo_cg;               /* k > 0: RD zero-out of the 4x4 coefficient groups of inter TUs with lambda x k / 2 (see code_tu); 0: off */
 } orc_params;
 
 /* ---- primitives (clauses of H.265 in the .c) ---- */

@@ -28,7 +28,7 @@ def build(force: bool = False) -> Path:
 
 class Params(C.Structure):
     _fields_ = [("qp", C.c_int), ("qp_c", C.c_int), ("bit_depth", C.c_int), ("lambda_sad_q4", C.c_int),
-                ("lambda_q4", C.c_int), ("me_range", C.c_int), ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("intra_nxn", C.c_int), ("intra_in_p", C.c_int), ("pre_search", C.c_int), ("rdo_zero", C.c_int), ("chroma_modes", C.c_int), ("mc_top", C.c_int), ("mc_bottom", C.c_int)]
+                ("lambda_q4", C.c_int), ("me_range", C.c_int), ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("intra_nxn", C.c_int), ("intra_in_p", C.c_int), ("pre_search", C.c_int), ("rdo_zero", C.c_int), ("chroma_modes", C.c_int), ("mc_top", C.c_int), ("mc_bottom", C.c_int), ("rdo_cg", C.c_int)]
 
 
 CU_DTYPE = np.dtype([("log2_size", "u1"), ("flags", "u1"), ("chroma_mode", "u1"), ("qp", "u1"), ("intra_mode", "u1", (4,)),

@@ -55,7 +55,7 @@ template <typename T> struct Padded {
 
 static CostParams to_prm(const mihevc_cost_params *p)
 {
-    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search, p->rdo_zero, p->chroma_modes, p->mc_top, p->mc_bottom};
+    return CostParams{p->qp, p->qp_c, p->bit_depth, p->lambda_sad_q4, p->lambda_q4, p->me_range, p->tile_cols, p->tile_rows, p->intra_nxn, p->intra_in_p, p->pre_search, p->rdo_zero, p->chroma_modes, p->mc_top, p->mc_bottom, p->rdo_cg};
 }
 
 // ---- EMU_WAVES=<seed>: the four waves of a workgroup as four host threads -------------------------------------------------------------

@@ -61,6 +61,7 @@ def session_params(lib, cfg, qp, idr):
     cp.intra_nxn, cp.intra_in_p, cp.pre_search, cp.rdo_zero, cp.chroma_modes = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.chroma_modes
     prm = O.Params(cp.qp, cp.qp_c, cp.bit_depth, cp.lambda_sad_q4, cp.lambda_q4, cp.me_range, cp.tile_cols, cp.tile_rows, cp.intra_nxn, cp.intra_in_p,
                    cp.pre_search, cp.rdo_zero, cp.chroma_modes)
+    prm.rdo_cg = cp.rdo_cg = max(0, cfg.rdo_cg)
     return prm, cp
 
 

@@ -69,6 +69,7 @@ def test_stage_parity_i_p_p(lib, api, w, h, qp, bd, rng):
     prm_i, cp_i = lib_params(lib, max(0, qp - 3), bd, rng)
     prm_p, cp_p = lib_params(lib, qp, bd, rng)
     prm_p.rdo_zero = cp_p.rdo_zero = int(qp >= 24)       # RD zero-out of inter TUs on for the higher QPs, off for the rest
+    prm_p.rdo_cg = cp_p.rdo_cg = 5 if 22 <= qp <= 30 else 0   # RD zero-out of 4x4 coefficient groups at the session's default strength / off
     prm_i.chroma_modes = cp_i.chroma_modes = int(qp < 35)  # chroma intra mode decision
     srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
     want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
@@ -211,7 +212,7 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # 544x160: IDR pictures carry a 2x2 tile grid (PPS 1)
     prm_i.intra_nxn = prm_p.intra_nxn = cfg.intra_nxn            # NxN trial when the session asks for it
     prm_i.chroma_modes = prm_p.chroma_modes = cfg.chroma_modes   # default 1
-    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero   # session defaults: pre-search and RD zero-out on
+    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg   # session defaults: pre-search and both RD zero-outs on
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     idr = util.idr_positions(n, keyint, cfg.gops_in_flight)       # (132, 76, keyint 5, 7 pictures): GOPs of 4 + 3, not 5 + 2
     ref = None
@@ -268,7 +269,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
     ref = None
     for i, f in enumerate(frames):
         prm, _ = lib_params(lib, qps[i], bd, 8)
-        prm.intra_nxn, prm.intra_in_p, prm.pre_search, prm.rdo_zero = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero
+        prm.intra_nxn, prm.intra_in_p, prm.pre_search, prm.rdo_zero, prm.rdo_cg = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
         prm.chroma_modes = cfg.chroma_modes
         a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)

@@ -38,6 +38,7 @@ def test_stepped_kernels_equal_oracle(emu, w, h, qp, bd, rng):
     prm_i = O.default_params(max(0, qp - 3), bit_depth=bd, me_range=rng)
     prm_p = O.default_params(qp, bit_depth=bd, me_range=rng)
     prm_p.rdo_zero = int(qp >= 26)               # RD zero-out of inter TUs on for the higher QPs (where it bites), off for the rest
+    prm_p.rdo_cg = 5 if 22 <= qp <= 30 else 0    # RD zero-out of 4x4 coefficient groups: the session's default strength / off
     prm_i.chroma_modes = int(qp < 35)            # chroma intra mode decision on for most cases (4x4, 8x8 and 16x16 chroma blocks)
     srcs = [util.synth_frame(h, w, seed=3, shift=(2 * i, i), bit_depth=bd) for i in range(3)]
     want = util.run_pipeline(O, srcs, prm_i, prm_p, bd)
@@ -139,7 +140,7 @@ def test_phase_programs_do_not_depend_on_thread_order_or_initial_lds(emu, monkey
     if fill:
         monkeypatch.setenv("EMU_SHARED_FILL", fill)
     prm = O.default_params(24, bit_depth=8, me_range=8)
-    prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search = 1, 1, 1, 1
+    prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search, prm.rdo_cg = 1, 1, 1, 1, 5
     srcs = [util.synth_frame(104, 136, seed=31, shift=(3 * i, i), bit_depth=8) for i in range(2)]
     want, got = O.analyze_intra(srcs[0], prm), emu.intra(srcs[0], prm)
     assert util.same_analysis(want, got), util.describe_diff(want, got)
@@ -156,7 +157,7 @@ def test_waves_as_threads_with_real_barriers(emu, monkeypatch):
     from tests.test_bitstream_cpu import occluded_clip
     monkeypatch.setenv("EMU_WAVES", "5")
     prm = O.default_params(24, bit_depth=8, me_range=8)
-    prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search, prm.intra_in_p = 1, 1, 1, 1, 1
+    prm.intra_nxn, prm.chroma_modes, prm.rdo_zero, prm.pre_search, prm.intra_in_p, prm.rdo_cg = 1, 1, 1, 1, 1, 5
     srcs = occluded_clip(136, 104, 8)
     want, got = O.analyze_intra(srcs[0], prm), emu.intra(srcs[0], prm)
     assert (want.cu["flags"] & 16).any()
