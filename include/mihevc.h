@@ -74,7 +74,8 @@ typedef struct mihevc_config {
     int32_t pre_search;               /* 1 (default): search centres from a +-14 full search on the 1/4-size pictures, so the +-me_range
                                        * integer search follows motion up to +-56 samples; 0: centres at zero */
     int32_t rdo_zero;                 /* 1 (default): inter TUs whose levels cost more (lambda x bits) than the distortion they remove are
-                                       * coded as all-zero (-2.5 % bits at -0.01 dB on the bench clip's P pictures) */
+                                       * coded as all-zero (whole 300-picture bench clip: -12 % bits at -0.14 dB at fixed QP 27, +0.02 dB at equal bitrate
+                                       * under the rate controller) */
     int32_t chroma_modes;             /* 1 (default): 2Nx2N intra CUs choose intra_chroma_pred_mode among DM / planar / vertical / horizontal /
                                        * DC by SATD over Cb + Cr; 0: always DM */
     /* ---- one picture over several devices (BASELINE configs[4]): a session may code ONE SLICE — a full-width band of CTU rows — of
