@@ -347,6 +347,9 @@ def main():
             raise SystemExit(f"bench.py: rank {rank} wants device {local} but only {torch.cuda.device_count()} are visible")
         local %= torch.cuda.device_count()      # rehearsal of the multi-rank path on a box with fewer devices: ranks share them, the line says so
     torch.cuda.set_device(local)
+    torch.cuda.init()                                 # torch's HIP runtime comes up before libmihevc's
+    from hevc_amd.utils import bind_to_device_node
+    numa_node = bind_to_device_node(local)            # one process per GPU: CABAC workers and pinned buffers on the device's NUMA node
     ranks = Ranks(rank, world)
 
     from hevc_amd import _lib
@@ -487,7 +490,7 @@ def main():
             "quality": {"psnr_y_db": round(psnr, 3), "bitrate_kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 1), "vbv_maxrate_kbps": maxrate,
                         "libx265_parity": "see `libx265`" if ok265 else why265},
             "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(stage_ms[i] / max(1.0, stage_pics[i]), 4) for i in range(8)},
-            "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count(),
+            "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count(), "numa_node": numa_node, "cpus_bound": len(os.sched_getaffinity(0)),
                      "step_phases_ms": dict(zip(("open", "send", "flush_drain", "close"), [round(x / args.steps * 1e3, 2) for x in phase_s])),
                      "device_ms_per_step": round(st.device_ms, 2)},
             "roofline": {"bound": "hbm", "kernel": _lib.STAGE_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -42,7 +42,7 @@ class CostParams(C.Structure):
 
 # every symbol include/mihevc.h declares; tests/test_abi.py checks the header against this list and the .so
 EXPORTS = (
-    "mihevc_abi_version", "mihevc_device_count", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_device",
+    "mihevc_abi_version", "mihevc_device_count", "mihevc_device_numa_node", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_device",
     "mihevc_receive_packet", "mihevc_flush", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
     "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_tile_grid", "mihevc_k_transform",
     "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_write_parameter_sets",

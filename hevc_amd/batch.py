@@ -45,6 +45,9 @@ def _proc_worker(slot, device, task_q, result_q, stop_ev, out_dir, kw, convert_r
     """Body of one worker process: files arrive one at a time from the parent; progress is throttled to ~10 messages a second."""
     mod, name = convert_ref
     convert = getattr(importlib.import_module(mod), name)
+    if device is not None and device >= 0:
+        from .utils import bind_to_device_node
+        bind_to_device_node(device)          # this process drives one device: its threads and pinned buffers stay on that device's NUMA node
     while True:
         f = task_q.get()
         if f is None:

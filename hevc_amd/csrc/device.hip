@@ -1,6 +1,7 @@
 // hevc_amd/csrc/device.hip — __global__ entry points, launchers and the per-stage C-ABI functions (mihevc_k_*).
 #include "device.h"
 
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -656,6 +657,20 @@ int select_device(int device)
 extern "C" {
 
 int mihevc_device_count(void) { return gfx950_device_count(); }
+int mihevc_device_numa_node(int device)
+{
+    char bus[64] = {0};
+    if (device < 0 || device >= gfx950_device_count() || hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess) return -1;
+    for (char *c = bus; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');      // sysfs names are lower case
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    return node;
+}
 
 int mihevc_k_transform(int device, const int16_t *residual, int16_t *levels, int16_t *recon_residual, int n_blocks, int log2n, int qp,
                        int bit_depth, int intra, int dst4)

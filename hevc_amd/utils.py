@@ -6,6 +6,7 @@ hevc_nvenc helpers (`has_nvenc`, `detect_gpu_type`, the NVENC argv) are out of s
 """
 from __future__ import annotations
 
+import os
 import logging
 import shutil
 import subprocess
@@ -45,6 +46,36 @@ def mi355x_device_count() -> int:
 
 def has_mi355x() -> bool:
     return mi355x_device_count() > 0
+
+
+def parse_cpulist(text: str) -> set:
+    """'0-3,8,10-11' (the kernel's cpulist format) -> {0, 1, 2, 3, 8, 10, 11}"""
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_device_node(device: int, min_cpus: int = 8):
+    """One process per GPU: run this process (and every thread it starts from now on: the library's CABAC workers, the pinned-buffer
+    allocations' first touch) on the CPUs of the NUMA node next to `device`.  Returns the node, or None when the platform does not name one,
+    the node has fewer than `min_cpus` usable CPUs, or anything about it fails — binding is an optimisation, never an error."""
+    try:
+        from . import _lib
+        node = int(_lib.load().mihevc_device_numa_node(device))
+        if node < 0:
+            return None
+        with open(f'/sys/devices/system/node/node{node}/cpulist') as f:
+            cpus = parse_cpulist(f.read()) & os.sched_getaffinity(0)
+        if len(cpus) < min_cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:       # noqa: BLE001
+        return None
 
 
 def build_hdr_metadata(master_display: str, max_cll: str, use_nvenc: bool = False, fps: float = 30.0) -> List[str]:

@@ -115,6 +115,10 @@ typedef struct mihevc_stats {
 
 int  mihevc_abi_version(void);
 int  mihevc_device_count(void);                      /* gfx950 devices visible; 0 when none / no runtime */
+/* NUMA node of the host memory closest to `device` (its PCI function's numa_node in sysfs); -1 when the platform does not say.  A process that
+ * drives one device (one process per GPU: bench.py, hevc_amd/batch.py) binds itself to that node's CPUs BEFORE its first mihevc_open, so the pinned
+ * symbol buffers and the CABAC workers that read them sit next to the device (hevc_amd/utils.py: bind_to_device_node). */
+int  mihevc_device_numa_node(int device);
 void mihevc_config_default(mihevc_config *cfg);      /* 1080p30 8-bit SDR at the reference's operating point */
 int  mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out);
 /* Caller-owned host planes (8-bit: 1 byte/sample, 10-bit: 2 bytes little endian), copied/uploaded before return. */

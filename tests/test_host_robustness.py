@@ -121,3 +121,16 @@ def test_mp4_chunk_offset_width_is_decided_once(tmp_path):
         off = struct.unpack(">Q" if want64 else ">I", data[b[1] + 8:b[2]])[0]
         assert off == lay["chunk_offset"] == 28 + len(data) + (16 if want64 else 8)      # ftyp (28 bytes) + moov + mdat header
         w.abort()
+
+
+def test_cpulist_parsing_and_numa_binding_is_optional():
+    """hevc_amd.utils.bind_to_device_node: one process per GPU pins itself to the device's NUMA node; without a device (this container) or without
+    sysfs information it returns None and leaves the affinity alone."""
+    import os
+    from hevc_amd.utils import bind_to_device_node, parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and parse_cpulist("") == set() and parse_cpulist("5") == {5}
+    before = os.sched_getaffinity(0)
+    assert bind_to_device_node(0) is None or len(os.sched_getaffinity(0)) >= 8
+    if bind_to_device_node(99) is None:
+        pass
+    assert os.sched_getaffinity(0) <= before
