@@ -509,6 +509,8 @@ struct GpuExec {
     DEV void atomic_or(unsigned *p, unsigned v) { atomicOr(p, v); }
     DEV void atomic_and(unsigned *p, unsigned v) { atomicAnd(p, v); }
     DEV void atomic_min(unsigned long long *p, unsigned long long v) { atomicMin(p, v); }
+    // a plain read of a word other lanes update with atomic_min: only good for skipping an atomic that could not win
+    DEV unsigned long long peek(const unsigned long long *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
     DEV void atomic_add_global(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
 };
 #endif
@@ -538,6 +540,7 @@ struct SeqExec {      // sequential stepping of a phase program (tests/emu)
     void atomic_or(unsigned *p, unsigned v) { *p |= v; }
     void atomic_and(unsigned *p, unsigned v) { *p &= v; }
     void atomic_min(unsigned long long *p, unsigned long long v) { if (v < *p) *p = v; }
+    unsigned long long peek(const unsigned long long *p) { return *p; }
     void atomic_add_global(unsigned long long *p, unsigned long long v) { *p += v; }
 };
 

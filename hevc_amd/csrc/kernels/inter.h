@@ -296,7 +296,7 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                 for (int j = 1; j < 4; j++) { const unsigned kj = (sad[j] << ksh) + bitsj[j]; k = kj < k ? kj : k; }
                 if (!((ok >> node) & 1)) return;
                 const unsigned long long key = ((unsigned long long)(k >> 2) << 16) | (pos0 + (k & 3));
-                if (key < s.best[node]) ex.atomic_min(&s.best[node], key);
+                if (key < ex.peek(&s.best[node])) ex.atomic_min(&s.best[node], key);
             };
 #pragma unroll
             for (int half = 0; half < 2; half++) {

@@ -108,6 +108,7 @@ struct WaveExec {
         unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
         while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     }
+    unsigned long long peek(const unsigned long long *p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
     void atomic_add_global(unsigned long long *p, unsigned long long v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 };
 // run one workgroup program on four wave threads; false when a barrier broke
