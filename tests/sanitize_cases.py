@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Driver of tools/sanitize_cpu.sh: steps the kernel sources (tests/emu) against the oracle on a few pictures with the emulator library given in
+"""Driver of tests/sanitize_cpu.sh: steps the kernel sources (tests/emu) against the oracle on a few pictures with the emulator library given in
 EMU_LIB (an ASAN/UBSAN or TSAN build).  EMU_WAVES set: four wave threads with real barriers.  Test infrastructure, not product."""
 import ctypes as C
 import os

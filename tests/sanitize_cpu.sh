@@ -1,5 +1,5 @@
 #!/bin/bash
-# Sanitizer runs of everything that has a CPU build (GPU sanitizers do not exist on this pool): bash tools/sanitize_cpu.sh
+# Sanitizer runs of everything that has a CPU build (GPU sanitizers do not exist on this pool): bash tests/sanitize_cpu.sh
 #  1. kernel sources stepped on the CPU (tests/emu) under ASAN + UBSAN, sequential lanes
 #  2. the same under TSAN with four wave threads and real barriers (EMU_WAVES)
 #  3. oracle + decoder (oracle/) and the host coder (bitstream.cpp, api_host.cpp built with g++) under ASAN + UBSAN: their pytest files
@@ -13,12 +13,12 @@ tmp=$(mktemp -d /tmp/mihevc_san.XXXXXX)
 fail=0
 echo "== 1. stepped kernels, ASAN + UBSAN"
 g++ -std=c++17 -O1 -g -fPIC -shared -w -pthread -fsanitize=address,undefined -o $tmp/libemu_asan.so tests/emu/emu.cpp
-EMU_LIB=$tmp/libemu_asan.so LD_PRELOAD=$asan ASAN_OPTIONS=detect_leaks=0 python3 tools/sanitize_cases.py > $tmp/1.log 2>&1 || fail=1
+EMU_LIB=$tmp/libemu_asan.so LD_PRELOAD=$asan ASAN_OPTIONS=detect_leaks=0 python3 tests/sanitize_cases.py > $tmp/1.log 2>&1 || fail=1
 grep -E "^ok|runtime error|ERROR: AddressSanitizer" $tmp/1.log | sort | uniq -c
 grep -qE "runtime error|ERROR: AddressSanitizer" $tmp/1.log && fail=1
 echo "== 2. stepped kernels on four wave threads, TSAN"
 g++ -std=c++17 -O1 -g -fPIC -shared -w -pthread -fsanitize=thread -o $tmp/libemu_tsan.so tests/emu/emu.cpp
-EMU_WAVES=7 EMU_LIB=$tmp/libemu_tsan.so LD_PRELOAD=$gccdir/libtsan.so TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" python3 tools/sanitize_cases.py > $tmp/2.log 2>&1 || fail=1
+EMU_WAVES=7 EMU_LIB=$tmp/libemu_tsan.so LD_PRELOAD=$gccdir/libtsan.so TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" python3 tests/sanitize_cases.py > $tmp/2.log 2>&1 || fail=1
 grep -E "^ok|SUMMARY: ThreadSanitizer" $tmp/2.log | cut -c1-160 | sort | uniq -c
 grep -q "WARNING: ThreadSanitizer" $tmp/2.log && fail=1
 echo "== 3. oracle + decoder + host coder, ASAN + UBSAN"
