@@ -530,9 +530,9 @@ def main():
     ranks.close()
 
 
-def run_2160p(local, operating_point, step, SyntheticClip, verify, torch, n=120):
-    """BASELINE configs[2]: 3840x2160 Main10 HDR10 at the reference's operating point, 120 frames (2 closed GOPs of keyint 60: half of the 4 lanes
-    a longer clip keeps busy): frames resident in HBM as for the headline value, and handed over as pageable host buffers (PCIe-inclusive)."""
+def run_2160p(local, operating_point, step, SyntheticClip, verify, torch, n=300):
+    """BASELINE configs[2]: 3840x2160 Main10 HDR10 at the reference's operating point, the 300-frame clip SURVEY §8d names (5 closed GOPs of
+    keyint 60, one lane each): frames resident in HBM (7.5 GB) as for the headline value, and handed over as pageable host buffers (PCIe-inclusive)."""
     w, h = 3840, 2160
     info, cfg, (crf, maxrate, bufsize, gop) = operating_point(w, h, n, True)
     clip = SyntheticClip("motion", 0, w, h, n, bit_depth=10)

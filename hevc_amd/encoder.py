@@ -35,6 +35,15 @@ def bit_depth_of(info: VideoInfo) -> int:
     return 10 if (info.hdr or '10' in fmt) else 8
 
 
+def lanes_for(total_frames: int, keyint: int) -> int:
+    """GOP lanes of the session's lock-step pipeline (`gops_in_flight`): a chunk is lanes x keyint pictures and its GOPs run side by side, so a clip
+    of up to 8 GOPs is one chunk with every GOP its own lane, longer clips run 8 at a time (more lanes fill the launches better: +2.6 % measured
+    from 4 to 8 on one MI355X); 4 is the floor and what an unknown length gets."""
+    if total_frames <= 0 or keyint <= 0:
+        return 4
+    return max(4, min(8, -(-total_frames // keyint)))
+
+
 def config_for(info: VideoInfo, crf: int, vbv_maxrate: int, vbv_bufsize: int, gop: int, level: str, tier: str,
                master_display: str = "", max_cll: str = "") -> _lib.Config:
     """Map the reference's libx265 operating point (build_ffmpeg_params CPU branch) onto a mihevc_config."""
@@ -51,6 +60,7 @@ def config_for(info: VideoInfo, crf: int, vbv_maxrate: int, vbv_bufsize: int, go
     cfg.crf, cfg.qp = int(crf), -1
     cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = int(vbv_maxrate), int(vbv_bufsize)
     cfg.keyint, cfg.min_keyint = int(gop), max(2, int(gop) // 2)
+    cfg.gops_in_flight = lanes_for(int(getattr(info, 'nb_frames', 0) or 0), int(gop))
     if hdr:   # the HDR10 set of core/utils.py:58-69
         cfg.colour_primaries, cfg.transfer, cfg.matrix = 9, 16, 9
         cfg.chroma_loc, cfg.aud, cfg.repeat_headers, cfg.hdr10, cfg.hrd = 0, 1, 1, 1, 1       # ... hrd=1:aud=1:chromaloc=0:repeat-headers=1
