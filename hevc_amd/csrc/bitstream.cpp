@@ -932,10 +932,18 @@ private:
         const int l2sb = log2n - 2, nsb = 1 << l2sb, n = 1 << log2n;
         const uint8_t(*sbscan)[2] = kScans.xy[scan][l2sb];
         const uint8_t(*pscan)[2] = kScans.xy[scan][2];
+        // a 4x4 sub-block without a level, seen in four 64-bit reads: most sub-blocks of a P picture's TUs are, and gathering their 16 levels in scan
+        // order one by one was the larger part of this function's time
+        auto empty = [stride](const int16_t *b) {
+            uint64_t r[4];
+            for (int j = 0; j < 4; j++) memcpy(&r[j], b + (size_t)j * stride, 8);
+            return ((r[0] | r[1]) | (r[2] | r[3])) == 0;
+        };
         // gather sub-blocks in scan order, find the last significant position
         int last_sb = -1, last_pos = -1;
         for (int i = (1 << (2 * l2sb)) - 1; i >= 0 && last_sb < 0; i--) {
             const int16_t *b = lv + (size_t)(sbscan[i][1] << 2) * stride + (sbscan[i][0] << 2);
+            if (empty(b)) continue;
             for (int k = 15; k >= 0; k--)
                 if (b[pscan[k][1] * stride + pscan[k][0]]) { last_sb = i; last_pos = k; break; }
         }
@@ -961,10 +969,14 @@ private:
         for (int i = last_sb; i >= 0; i--) {
             int xs = sbscan[i][0], ys = sbscan[i][1];
             const int16_t *b = lv + (size_t)(ys << 2) * stride + (xs << 2);
+            int right = xs + 1 < nsb ? csbf[ys][xs + 1] : 0, below = ys + 1 < nsb ? csbf[ys + 1][xs] : 0;
+            if (i < last_sb && i > 0 && empty(b)) {          // coded_sub_block_flag 0 and nothing else
+                cabac_.bin(kCsbf + ((right | below) ? 1 : 0) + (c_idx ? 2 : 0), 0);
+                continue;
+            }
             int lev[16], nsig = 0;
             int start = i == last_sb ? last_pos : 15;
             for (int k = 0; k < 16; k++) { lev[k] = k <= start ? b[pscan[k][1] * stride + pscan[k][0]] : 0; nsig += lev[k] != 0; }
-            int right = xs + 1 < nsb ? csbf[ys][xs + 1] : 0, below = ys + 1 < nsb ? csbf[ys + 1][xs] : 0;
             bool infer_dc = false;
             if (i < last_sb && i > 0) {
                 csbf[ys][xs] = nsig != 0;
