@@ -502,7 +502,7 @@ def main():
                          "note": "integer-VALU/LDS bound path: the HBM fraction is small by construction (SURVEY.md §0.5); valu_issue_frac is the "
                                  "share of SIMD issue slots the kernel fills, from the committed SQ counter pass"},
         }
-        if not args.no_extras:
+        if not args.no_extras and world == 1:     # the untimed legs describe ONE device: at N > 1 the other ranks would only wait for rank 0
             # the boundary hands over HOST buffers (mihevc_send_frame): the same clip, upload inside the clock
             n_p = max(1, min(args.steps, 3))
             step(host=True, frames=host_frames)
@@ -523,7 +523,7 @@ def main():
             del ys[:], us[:], vs[:]
             out["configs"]["2160p30_hdr10_main10"] = run_2160p(local, operating_point, step, SyntheticClip, verify_stream, torch)
             out["libx265"] = libx265_baseline(info, host_frames, 8) if ok265 else {"available": False, "reason": why265}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, H, st.last_qp, args.me_range)
         print(json.dumps(out))
     ranks.barrier()
