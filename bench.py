@@ -310,7 +310,7 @@ def main():
     ap.add_argument("--qp", type=int, default=-1, help="experiments only: force the P-picture QP instead of deriving it from the CRF")
     ap.add_argument("--profile-stages", type=int, default=2, help="HIP events in the timed steps: 2 = around the dominant kernel (inter_ctu) only, 1 = every stage, 0 = none")
     ap.add_argument("--stub", action="store_true", help="tests only: no GPU, no encoder — exercises the rank spawn / rendezvous / JSON path (tests/test_bench_ranks.py)")
-    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes", "gop-balance", "scenecut", "rdo-cg"):
+    for name in ("intra-nxn", "intra-tiles", "pre-search", "rdo-zero", "intra-in-p", "chroma-modes", "gop-balance", "scenecut", "rdo-cg", "gops-in-flight"):
         ap.add_argument("--" + name, type=int, default=None, help="experiments only: override cfg." + name.replace("-", "_"))
     args = ap.parse_args()
 
@@ -371,7 +371,7 @@ def main():
     cfg.me_range, cfg.profile_stages = args.me_range, args.profile_stages
     cfg.qp = args.qp
     cfg.host_threads = args.host_threads
-    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes", "gop_balance", "scenecut", "rdo_cg"):
+    for name in ("intra_nxn", "intra_tiles", "pre_search", "rdo_zero", "intra_in_p", "chroma_modes", "gop_balance", "scenecut", "rdo_cg", "gops_in_flight"):
         if getattr(args, name) is not None:
             setattr(cfg, name, getattr(args, name))
 

@@ -37,8 +37,8 @@ def bit_depth_of(info: VideoInfo) -> int:
 
 def lanes_for(total_frames: int, keyint: int) -> int:
     """GOP lanes of the session's lock-step pipeline (`gops_in_flight`): a chunk is lanes x keyint pictures and its GOPs run side by side, so a clip
-    of up to 8 GOPs is one chunk with every GOP its own lane, longer clips run 8 at a time (more lanes fill the launches better: +2.6 % measured
-    from 4 to 8 on one MI355X); 4 is the floor and what an unknown length gets."""
+    of up to 8 GOPs is one chunk with every GOP its own lane, longer clips run 8 at a time (a step's fixed part — small kernels, launch ramps, the IDR chain —
+    is shared by more pictures: 4609 -> 5150 fps from 4 to 8 lanes on a 1440-frame 1080p clip, no more at 12 or 16); 4 is the floor and what an unknown length gets."""
     if total_frames <= 0 or keyint <= 0:
         return 4
     return max(4, min(8, -(-total_frames // keyint)))
