@@ -612,6 +612,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         StepView<T> dv(da, lay, t), hv(ha, lay, t);
         std::vector<int> qp_step(B), lane_slot(B, slot0);
+        if (t >= 2) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_copy[slot_of(t - 2)], 0));      // the SSE pass of step t - 2 still reads the picture buffer this step reuses
         if (s->rc_on && t >= 3) {
             // rate feedback with a fixed lag of two steps: wait for the symbol copy of step t-2 (step t-1 is already queued behind
             // it, so the device never idles) and take its estimates.  A fixed lag makes the QP sequence reproducible.
@@ -752,9 +753,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
         STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
         STAGE(4, B, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
         STAGE(5, B, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
-        STAGE(6, B, launch_frame_sse<T>(s->st_compute, dv.sao, B));
         HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot0], 0));
+        // the SSE pass (statistics only) runs on the copy stream, in front of the symbol copies that carry its sums: 14 us per step off the
+        // compute stream's critical path.  It reads the reconstruction this step wrote; the step after next writes that buffer again and waits
+        // for this stream's event first (above).
+        HIPCK(s, launch_frame_sse<T>(s->st_copy, dv.sao, B));
         for (int g = 0; g < B; g++)
         {   // CU records, then SAO parameters + SSE + rate estimate (the level planes were written to the host block directly)
             uint8_t *hd = s->lane[g].sym_host[lane_slot[g]], *dd = s->lane[g].sym_dev[lane_slot[g]];
