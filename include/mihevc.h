@@ -107,7 +107,7 @@ typedef struct mihevc_stats {
     int32_t reserved[7];
     /* per-stage device time, filled when cfg.profile_stages: sum of HIP-event intervals and number of launches.
      * index: 0 intra (all anti-diagonals of a step), 1 me_search (incl. the pre-search), 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
-     * 5 border pad, 6 sse, 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
+     * 5 border pad, 6 unused since ABI 2 (the SSE pass runs on the copy stream, beside the next step), 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
     double  stage_ms[8];
     int64_t stage_launches[8];
     int64_t stage_pictures[8];
