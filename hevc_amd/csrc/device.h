@@ -29,7 +29,8 @@ template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArg
 // all anti-diagonals of an I picture batch; h_args is the host copy (geometry only), d_args the device array
 template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows);
 template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch);
-template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int batch);
+// with_lowres false: the 1/4-size pictures were made by launch_prep_p_step
+template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int batch, bool with_lowres);
 template <typename T> hipError_t launch_deblock(hipStream_t st, const DeblockArgs<T> *d_args_v, const DeblockArgs<T> *d_args_h, int w, int h, int batch);
 template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch, bool decide);
 template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch);
@@ -38,6 +39,9 @@ template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<
 constexpr int MAX_LANES = 16;
 struct StepParams { CostParams prm[MAX_LANES]; };      // one P step's cost parameters per lane, passed by value
 template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch);
+// head of a P step in one launch: border pad of the pictures `prev` describes (nullptr: none), 1/4-size pictures for `pre` (nullptr: none), then launch_begin_p_step's work
+template <typename T> hipError_t launch_prep_p_step(hipStream_t st, const SaoArgs<T> *prev, const PreArgs<T> *pre, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa,
+                                                    const StepParams &p, int w, int h, int batch);
 
 // scene-cut detector input: luma plane of one source picture
 template <typename T> struct ScenePic { const T *p; int stride; };

@@ -233,7 +233,46 @@ template <typename T> __global__ __launch_bounds__(64) void k_begin_p_step(Intra
     if (threadIdx.x < 4) sa[g].sse[threadIdx.x] = 0;
 }
 
+// Head of a P step in ONE launch (three tiny kernels before: every launch boundary on the compute stream costs ~6 us, a step had ten): the border pad of
+// the picture the previous step finished (only the next picture's searches read the border), the 1/4-size pictures of this step's source and reference,
+// and the step's cost parameters.  blockIdx.x selects the job, blockIdx.y the lane.
+template <typename T> __global__ __launch_bounds__(256) void k_prep_p_step(const SaoArgs<T> *prev, int n_pad_blocks, const PreArgs<T> *pre, int n_low_blocks,
+                                                                           IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, StepParams p)
+{
+    int b = (int)blockIdx.x;
+    const int g = (int)blockIdx.y;
+    if (b < n_pad_blocks) {
+        const SaoArgs<T> &a = prev[g];
+        const int ny = pad_border_count(a.w, a.h, PAD_Y), ncp = pad_border_count(a.w >> 1, a.h >> 1, PAD_C);
+        int i = b * 256 + (int)threadIdx.x;
+        if (i < ny) { pad_border_sample<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
+        i -= ny;
+        if (i < ncp) { pad_border_sample<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
+        i -= ncp;
+        if (i < ncp) pad_border_sample<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
+        return;
+    }
+    b -= n_pad_blocks;
+    if (b < n_low_blocks) { lowres_sample<T>(pre[g], b * 256 + (int)threadIdx.x); return; }
+    if (threadIdx.x == 0) {
+        CostParams c = p.prm[g];
+        ea[g].prm = c; sa[g].prm = c;
+        c.tile_cols = c.tile_rows = 1;      // P pictures use PPS 0 (one tile)
+        ia[g].prm = c;
+    }
+    if (threadIdx.x < 4) sa[g].sse[threadIdx.x] = 0;
+}
+
 // ------------------------------------------------------------------------------------------ launchers
+template <typename T> hipError_t launch_prep_p_step(hipStream_t st, const SaoArgs<T> *prev, const PreArgs<T> *pre, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa,
+                                                    const StepParams &p, int w, int h, int batch)
+{
+    if (batch > MAX_LANES) return hipErrorInvalidValue;
+    const int n_pad = prev ? (pad_border_count(w, h, PAD_Y) + 2 * pad_border_count(w >> 1, h >> 1, PAD_C) + 255) / 256 : 0;
+    const int n_low = pre ? (2 * (w >> 2) * (h >> 2) + 255) / 256 : 0;
+    hipLaunchKernelGGL(k_prep_p_step<T>, dim3((unsigned)(n_pad + n_low + 1), (unsigned)batch), dim3(256), 0, st, prev, n_pad, pre, n_low, ia, ea, sa, p);
+    return hipGetLastError();
+}
 template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch)
 {
     if (batch > MAX_LANES) return hipErrorInvalidValue;
@@ -290,10 +329,10 @@ template <typename T> hipError_t launch_intra_picture(hipStream_t st, const Intr
     return hipGetLastError();
 }
 
-template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int batch)
+template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int batch, bool with_lowres)
 {
     const int n = 2 * (w >> 2) * (h >> 2);
-    hipLaunchKernelGGL(k_lowres<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
+    if (with_lowres) hipLaunchKernelGGL(k_lowres<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);      // else: k_prep_p_step made the pictures
     hipLaunchKernelGGL(k_pre_search<T>, dim3((unsigned)n_ctu, (unsigned)batch), dim3(NT), 0, st, d_args, n_ctu);
     return hipGetLastError();
 }
@@ -365,7 +404,8 @@ int gfx950_device_count()
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                 \
     template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                                       \
-    template hipError_t launch_pre_search<T>(hipStream_t, const PreArgs<T> *, int, int, int, int);                      \
+    template hipError_t launch_pre_search<T>(hipStream_t, const PreArgs<T> *, int, int, int, int, bool);                \
+    template hipError_t launch_prep_p_step<T>(hipStream_t, const SaoArgs<T> *, const PreArgs<T> *, IntraArgs<T> *, InterArgs<T> *, SaoArgs<T> *, const StepParams &, int, int, int); \
     template hipError_t launch_deblock<T>(hipStream_t, const DeblockArgs<T> *, const DeblockArgs<T> *, int, int, int);  \
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
@@ -576,7 +616,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
         PreArgs<T> pa2;
         pa2.src = a.src[0]; pa2.ref = a.ref[0]; pa2.lsrc = dls.as<uint8_t>(); pa2.lref = dlr.as<uint8_t>(); pa2.w = w; pa2.h = h; pa2.bit_depth = a.prm.bit_depth; pa2.centers = dcen.as<int16_t>();
         CK(hipMemcpy(dpre.p, &pa2, sizeof pa2, hipMemcpyHostToDevice));
-        CK(launch_pre_search<T>(0, dpre.as<PreArgs<T>>(), w, h, n_ctu, 1));
+        CK(launch_pre_search<T>(0, dpre.as<PreArgs<T>>(), w, h, n_ctu, 1, true));
         a.centers = dcen.as<int16_t>();
     }
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));

@@ -689,7 +689,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     HIPCK(s, hipMemcpyAsync(da + (size_t)tb * lay.total, ha + (size_t)tb * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
                     HIPCK(s, launch_sao<T>(s->st_compute, dtv.sao, s->w, s->h, B1, false));
                     HIPCK(s, launch_pad<T>(s->st_compute, dtv.sao, s->w, s->h, B1));
-                    if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dtv.pre, s->w, s->h, s->n_ctu, B1));
+                    if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dtv.pre, s->w, s->h, s->n_ctu, B1, true));
                     HIPCK(s, launch_me_search<T>(s->st_compute, dtv.inter, s->n_ctu, B1, s->me_range));
                     HIPCK(s, launch_inter_ctu<T>(s->st_compute, dtv.inter, s->n_ctu, B1, s->me_range));
                     HIPCK(s, hipStreamSynchronize(s->st_compute));
@@ -738,13 +738,16 @@ template <typename T> int encode_chunk(mihevc_session *s)
         } else {
             {   // the step's QPs reach the device inside one tiny launch that also zeroes the slot's SSE + estimate accumulators; everything
                 // else in the step's argument block went up with the chunk
+                // The same launch pads the border of the previous step's pictures (nothing before this step's searches reads it) and makes the 1/4-size
+                // pictures: one launch boundary on the compute stream instead of three (~6 us each, profiles/r02_e: kernel time 733 of 797 us per step).
                 StepParams sp{};
                 for (int g = 0; g < B; g++) sp.prm[g] = hv.inter[g].prm;
-                HIPCK(s, launch_begin_p_step<T>(s->st_compute, dv.intra, dv.inter, dv.sao, sp, B));
+                StepView<T> pv(da, lay, t - 1);
+                HIPCK(s, launch_prep_p_step<T>(s->st_compute, pv.sao, s->cfg.pre_search ? dv.pre : nullptr, dv.intra, dv.inter, dv.sao, sp, s->w, s->h, B));
             }
-            // stage 1 = search centres from the 1/4-size pictures (k_lowres, k_pre_search) + the integer search around them
+            // stage 1 = search centres (k_pre_search on the 1/4-size pictures the launch above made) + the integer search around them
             if (int e_ = mark(1, B, true)) return e_;
-            if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dv.pre, s->w, s->h, s->n_ctu, B));
+            if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dv.pre, s->w, s->h, s->n_ctu, B, false));
             HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
             if (int e_ = mark(1, B, false)) return e_;
             STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
@@ -752,8 +755,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
         STAGE(4, B, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
-        STAGE(5, B, launch_pad<T>(s->st_compute, dv.sao, s->w, s->h, B));
-        HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));
+        HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));      // (the border pad of these pictures is part of the next step's first launch)
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot0], 0));
         // the SSE pass (statistics only) runs on the copy stream, in front of the symbol copies that carry its sums: 14 us per step off the
         // compute stream's critical path.  It reads the reconstruction this step wrote; the step after next writes that buffer again and waits
