@@ -55,11 +55,13 @@ def cpu_baseline(width, height, qp, me_range, budget_frames=3):
     prm_i.intra_nxn, prm_i.chroma_modes = cfg.intra_nxn, cfg.chroma_modes
     prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
     t0 = time.perf_counter()
-    ref = None
+    ref = prev = None
     for i, (y, u, v) in enumerate(clip.frames()):
         f = O.Frame(np.pad(y, ((0, ch - height), (0, 0)), mode="edge"), np.pad(u, ((0, (ch - height) // 2), (0, 0)), mode="edge"),
                     np.pad(v, ((0, (ch - height) // 2), (0, 0)), mode="edge"))
-        a = O.analyze_intra(f, prm_i) if i == 0 else O.analyze_inter(f, ref, prm_p)
+        cen = O.search_centres(f, prev, 8) if i and cfg.pre_search else None        # as the session: centres from the source pictures
+        a = O.analyze_intra(f, prm_i) if i == 0 else O.analyze_inter(f, ref, prm_p, centers=cen)
+        prev = f
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, 8), prm_i if i == 0 else prm_p)
     dt = time.perf_counter() - t0
     return {"value": round(budget_frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",

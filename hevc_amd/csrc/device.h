@@ -29,6 +29,8 @@ template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArg
 // all anti-diagonals of an I picture batch; h_args is the host copy (geometry only), d_args the device array
 template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows);
 template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch);
+// a whole chunk: d_args[i] = picture i in stream order; its 1/4-size SOURCE picture (lsrc) and its search centres from lsrc against lref (the predecessor's lsrc)
+template <typename T> hipError_t launch_pre_search_chunk(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int n_pictures);
 // with_lowres false: the 1/4-size pictures were made by launch_prep_p_step
 template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int batch, bool with_lowres);
 template <typename T> hipError_t launch_deblock(hipStream_t st, const DeblockArgs<T> *d_args_v, const DeblockArgs<T> *d_args_h, int w, int h, int batch);

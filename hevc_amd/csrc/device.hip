@@ -337,6 +337,23 @@ template <typename T> hipError_t launch_pre_search(hipStream_t st, const PreArgs
     return hipGetLastError();
 }
 
+// every picture of a chunk at once (args[i]: picture i in stream order): 1/4-size pictures of the SOURCES, then the search centres of picture i from
+// lsrc (its own) against lref (its predecessor's) — PreArgs::ref is not read
+template <typename T> __global__ __launch_bounds__(256) void k_lowres_src(const PreArgs<T> *args)
+{
+    const PreArgs<T> &a = args[blockIdx.y];
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i < (a.w >> 2) * (a.h >> 2)) lowres_sample<T>(a, i);
+}
+template <typename T> hipError_t launch_pre_search_chunk(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int n_pictures)
+{
+    if (n_pictures <= 0) return hipSuccess;
+    const int n = (w >> 2) * (h >> 2);
+    hipLaunchKernelGGL(k_lowres_src<T>, dim3((unsigned)((n + 255) / 256), (unsigned)n_pictures), dim3(256), 0, st, d_args);
+    hipLaunchKernelGGL(k_pre_search<T>, dim3((unsigned)n_ctu, (unsigned)n_pictures), dim3(NT), 0, st, d_args, n_ctu);
+    return hipGetLastError();
+}
+
 template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch)
 {
     size_t smem = round16(sizeof(IntraShared<T>));
@@ -405,6 +422,7 @@ int gfx950_device_count()
     template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                 \
     template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                                       \
     template hipError_t launch_pre_search<T>(hipStream_t, const PreArgs<T> *, int, int, int, int, bool);                \
+    template hipError_t launch_pre_search_chunk<T>(hipStream_t, const PreArgs<T> *, int, int, int, int);                \
     template hipError_t launch_prep_p_step<T>(hipStream_t, const SaoArgs<T> *, const PreArgs<T> *, IntraArgs<T> *, InterArgs<T> *, SaoArgs<T> *, const StepParams &, int, int, int); \
     template hipError_t launch_deblock<T>(hipStream_t, const DeblockArgs<T> *, const DeblockArgs<T> *, int, int, int);  \
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \

@@ -179,7 +179,7 @@ struct mihevc_session {
     int keyint = 90, lanes = 4, me_range = 16, qp_p = 22, qp_i = 19;
     bool is16 = false, keep_recon = false, flushed = false, failed = false;
     std::string err;
-    hipStream_t st_compute = nullptr, st_copy = nullptr;
+    hipStream_t st_compute = nullptr, st_copy = nullptr, st_pre = nullptr;      // st_pre: the chunk's pre-search, beside the IDR step
     // source pictures of the current chunk (device), in display order
     struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; bool borrowed; };      // borrowed: the caller's device planes, not copied
     size_t plane_bytes[2][3] = {{0}};   // [padded][plane] allocation sizes (for the buffer cache)
@@ -192,8 +192,6 @@ struct mihevc_session {
         int32_t *me = nullptr;
         IpInfo *ip = nullptr;      // per CTU: inter pass -> intra second pass of P pictures
         IntraPlan *plan = nullptr; // per CTU: k_intra_plan -> k_intra_diag (IDR pictures)
-        void *lsrc = nullptr, *lref = nullptr;   // 1/4-size source / reference luma of the step's picture (pre-search)
-        int16_t *centers = nullptr;              // per CTU search centre
         uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
     };
     std::vector<Lane> lane;
@@ -223,6 +221,8 @@ struct mihevc_session {
     int idr_qp_hint = -1;                     // mean IDR QP the last chunk settled on: where the next chunk's IDR analysis starts
     int last_gop_len = 0;                     // length of the stream's previous GOP (picture timing SEI at the next IDR)
     double scene_avg = 0;                     // running mean of the picture-to-picture difference over ordinary pictures (scene-cut detector)
+    void *d_low = nullptr; size_t low_cap = 0;       // per chunk: 1/4-size SOURCE pictures of every picture, then the search centres of every picture (pre-search)
+    hipEvent_t ev_pre = nullptr, ev_args = nullptr;  // the chunk's centres are ready (copy stream) / its argument blocks are on the device (compute stream)
     void *d_scene = nullptr; size_t scene_cap = 0;   // per chunk: picture pointers / pitches in, difference sums out (k_scene_diff)
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
@@ -273,9 +273,6 @@ int ensure_lanes(mihevc_session *s, int n)
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, (void **)&L.plan));
-        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lsrc));
-        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, &L.lref));
-        HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, (void **)&L.centers));
         for (int k = 0; k < s->ring; k++) {
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, true, (void **)&L.sym_host[k]));
@@ -443,7 +440,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto slot_of = [ring](int t) { return t == 0 ? 0 : 1 + (t - 1) % (ring - 1); };
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
-    const size_t need = (size_t)(steps + 1) * lay.total;      // + one block for the rho trial (below)
+    const size_t flat_off = (size_t)(steps + 1) * lay.total;  // + one block for the rho trial (below)
+    const size_t need = flat_off + (size_t)n * sizeof(PreArgs<T>);          // + one pre-search block per picture of the chunk (stream order)
     if (need > s->args_cap) {
         BufferCache &bc = BufferCache::get();
         bc.release(s->device, s->args_cap, false, s->d_args); bc.release(s->device, s->args_cap, true, s->h_args);
@@ -454,6 +452,21 @@ template <typename T> int encode_chunk(mihevc_session *s)
         s->args_cap = cap;
     }
     uint8_t *ha = s->h_args, *da = (uint8_t *)s->d_args;
+    // the chunk's 1/4-size source pictures and search centres (cfg.pre_search): [n pictures of (w/4)(h/4) bytes | n x n_ctu x 2 int16]
+    const size_t low_pic = (size_t)(s->w >> 2) * (s->h >> 2), low_bytes = ((size_t)n * low_pic + 255) & ~(size_t)255;
+    if (s->cfg.pre_search) {
+        const size_t want = low_bytes + (size_t)n * s->n_ctu * 2 * sizeof(int16_t);
+        if (want > s->low_cap) {
+            BufferCache &bc = BufferCache::get();
+            bc.release(s->device, s->low_cap, false, s->d_low);
+            s->d_low = nullptr; s->low_cap = 0;
+            const size_t cap = (want + 0xfffff) & ~(size_t)0xfffff;
+            HIPCK(s, bc.alloc(s->device, cap, false, &s->d_low));
+            s->low_cap = cap;
+        }
+    }
+    uint8_t *const low = (uint8_t *)s->d_low;
+    int16_t *const cen = (int16_t *)((uint8_t *)s->d_low + low_bytes);
     auto prm_for = [&](int qp) {
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
@@ -501,10 +514,13 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.sparse_coef = A.inter.sparse_coef = 1;
             A.intra.diagonal = 0;
             A.inter.centers = nullptr; A.inter.me = L.me;
-            if (t > 0 && s->cfg.pre_search) {       // search centres from the 1/4-size source and reference of this step
-                PreArgs<T> &P4 = hv.pre[g];
-                P4.src = A.inter.src[0]; P4.ref = A.inter.ref[0]; P4.lsrc = (uint8_t *)L.lsrc; P4.lref = (uint8_t *)L.lref; P4.w = s->w; P4.h = s->h; P4.bit_depth = s->cfg.bit_depth; P4.centers = L.centers;
-                A.inter.centers = L.centers;
+            if (s->cfg.pre_search) {       // search centres: the chunk's pre-search fills them for every picture (below)
+                const size_t idx = (size_t)(gstart[(size_t)g] + t);
+                PreArgs<T> &P4 = ((PreArgs<T> *)(ha + flat_off))[idx];
+                P4.src = A.inter.src[0]; P4.ref = A.inter.src[0];
+                P4.lsrc = low + idx * low_pic; P4.lref = low + (t > 0 ? idx - 1 : idx) * low_pic;      // an IDR picture's centres are never read
+                P4.w = s->w; P4.h = s->h; P4.bit_depth = s->cfg.bit_depth; P4.centers = cen + idx * (size_t)s->n_ctu * 2;
+                if (t > 0) A.inter.centers = P4.centers;
             }
             // P pictures: the inter pass leaves per-CTU costs for the intra second pass, which runs on the same work picture,
             // records and levels with the one-tile PPS 0 geometry
@@ -519,6 +535,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.est = A.inter.est = (unsigned long long *)(sym + sl.est);
         }
     HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
+    if (s->cfg.pre_search) {
+        // Search centres of EVERY picture of the chunk, from the 1/4-size SOURCE pictures (this picture against the one before it: nothing here waits
+        // for a reconstruction), on a stream of its own: the work (4 ms of latency-bound launches at 1080p, 7 % of a clip's device time when it ran inside
+        // every step) sits under the IDR step, whose anti-diagonal chain leaves most of the device idle.  The first P step waits for ev_pre.
+        HIPCK(s, hipEventRecord(s->ev_args, s->st_compute));
+        HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_args, 0));
+        HIPCK(s, launch_pre_search_chunk<T>(s->st_pre, (const PreArgs<T> *)(da + flat_off), s->w, s->h, s->n_ctu, n));
+        HIPCK(s, hipEventRecord(s->ev_pre, s->st_pre));
+    }
     // ---- per-lane rate controllers ----
     // CPB model (x265 nal-hrd=vbr + vbv-maxrate / vbv-bufsize, reference core/transcoder.py:399-400).  The GOPs of a chunk are coded in
     // lock-step, so a GOP cannot know the buffer level its predecessor leaves.  Every closed GOP is therefore planned to be buffer-neutral:
@@ -683,13 +708,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         for (int i = 0; i < 3; i++) tv.inter[g].rec[i] = mk<T>(L.rec_p[1][i], L.rec_stride[i]);
                         tv.inter[g].prm = prm_for(qp_trial[(size_t)g]);
                         tv.inter[g].ip = nullptr;
-                        tv.pre[g] = h1.pre[g];
                         HIPCK(s, hipMemsetAsync(L.sym_dev[slot_of(1)] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
                     }
                     HIPCK(s, hipMemcpyAsync(da + (size_t)tb * lay.total, ha + (size_t)tb * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
                     HIPCK(s, launch_sao<T>(s->st_compute, dtv.sao, s->w, s->h, B1, false));
                     HIPCK(s, launch_pad<T>(s->st_compute, dtv.sao, s->w, s->h, B1));
-                    if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dtv.pre, s->w, s->h, s->n_ctu, B1, true));
+                    if (s->cfg.pre_search) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_pre, 0));      // the chunk's search centres
                     HIPCK(s, launch_me_search<T>(s->st_compute, dtv.inter, s->n_ctu, B1, s->me_range));
                     HIPCK(s, launch_inter_ctu<T>(s->st_compute, dtv.inter, s->n_ctu, B1, s->me_range));
                     HIPCK(s, hipStreamSynchronize(s->st_compute));
@@ -743,11 +767,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 StepParams sp{};
                 for (int g = 0; g < B; g++) sp.prm[g] = hv.inter[g].prm;
                 StepView<T> pv(da, lay, t - 1);
-                HIPCK(s, launch_prep_p_step<T>(s->st_compute, pv.sao, s->cfg.pre_search ? dv.pre : nullptr, dv.intra, dv.inter, dv.sao, sp, s->w, s->h, B));
+                HIPCK(s, launch_prep_p_step<T>(s->st_compute, pv.sao, (const PreArgs<T> *)nullptr, dv.intra, dv.inter, dv.sao, sp, s->w, s->h, B));
+                if (t == 1 && s->cfg.pre_search) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_pre, 0));      // the chunk's search centres (st_pre, under the IDR step)
             }
-            // stage 1 = search centres (k_pre_search on the 1/4-size pictures the launch above made) + the integer search around them
+            // stage 1 = the integer search around the chunk's search centres
             if (int e_ = mark(1, B, true)) return e_;
-            if (s->cfg.pre_search) HIPCK(s, launch_pre_search<T>(s->st_compute, dv.pre, s->w, s->h, s->n_ctu, B, false));
             HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
             if (int e_ = mark(1, B, false)) return e_;
             STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
@@ -902,14 +926,19 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->stats.last_qp = s->qp_p;
     s->rc_on = cfg->qp < 0 && cfg->vbv_maxrate_kbps > 0;
     write_parameter_sets(s->cfg, s->headers);
-    bool ok = StreamCache::get().acquire(s->device, &s->st_compute) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_copy) == hipSuccess;
+    bool ok = StreamCache::get().acquire(s->device, &s->st_compute) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_copy) == hipSuccess &&
+              StreamCache::get().acquire(s->device, &s->st_pre) == hipSuccess;
     for (int i = 0; ok && i < kRing; i++)
         ok = hipEventCreateWithFlags(&s->ev_compute[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_args, hipEventDisableTiming) == hipSuccess;
     if (!ok) {               // give back what was acquired (event handles of the slots never reached stay null)
         for (int i = 0; i < kRing; i++) { if (s->ev_compute[i]) (void)hipEventDestroy(s->ev_compute[i]); if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]); }
+        if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
+        if (s->ev_args) (void)hipEventDestroy(s->ev_args);
         StreamCache::get().release(s->device, s->st_compute);
         StreamCache::get().release(s->device, s->st_copy);
+        StreamCache::get().release(s->device, s->st_pre);
         delete s;
         return MIHEVC_EDEVICE;
     }
@@ -1070,6 +1099,7 @@ void mihevc_close(mihevc_session *s)
     }
     if (s->st_compute) (void)hipStreamSynchronize(s->st_compute);
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
+    if (s->st_pre) (void)hipStreamSynchronize(s->st_pre);
     BufferCache &bc = BufferCache::get();
     SymLayout sl(s->w, s->h);
     auto free3 = [&](void *b[3], int padded) { for (int i = 0; i < 3; i++) bc.release(s->device, s->plane_bytes[padded][i], false, b[i]); };
@@ -1080,9 +1110,6 @@ void mihevc_close(mihevc_session *s)
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, L.plan);
-        bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lsrc);
-        bc.release(s->device, (size_t)(s->w >> 2) * (s->h >> 2), false, L.lref);
-        bc.release(s->device, (size_t)s->n_ctu * 2 * sizeof(int16_t), false, L.centers);
         for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     bc.release(s->device, s->args_cap, false, s->d_args);
@@ -1090,8 +1117,11 @@ void mihevc_close(mihevc_session *s)
     bc.release(s->device, s->args_cap, true, s->h_args);
     for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(s->ev_pre); (void)hipEventDestroy(s->ev_args);
+    bc.release(s->device, s->low_cap, false, s->d_low);
     StreamCache::get().release(s->device, s->st_compute);       // both idle: synchronised above
     StreamCache::get().release(s->device, s->st_copy);
+    StreamCache::get().release(s->device, s->st_pre);
     delete s;
 }
 

@@ -72,7 +72,8 @@ typedef struct mihevc_config {
     int32_t hrd;                      /* 1: HRD parameters in the VUI + buffering-period SEI at every IDR + picture-timing SEI per picture
                                        * (x265 hrd=1, part of the reference's HDR10 set, core/utils.py:66); needs vbv_maxrate/bufsize */
     int32_t pre_search;               /* 1 (default): search centres from a +-14 full search on the 1/4-size pictures, so the +-me_range
-                                       * integer search follows motion up to +-56 samples; 0: centres at zero */
+                                       * integer search follows motion up to +-56 samples; 0: centres at zero.  A session searches the 1/4-size SOURCE
+                                       * picture against the SOURCE picture before it, for a whole chunk at once (beside the IDR step) */
     int32_t rdo_zero;                 /* 1 (default): inter TUs whose levels cost more (lambda x bits) than the distortion they remove are
                                        * coded as all-zero (whole 300-picture bench clip: -12 % bits at -0.14 dB at fixed QP 27, +0.02 dB at equal bitrate
                                        * under the rate controller) */

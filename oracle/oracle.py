@@ -228,6 +228,21 @@ def analyze_inter(src: Frame, ref: Frame, prm: Params, centers=None, dump_me=Fal
     return a
 
 
+def search_centres(src: Frame, prev: Frame, bit_depth=8) -> np.ndarray:
+    """Per-CTU search centres of picture `src` from the 1/4-size pictures of `src` and `prev` (orc_lowres + orc_pre_search).  A session feeds its
+    integer search with the centres of the SOURCE picture against the SOURCE picture before it (the whole chunk at once, before any reconstruction
+    exists): replaying a session means passing these as `centers` to analyze_inter."""
+    h, w = src.shape
+    lw, lh = w >> 2, h >> 2
+    ls, lr = np.empty((lh, lw), np.uint16), np.empty((lh, lw), np.uint16)
+    lib().orc_lowres(_p(src.y), w, w, h, bit_depth, _p(ls))
+    lib().orc_lowres(_p(prev.y), w, w, h, bit_depth, _p(lr))
+    n_ctu = ((w + CTU - 1) // CTU) * ((h + CTU - 1) // CTU)
+    cen = np.zeros((n_ctu, 2), np.int16)
+    lib().orc_pre_search(_p(ls), _p(lr), lw, lh, _p(cen))
+    return cen
+
+
 def deblock(rec: Frame, cu: np.ndarray, bit_depth=8) -> Frame:
     out = rec.copy()
     h, w = out.shape

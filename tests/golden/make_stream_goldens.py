@@ -63,7 +63,7 @@ def oracle_pictures(name):
         prm.intra_nxn, prm.chroma_modes = cfg.intra_nxn, cfg.chroma_modes
     prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
     buf = (C.c_uint8 * (4 << 20))()
-    out, ref, poc = [], None, 0
+    out, ref, poc, prev_pad = [], None, 0, None
     import numpy as np
     for i, f in enumerate(frames(name)):
         pad = O.Frame(np.pad(f.y, ((0, ch - h), (0, cw - w)), mode="edge"), np.pad(f.u, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"),
@@ -71,7 +71,8 @@ def oracle_pictures(name):
         intra = i in idr
         poc = 0 if intra else poc + 1
         prm = prm_i if intra else prm_p
-        a = O.analyze_intra(pad, prm) if intra else O.analyze_inter(pad, ref, prm)
+        a = O.analyze_intra(pad, prm) if intra else O.analyze_inter(pad, ref, prm, centers=O.search_centres(pad, prev_pad, bd) if cfg.pre_search else None)
+        prev_pad = pad
         ref, sao = O.sao(pad, O.deblock(a.rec, a.cu, bd), prm)
         nb = lib.mihevc_encode_picture_host(C.byref(cfg), 2 if intra else 1, poc, prm.qp, util.ptr(a.cu), util.ptr(a.coef_y), util.ptr(a.coef_u),
                                             util.ptr(a.coef_v), util.ptr(sao), buf, len(buf))

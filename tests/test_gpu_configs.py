@@ -108,7 +108,7 @@ def replay(lib, cfg, frames, infos, recs, upto):
         qp, st, _ = infos[i]
         prm, _ = session_params(lib, cfg, qp, st == 2)
         src = frames[i][1]
-        a = O.analyze_intra(src, prm) if st == 2 else O.analyze_inter(src, ref, prm)
+        a = O.analyze_intra(src, prm) if st == 2 else O.analyze_inter(src, ref, prm, centers=O.search_centres(src, frames[i - 1][1], cfg.bit_depth) if cfg.pre_search else None)
         ref, _ = O.sao(src, O.deblock(a.rec, a.cu, cfg.bit_depth), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qp}): session reconstruction != oracle pipeline"
 

@@ -215,14 +215,15 @@ def test_session_stream_decodes_to_encoder_reconstruction(lib, w, h, bd, keyint,
     prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg   # session defaults: pre-search and both RD zero-outs on
     assert _lib.tile_grid(cfg) == ((2, 2) if w >= 256 else (1, 1))
     idr = util.idr_positions(n, keyint, cfg.gops_in_flight)       # (132, 76, keyint 5, 7 pictures): GOPs of 4 + 3, not 5 + 2
-    ref = None
+    ref = prev_pad = None
     for i, f in enumerate(frames):
         pad = O.Frame(np.pad(f.y, ((0, ch - h), (0, cw - w)), mode="edge"), np.pad(f.u, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"),
                       np.pad(f.v, ((0, (ch - h) // 2), (0, (cw - w) // 2)), mode="edge"))
         if i in idr:
             a = O.analyze_intra(pad, prm_i)
-        else:
-            a = O.analyze_inter(pad, ref, prm_p)
+        else:       # the session's search centres come from the source pictures (this one against the one before it)
+            a = O.analyze_inter(pad, ref, prm_p, centers=O.search_centres(pad, prev_pad, bd) if cfg.pre_search else None)
+        prev_pad = pad
         prm = prm_i if i in idr else prm_p
         ref, _ = O.sao(pad, O.deblock(a.rec, a.cu, bd), prm)
         enc_rec = O.Frame(*recs[i])
@@ -271,7 +272,7 @@ def test_rate_control_caps_the_gop_bitrate_and_stays_bit_exact(lib):
         prm, _ = lib_params(lib, qps[i], bd, 8)
         prm.intra_nxn, prm.intra_in_p, prm.pre_search, prm.rdo_zero, prm.rdo_cg = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
         prm.chroma_modes = cfg.chroma_modes
-        a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm)
+        a = O.analyze_intra(f, prm) if i % keyint == 0 else O.analyze_inter(f, ref, prm, centers=O.search_centres(f, frames[i - 1], bd) if cfg.pre_search else None)
         ref, _ = O.sao(f, O.deblock(a.rec, a.cu, bd), prm)
         assert recs[i].same(ref), f"picture {i} (qp {qps[i]})"
 
