@@ -27,7 +27,8 @@ template <typename T> void free_plane(DevPlane<T> &d);
 template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
 template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
 // all anti-diagonals of an I picture batch; h_args is the host copy (geometry only), d_args the device array
-template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows);
+// after_plan (optional): recorded between stage A (k_intra_plan, throughput-bound) and the anti-diagonal chain of stage B (latency-bound: other streams' work fits beside it)
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows, hipEvent_t after_plan);
 template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch);
 // a whole chunk: d_args[i] = picture i in stream order; its 1/4-size SOURCE picture (lsrc) and its search centres from lsrc against lref (the predecessor's lsrc)
 template <typename T> hipError_t launch_pre_search_chunk(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int n_pictures);

@@ -311,7 +311,7 @@ template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArg
     return hipGetLastError();
 }
 
-template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows)
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows, hipEvent_t after_plan)
 {
     size_t smem = round16(sizeof(IntraShared<T>));
     hipError_t e = ensure_smem(k_intra_plan<T>, smem);
@@ -322,6 +322,7 @@ template <typename T> hipError_t launch_intra_picture(hipStream_t st, const Intr
     if (tile_rows < 1) tile_rows = 1;
     const int n_ctu = ctus_w * ctus_h;
     hipLaunchKernelGGL(k_intra_plan<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), smem, st, d_args, n_ctu);      // stage A: every CTU at once
+    if (after_plan) { e = hipEventRecord(after_plan, st); if (e != hipSuccess) return e; }      // from here on the stream runs the latency-bound anti-diagonal chain
     // stage B, per tile one anti-diagonal at a time; uniform spacing: the widest column / tallest row is ceil(n_ctb / n_tiles)
     const int colw = (ctus_w + tile_cols - 1) / tile_cols, rowh = (ctus_h + tile_rows - 1) / tile_rows;
     for (int d = 0; d <= (colw - 1) + 2 * (rowh - 1); d++)
@@ -419,7 +420,7 @@ int gfx950_device_count()
 #define INSTANTIATE(T)                                                                                                   \
     template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
-    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int);                 \
+    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int, hipEvent_t);     \
     template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                                       \
     template hipError_t launch_pre_search<T>(hipStream_t, const PreArgs<T> *, int, int, int, int, bool);                \
     template hipError_t launch_pre_search_chunk<T>(hipStream_t, const PreArgs<T> *, int, int, int, int);                \
@@ -586,7 +587,7 @@ int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, co
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
     a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0; a.ip = nullptr; a.plan = dplan.as<IntraPlan>();
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
-    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows));
+    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows, nullptr));
     CK(hipDeviceSynchronize());
     if (int e = rec.download(ry, ru, rv)) return e;
     CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));

@@ -222,7 +222,7 @@ struct mihevc_session {
     int last_gop_len = 0;                     // length of the stream's previous GOP (picture timing SEI at the next IDR)
     double scene_avg = 0;                     // running mean of the picture-to-picture difference over ordinary pictures (scene-cut detector)
     void *d_low = nullptr; size_t low_cap = 0;       // per chunk: 1/4-size SOURCE pictures of every picture, then the search centres of every picture (pre-search)
-    hipEvent_t ev_pre = nullptr, ev_args = nullptr;  // the chunk's centres are ready (copy stream) / its argument blocks are on the device (compute stream)
+    hipEvent_t ev_pre = nullptr, ev_args = nullptr;  // the chunk's centres are ready (st_pre) / the IDR step's k_intra_plan is through (compute stream: the argument blocks are on the device too)
     void *d_scene = nullptr; size_t scene_cap = 0;   // per chunk: picture pointers / pitches in, difference sums out (k_scene_diff)
     struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
     std::vector<FrameRec> frames;             // by output index
@@ -535,15 +535,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.est = A.inter.est = (unsigned long long *)(sym + sl.est);
         }
     HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
-    if (s->cfg.pre_search) {
-        // Search centres of EVERY picture of the chunk, from the 1/4-size SOURCE pictures (this picture against the one before it: nothing here waits
-        // for a reconstruction), on a stream of its own: the work (4 ms of latency-bound launches at 1080p, 7 % of a clip's device time when it ran inside
-        // every step) sits under the IDR step, whose anti-diagonal chain leaves most of the device idle.  The first P step waits for ev_pre.
-        HIPCK(s, hipEventRecord(s->ev_args, s->st_compute));
-        HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_args, 0));
-        HIPCK(s, launch_pre_search_chunk<T>(s->st_pre, (const PreArgs<T> *)(da + flat_off), s->w, s->h, s->n_ctu, n));
-        HIPCK(s, hipEventRecord(s->ev_pre, s->st_pre));
-    }
+    // cfg.pre_search: the search centres of EVERY picture of the chunk come from the 1/4-size SOURCE pictures (this picture against the one before it: nothing
+    // in it waits for a reconstruction), in two launches on a stream of their own in the IDR step below: the work (7 % of a clip's device time when it ran
+    // inside every step) sits beside the anti-diagonal chain, which leaves most of the device idle.  The first P step waits for ev_pre.
     // ---- per-lane rate controllers ----
     // CPB model (x265 nal-hrd=vbr + vbv-maxrate / vbv-bufsize, reference core/transcoder.py:399-400).  The GOPs of a chunk are coded in
     // lock-step, so a GOP cannot know the buffer level its predecessor leaves.  Every closed GOP is therefore planned to be buffer-neutral:
@@ -661,7 +655,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (t == 0) {
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
             for (int g = 0; g < B; g++) HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
-            STAGE(0, B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B, s->tiles.cols, s->tiles.rows));
+            STAGE(0, B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B, s->tiles.cols, s->tiles.rows, s->cfg.pre_search ? s->ev_args : nullptr));
+            if (s->cfg.pre_search) {       // the chunk's search centres: beside the anti-diagonal chain, not beside k_intra_plan (both want the ALUs)
+                HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_args, 0));
+                HIPCK(s, launch_pre_search_chunk<T>(s->st_pre, (const PreArgs<T> *)(da + flat_off), s->w, s->h, s->n_ctu, n));
+                HIPCK(s, hipEventRecord(s->ev_pre, s->st_pre));
+            }
             if (s->rc_on) {
                 // ONE analysis per IDR picture, then the rate model decides: IDR bits scale as 2^(-dQP/6) around the analysed point, P size
                 // at the IDR's QP is rho x IDR size, the rest of the GOP budget is shared by the P pictures; wanted is the IDR QP whose
@@ -745,7 +744,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
                     }
                     HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
-                    STAGE(0, (int)redo.size(), launch_intra_picture<T>(s->st_compute, dv.intra + B, s->ctus_w, s->ctus_h, (int)redo.size(), s->tiles.cols, s->tiles.rows));
+                    STAGE(0, (int)redo.size(), launch_intra_picture<T>(s->st_compute, dv.intra + B, s->ctus_w, s->ctus_h, (int)redo.size(), s->tiles.cols, s->tiles.rows, nullptr));
                     HIPCK(s, hipStreamSynchronize(s->st_compute));
                     for (int g : redo) HIPCK(s, hipMemcpy(&ev[(size_t)g], s->lane[g].sym_dev[0] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
                 }
