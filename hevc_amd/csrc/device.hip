@@ -377,7 +377,10 @@ template <typename T> hipError_t launch_deblock(hipStream_t st, const DeblockArg
 template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch, bool decide)
 {
     int n_ctu = ((w + CTU - 1) / CTU) * ((h + CTU - 1) / CTU);
-    if (decide) hipLaunchKernelGGL(k_sao_decide<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), 0, st, d_args, n_ctu);
+    if (decide) {        // the CTU program decides AND applies (its deblocked tile is in LDS): no second pass
+        hipLaunchKernelGGL(k_sao_decide<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), 0, st, d_args, n_ctu);
+        return hipGetLastError();
+    }
     int n = (w * h + (w * h >> 1)) >> 2;
     hipLaunchKernelGGL(k_sao_apply<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
     return hipGetLastError();

@@ -123,6 +123,7 @@ struct SaoShared {
     // 64 samples of a plane, so the biased sum (< 64 * 2048) never reaches the count field.
     unsigned priv[3][16][53];        // per copy: eo[4][5] | bo[32], packed
     unsigned long long band_key[3];  // min over the 29 band positions of ((cost + bias) << 8 | position)
+    mihevc_sao_ctu chosen;           // the CTU's parameters, for the apply phase
 };
 
 DEVCONST int8_t kEoDx[4][2] = {{-1, 1}, {0, 0}, {-1, 1}, {1, -1}};
@@ -319,6 +320,44 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             for (int i = 0; i < 4; i++) o.offset[pl][i] = type == 1 ? s.bo_off[pl][band[pl] + i] : type == 2 ? s.eo_off[pl][k == 0 ? 0 : k < 2 ? 0 : k - 2][i] : (int8_t)0;
         }
         a.sao[ctu] = o;
+        s.chosen = o;
+    });
+    // apply (8.7.3) to the CTU's own samples, from the deblocked tile already in LDS (a CTU's samples depend on its own parameters and on deblocked
+    // neighbour SAMPLES only): the separate pass over the picture re-read it from HBM behind one more launch boundary (18 + 6 us per step).  A lane
+    // owns the strips of the statistics phase: four luma and two chroma samples.
+    ex.phase([&](int tid) {
+        const mihevc_sao_ctu &o = s.chosen;
+        const int maxv = (1 << bd) - 1;
+        auto strip = [&](auto count, int pl, int x, int y) {
+            constexpr int N = decltype(count)::value;
+            const int pw = pl ? (a.w >> 1) : a.w, ph = pl ? (a.h >> 1) : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
+            if (gx >= pw || gy >= ph) return;
+            const uint16_t *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
+            const int ts = pl ? SAO_TS_C : SAO_TS_Y, ti = (y + 1) * ts + x + 3, type = o.type[pl ? 1 : 0], cls = o.eo_class[pl ? 1 : 0];
+            int v[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < N; i++) {
+                const int r = tp[ti + 1 + i];
+                int out = r;
+                if (type == 2) {
+                    const int xa = gx + i + kEoDx[cls][0], ya = gy + kEoDy[cls][0], xb = gx + i + kEoDx[cls][1], yb = gy + kEoDy[cls][1];
+                    if (!(xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph)) {
+                        const int e = 2 + sgn3(r - tp[ti + 1 + i + kEoDy[cls][0] * ts + kEoDx[cls][0]]) + sgn3(r - tp[ti + 1 + i + kEoDy[cls][1] * ts + kEoDx[cls][1]]);
+                        const int k = e == 2 ? 0 : e < 2 ? e + 1 : e;
+                        if (k) out = clip3(0, maxv, r + o.offset[pl][k - 1]);
+                    }
+                } else if (type == 1) {
+                    const int k = ((r >> (bd - 5)) - o.band_pos[pl]) & 31;
+                    if (k < 4) out = clip3(0, maxv, r + o.offset[pl][k]);
+                }
+                v[i] = out;
+            }
+            T *dst = a.out[pl].p + (ptrdiff_t)gy * a.out[pl].stride + gx;
+            if (N == 4) store4(dst, v[0], v[1], v[2], v[3]);
+            else { dst[0] = (T)v[0]; dst[1] = (T)v[1]; }
+        };
+        strip(std::integral_constant<int, 4>{}, 0, (tid & 7) * 4, tid >> 3);
+        strip(std::integral_constant<int, 2>{}, 1 + (tid >> 7), (tid & 7) * 2, (tid & 127) >> 3);
     });
 }
 

@@ -261,10 +261,7 @@ static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, 
         if (const char *e = getenv("EMU_WAVES")) { if (!run_waves((unsigned long long)atoll(e) + 131u * (unsigned)c, [&](WaveExec &wx) { sao_ctu_program<T>(wx, s, a, c); })) return -2; }
         else sao_ctu_program<T>(ex, s, a, c);
     }
-    for (int pl = 0; pl < 3; pl++)
-        for (int yy = 0; yy < (pl ? h / 2 : h); yy++)
-            for (int xx = 0; xx < (pl ? w / 2 : w); xx += 4) sao_apply_quad<T>(a, pl, xx, yy);
-    return 0;
+    return 0;          // the CTU programs applied the offsets themselves (as k_sao_decide does)
 }
 
 extern "C" {
