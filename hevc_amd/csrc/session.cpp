@@ -831,6 +831,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     HIPCK(s, hipEventRecord(t_end, s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_copy));
+    HIPCK(s, hipStreamSynchronize(s->st_pre));        // a chunk without P steps never waited for its pre-search: its buffers are reused by the next chunk
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t_begin, t_end);
     s->stats.device_ms += ms;
