@@ -140,13 +140,13 @@ template <typename T> __global__ __launch_bounds__(256) void k_sao_apply(const S
 template <typename T> __global__ __launch_bounds__(256) void k_pad(const SaoArgs<T> *args)
 {
     const SaoArgs<T> &a = args[blockIdx.y];
-    const int ny = pad_border_count(a.w, a.h, PAD_Y), ncp = pad_border_count(a.w >> 1, a.h >> 1, PAD_C);      // border samples only
+    const int ny = pad_border_quads(a.w, a.h, PAD_Y), ncp = pad_border_quads(a.w >> 1, a.h >> 1, PAD_C);      // border only, four samples a lane
     int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < ny) { pad_border_sample<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
+    if (i < ny) { pad_border_quad<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
     i -= ny;
-    if (i < ncp) { pad_border_sample<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
+    if (i < ncp) { pad_border_quad<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
     i -= ncp;
-    if (i < ncp) pad_border_sample<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
+    if (i < ncp) pad_border_quad<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
 }
 
 // fill the coded-size margin of a source plane (columns sw..pw-1, rows sh..ph-1) by edge replication
@@ -243,13 +243,13 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep_p_step(const
     const int g = (int)blockIdx.y;
     if (b < n_pad_blocks) {
         const SaoArgs<T> &a = prev[g];
-        const int ny = pad_border_count(a.w, a.h, PAD_Y), ncp = pad_border_count(a.w >> 1, a.h >> 1, PAD_C);
+        const int ny = pad_border_quads(a.w, a.h, PAD_Y), ncp = pad_border_quads(a.w >> 1, a.h >> 1, PAD_C);
         int i = b * 256 + (int)threadIdx.x;
-        if (i < ny) { pad_border_sample<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
+        if (i < ny) { pad_border_quad<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
         i -= ny;
-        if (i < ncp) { pad_border_sample<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
+        if (i < ncp) { pad_border_quad<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
         i -= ncp;
-        if (i < ncp) pad_border_sample<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
+        if (i < ncp) pad_border_quad<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
         return;
     }
     b -= n_pad_blocks;
@@ -268,7 +268,7 @@ template <typename T> hipError_t launch_prep_p_step(hipStream_t st, const SaoArg
                                                     const StepParams &p, int w, int h, int batch)
 {
     if (batch > MAX_LANES) return hipErrorInvalidValue;
-    const int n_pad = prev ? (pad_border_count(w, h, PAD_Y) + 2 * pad_border_count(w >> 1, h >> 1, PAD_C) + 255) / 256 : 0;
+    const int n_pad = prev ? (pad_border_quads(w, h, PAD_Y) + 2 * pad_border_quads(w >> 1, h >> 1, PAD_C) + 255) / 256 : 0;
     const int n_low = pre ? (2 * (w >> 2) * (h >> 2) + 255) / 256 : 0;
     hipLaunchKernelGGL(k_prep_p_step<T>, dim3((unsigned)(n_pad + n_low + 1), (unsigned)batch), dim3(256), 0, st, prev, n_pad, pre, n_low, ia, ea, sa, p);
     return hipGetLastError();
@@ -388,7 +388,7 @@ template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_
 
 template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch)
 {
-    int n = pad_border_count(w, h, PAD_Y) + 2 * pad_border_count(w >> 1, h >> 1, PAD_C);
+    int n = pad_border_quads(w, h, PAD_Y) + 2 * pad_border_quads(w >> 1, h >> 1, PAD_C);
     hipLaunchKernelGGL(k_pad<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
     return hipGetLastError();
 }

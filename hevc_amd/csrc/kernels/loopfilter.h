@@ -424,4 +424,26 @@ template <typename T> DEV void pad_border_sample(Plane<T> p, int w, int h, int p
     pad_sample<T>(p, w, h, pad, idx);
 }
 
+// the same border in quads of four samples (pad, plane width and row pitch are multiples of 4: a quad is border on one side of the picture or
+// a copy of picture columns, never both): one aligned store per lane instead of four byte stores, a quarter of the index arithmetic
+HDI int pad_border_quads(int w, int h, int pad) { return pad_border_count(w, h, pad) >> 2; }
+template <typename T> DEV void pad_border_quad(Plane<T> p, int w, int h, int pad, int j)
+{
+    const int qpr = (w + 2 * pad) >> 2, band = pad * qpr, side = pad >> 2;      // quads per padded row / per band above or below / per side of a picture row
+    int x, y;
+    if (j < 2 * band) {
+        const int k = j < band ? j : j - band;
+        y = (j < band ? -pad : h) + k / qpr; x = (k % qpr) * 4 - pad;
+    } else {
+        const int k = j - 2 * band, r = k / (2 * side), c = k % (2 * side);
+        if (r >= h) return;
+        y = r; x = c < side ? c * 4 - pad : w + (c - side) * 4;
+    }
+    const T *row = p.p + (ptrdiff_t)clip3(0, h - 1, y) * p.stride;
+    int v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (int)row[clip3(0, w - 1, x + i)];
+    store4(p.p + (ptrdiff_t)y * p.stride + x, v[0], v[1], v[2], v[3]);
+}
+
 }  // namespace mihevc
