@@ -318,6 +318,14 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         spawn_ranks(args)                        # never returns
+    # stdout carries ONE JSON line and nothing else: from here on file descriptor 1 is stderr for everything in this process (gloo's connection
+    # notes, runtime warnings, stray prints of a library), and the line goes out through a private duplicate of the real stdout
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
@@ -335,9 +343,9 @@ def main():
         dts = ranks.gather(time.perf_counter() - t0)         # barrier to barrier; the job takes the MAX over ranks
         if rank == 0:
             dt = max(dts)
-            print(json.dumps({"metric": METRIC, "value": round(world * args.steps * N / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            emit({"metric": METRIC, "value": round(world * args.steps * N / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                              "dtype": "u8", "data": "stub", "config": {"workload": "stub"}, "per_rank_fps": [round(args.steps * N / d, 2) for d in own], "stub": True}))
+                              "dtype": "u8", "data": "stub", "config": {"workload": "stub"}, "per_rank_fps": [round(args.steps * N / d, 2) for d in own], "stub": True})
         ranks.close()
         return
 
@@ -527,7 +535,7 @@ def main():
             out["libx265"] = libx265_baseline(info, host_frames, 8) if ok265 else {"available": False, "reason": why265}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(W, H, st.last_qp, args.me_range)
-        print(json.dumps(out))
+        emit(out)
     ranks.barrier()
     ranks.close()
 
