@@ -52,8 +52,7 @@ def _proc_worker(slot, device, task_q, result_q, stop_ev, out_dir, kw, convert_r
         f = task_q.get()
         if f is None:
             return
-        stop_ev.clear()                      # a stop signalled while this worker was idle concerned the previous file
-        last = [0.0]
+        last = [0.0]                         # (the parent clears stop_ev before it hands out a file: a stop_all() that lands after the hand-over stays set)
 
         def progress(fname, frame, total):
             now = time.time()
@@ -93,43 +92,72 @@ class BatchRunner:
         self._procs: list = []
 
     # -- process mode: one spawned process per worker slot, the parent dispatches
+    def _spawn(self, k: int):
+        device = k % self.n_devices if self.n_devices else None
+        ref = (self.convert.__module__, self.convert.__name__)
+        p = self._ctx.Process(target=_proc_worker, args=(k, device, self._task_q[k], self._result_q, self._stop_ev[k], str(self.out_dir), self.kw, ref), daemon=True)
+        p.start()
+        return p
+
     def _start_processes(self, n: int):
-        ctx = mp.get_context('spawn')
+        self._ctx = ctx = mp.get_context('spawn')
         self._result_q = ctx.Queue()
         self._task_q = [ctx.Queue() for _ in range(n)]
         self._stop_ev = [ctx.Event() for _ in range(n)]
-        ref = (self.convert.__module__, self.convert.__name__)
+        self._slot_file: Dict[int, str] = {}          # what every busy slot is working on (a worker that dies takes its file with it: the log names it)
         for k in range(n):
-            device = k % self.n_devices if self.n_devices else None
-            p = ctx.Process(target=_proc_worker, args=(k, device, self._task_q[k], self._result_q, self._stop_ev[k], str(self.out_dir), self.kw, ref), daemon=True)
-            p.start()
-            self._procs.append(p)
+            self._procs.append(self._spawn(k))
         t = threading.Thread(target=self._dispatch, args=(n,), daemon=True)
         self._threads.append(t)
         t.start()
+
+    def _hand_out(self, k: int) -> bool:
+        """next queued file -> slot k (lock held); False when the queue is empty (the slot's worker is told to leave)"""
+        if not self.queue:
+            self._active.pop(k, None)
+            self._slot_file.pop(k, None)
+            self._task_q[k].put(None)
+            return False
+        f = str(self.queue.popleft())
+        self._stop_ev[k].clear()                      # a stop that concerned the slot's previous file; cleared HERE, before the hand-over
+        self._slot_file[k] = f
+        self._active[k] = self._stop_ev[k]
+        self._task_q[k].put(f)
+        return True
 
     def _dispatch(self, n: int):
         busy = 0
         with self._lock:
             for k in range(n):
-                if self.queue:
-                    self._task_q[k].put(str(self.queue.popleft()))
-                    self._active[k] = self._stop_ev[k]
-                    busy += 1
-                else:
-                    self._task_q[k].put(None)
+                busy += self._hand_out(k)
+        last_check = time.time()
         while busy:
+            msg = None
             try:
-                msg = self._result_q.get(timeout=1.0)
+                msg = self._result_q.get(timeout=0.5)
             except Exception:
-                dead = [k for k, p in enumerate(self._procs) if not p.is_alive() and k in self._active]
-                for k in dead:               # a worker process that died takes its file with it: FAILED/UNKNOWN, like a raised exception
+                pass
+            if time.time() - last_check >= 0.5 or msg is None:
+                # dead workers are looked for on a timer, whatever the message traffic of the others.  A process that died takes its file with it:
+                # FAILED / UNKNOWN under the file's real name (like a raised exception, gui/worker.py:43-52), and the slot gets a fresh process
+                # so the rest of the queue is still coded
+                last_check = time.time()
+                for k, p in enumerate(self._procs):
+                    if p.is_alive() or k not in self._active:
+                        continue
                     with self._lock:
+                        lost = self._slot_file.pop(k, '?')
                         self._active.pop(k, None)
-                        self.results.append({'file': '?', 'status': 'FAILED', 'quality': None, 'retries': 0, 'method': 'UNKNOWN', 'hdr': False,
+                        logger.error('[ERROR] worker %d died (exit %s) while coding %s', k, p.exitcode, lost)
+                        self.results.append({'file': Path(lost).name, 'status': 'FAILED', 'quality': None, 'retries': 0, 'method': 'UNKNOWN', 'hdr': False,
                                              'seconds': '', 'device': ''})
                         self.save_csv()
-                    busy -= 1
+                        busy -= 1
+                        if self.queue:
+                            self._task_q[k] = self._ctx.Queue()          # the dead process may have left the old one half-read
+                            self._procs[k] = self._spawn(k)
+                            busy += self._hand_out(k)
+            if msg is None:
                 continue
             if msg[0] == 'progress':
                 if self.on_progress:
@@ -142,11 +170,8 @@ class BatchRunner:
             with self._lock:
                 self.results.append(res)
                 self.save_csv()
-                nxt = self.queue.popleft() if self.queue else None
-                if nxt is None:
-                    self._active.pop(k, None)
+                if not self._hand_out(k):
                     busy -= 1
-            self._task_q[k].put(str(nxt) if nxt is not None else None)
             if self.on_finished:
                 try:
                     self.on_finished(res)

@@ -177,7 +177,7 @@ struct mihevc_session {
     int w = 0, h = 0, ctus_w = 0, ctus_h = 0, n_ctu = 0;      // coded size
     TileGrid tiles;                                            // IDR pictures (PPS 1); 1x1 when cfg.intra_tiles == 0
     int keyint = 90, lanes = 4, me_range = 16, qp_p = 22, qp_i = 19;
-    bool is16 = false, keep_recon = false, flushed = false, failed = false;
+    bool is16 = false, keep_recon = false, flushed = false, failed = false, flushing = false;
     std::string err;
     hipStream_t st_compute = nullptr, st_copy = nullptr, st_pre = nullptr;      // st_pre: the chunk's pre-search, beside the IDR step
     // source pictures of the current chunk (device), in display order
@@ -400,7 +400,18 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (int e = scene_differences<T>(s, n, diff)) return e;
         const double per = (double)((s->w + 3) / 4) * ((s->h + 3) / 4) * (1 << (s->cfg.bit_depth - 8));
         int total = 0;                        // GOPs of the closed segments
-        auto is_jump = [&](int i) { const double d = (double)diff[(size_t)i] / per; return d > kCutAbs && s->scene_avg > 0 && d > kCutRatio * s->scene_avg; };
+        // Until the running mean has seen an ordinary picture (a session's first pictures) the chunk's MEDIAN difference stands in for it: a cut or a
+        // flash at the session's second picture is then a jump like any other and never becomes the mean the next pictures are measured against
+        double median = 0;
+        if (s->scene_avg <= 0) {
+            std::vector<unsigned long long> sorted(diff.begin() + 1, diff.end());
+            std::nth_element(sorted.begin(), sorted.begin() + (ptrdiff_t)(sorted.size() / 2), sorted.end());
+            median = (double)sorted[sorted.size() / 2] / per;
+        }
+        auto is_jump = [&](int i) {
+            const double d = (double)diff[(size_t)i] / per, base = s->scene_avg > 0 ? s->scene_avg : median;
+            return d > kCutAbs && d > kCutRatio * base;
+        };
         for (int i = 1; i < n; i++) {
             const double d = (double)diff[(size_t)i] / per;
             const int len = i - seg.back(), g = gops_of(len);
@@ -409,7 +420,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
             // not on the flash it would have to predict everything from
             const bool last_of_run = !(i + 1 < n && is_jump(i + 1));
             const int shortest = s->cfg.gop_balance ? len / g : (len % keyint ? len % keyint : keyint);
-            if (jump && last_of_run && shortest >= std::max(1, s->cfg.min_keyint) && total + g + gops_of(n - i) <= MAX_LANES) { total += g; seg.push_back(i); }
+            // the GOP the cut opens must keep min-keyint pictures too: the next chunk starts with an IDR picture of its own (the stream's last chunk may end short)
+            const bool tail_ok = s->flushing || n - i >= std::max(1, s->cfg.min_keyint);
+            if (jump && last_of_run && tail_ok && shortest >= std::max(1, s->cfg.min_keyint) && total + g + gops_of(n - i) <= MAX_LANES) { total += g; seg.push_back(i); }
             if (!jump) s->scene_avg = s->scene_avg > 0 ? 0.8 * s->scene_avg + 0.2 * d : d;      // ordinary pictures only: a jump says nothing about the new scene's motion
         }
     }
@@ -1009,6 +1022,7 @@ int mihevc_flush(mihevc_session *s)
     if (!s) return MIHEVC_EINVAL;
     if (s->failed) return MIHEVC_EDEVICE;
     if (s->flushed) return MIHEVC_OK;
+    s->flushing = true;
     int e = run_chunk(s);
     s->flushed = true;
     return e;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import logging
+import re
 import threading
 from fractions import Fraction
 from pathlib import Path
@@ -29,10 +30,18 @@ _COLOUR_CODES = {  # ffprobe names -> H.265 Table E.3/E.4/E.5 code points
 }
 
 
+_DEPTH_IN_FMT = re.compile(r'(?:p|gray|gbrp|yuva?\d{3}p?)(9|10|12|14|16)(?:le|be)?$|^(?:p0|p2|p4|y2)(10|12|16)(?:le|be)?$')
+
+
 def bit_depth_of(info: VideoInfo) -> int:
-    """10 for 10-bit sample formats (yuv420p10le, p010le, ...) and for anything probed as HDR, else 8."""
-    fmt = (info.pix_fmt or '').lower()
-    return 10 if (info.hdr or '10' in fmt) else 8
+    """10 for sample formats deeper than 8 bit (yuv420p10le, p010le, yuv420p12le ... — this path codes Main or Main10, so 12 / 16-bit sources come
+    in as 10) and for anything probed as HDR, else 8.  The depth is parsed from the END of the format name: yuv410p / yuvj411p are 8-bit formats
+    whose chroma layout happens to spell a '10' or '11'.  Deviation from the reference, documented in INTEGRATION.md §4: its libx265 branch codes
+    every non-HDR input as 8-bit Main (core/transcoder.py:363-364); the native path keeps a 10-bit SDR source's samples (Main10, no HDR10 SEI)."""
+    if info.hdr:
+        return 10
+    m = _DEPTH_IN_FMT.search((info.pix_fmt or '').lower())
+    return 10 if m and int(m.group(1) or m.group(2)) > 8 else 8
 
 
 def lanes_for(total_frames: int, keyint: int) -> int:

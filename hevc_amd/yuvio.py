@@ -10,6 +10,7 @@ from __future__ import annotations
 import re
 import shutil
 import subprocess
+import tempfile
 from fractions import Fraction
 from pathlib import Path
 from typing import Iterator, Optional, Tuple
@@ -92,12 +93,16 @@ class _PipeClip:
 
     def __init__(self, path: Path, info):
         self.width, self.height, self.fps = info.width, info.height, info.fps
-        self.bit_depth = 10 if (info.hdr or '10' in (info.pix_fmt or '')) else 8
+        from .encoder import bit_depth_of
+        self.bit_depth = bit_depth_of(info)
         self.n_frames = info.nb_frames or (int(info.duration * info.fps) if info.duration and info.fps else 0)
         pix = 'yuv420p10le' if self.bit_depth > 8 else 'yuv420p'
         self._name = Path(path).name
+        # stderr goes to a file, not a pipe: a damaged input can make `-v error` write more than a pipe buffer holds before the first frame, and a
+        # child blocked on stderr while frames() blocks on stdout would hang the encode for ever instead of failing it
+        self._err = tempfile.TemporaryFile()
         self._p = subprocess.Popen(['ffmpeg', '-v', 'error', '-i', str(path), '-f', 'rawvideo', '-pix_fmt', pix, '-'],
-                                   stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                                   stdout=subprocess.PIPE, stderr=self._err)
 
     def frames(self) -> Iterator[Planes]:
         w, h = self.width, self.height
@@ -112,7 +117,9 @@ class _PipeClip:
             n += 1
             yield a[:w * h].reshape(h, w), a[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), a[w * h * 5 // 4:].reshape(h // 2, w // 2)
         rc = self._p.wait()
-        err = (self._p.stderr.read() or b'').decode('utf-8', 'replace')[-500:]
+        self._err.seek(0, 2)
+        self._err.seek(max(0, self._err.tell() - 2000))
+        err = self._err.read().decode('utf-8', 'replace')[-500:]
         if rc != 0:
             raise RuntimeError(f'{self._name}: ffmpeg decode failed (exit {rc}): {err}')
         if self.n_frames and n < self.n_frames - max(2, self.n_frames // 100):      # container frame counts can be off by a frame or two
@@ -121,6 +128,12 @@ class _PipeClip:
     def close(self):
         try:
             self._p.kill()
+            self._p.wait()
+        except Exception:
+            pass
+        try:
+            self._p.stdout.close()
+            self._err.close()
         except Exception:
             pass
 

@@ -163,3 +163,33 @@ def test_one_worker_process_per_device(tmp_path):
     assert {n for n, _, _ in prog} == {f.name for f in files} and all(b == 3 for _, _, b in prog)
     rows = list(csv.DictReader(open(out / "transcode_log.csv")))
     assert len(rows) == 5 and {x["device"] for x in rows} == {"0", "1"} and {x["method"] for x in rows} == {"MI355X"}
+
+
+def convert_that_kills_its_process(f, out_dir, progress_callback=None, stop_event=None, device=None, **kw):
+    """stand-in for convert_video whose worker PROCESS dies on one file (a device runtime fault takes the process with it) while the others
+    keep sending progress messages ten times a second"""
+    import os
+    if f.stem == "clip1":
+        os._exit(17)
+    for i in range(10):
+        progress_callback(f.name, i + 1, 10)
+        time.sleep(0.1)
+    (Path(out_dir) / (f.stem + ".pid")).write_text(str(os.getpid()))
+    return {"file": f.name, "status": "SUCCESS", "quality": 19, "retries": 0, "method": "MI355X", "hdr": False}
+
+
+def test_a_dead_worker_process_is_named_and_replaced(tmp_path):
+    """the lost file is logged under its real name although the other worker's progress messages never let the queue run dry, the
+    slot gets a fresh process, and the files still queued are coded"""
+    files = [tmp_path / f"clip{i}.mp4" for i in range(5)]
+    for f in files:
+        f.write_bytes(b"x")
+    out = tmp_path / "out"
+    res = batch.BatchRunner(files, out, max_workers=2, convert=convert_that_kills_its_process, n_devices=2, use_processes=True).start().wait()
+    by = {x["file"]: x for x in res}
+    assert set(by) == {f.name for f in files}, res
+    assert by["clip1.mp4"]["status"] == "FAILED" and by["clip1.mp4"]["method"] == "UNKNOWN"
+    assert all(by[f.name]["status"] == "SUCCESS" for f in files if f.stem != "clip1")
+    rows = list(csv.DictReader(open(out / "transcode_log.csv")))
+    assert sorted(x["file"] for x in rows) == sorted(f.name for f in files)
+    assert len({(out / (f.stem + ".pid")).read_text() for f in files if f.stem != "clip1"}) >= 2       # the replacement process took files too

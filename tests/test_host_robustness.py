@@ -13,7 +13,7 @@ FAKE_FFMPEG = """#!/bin/sh
 # stand-in for ffmpeg: records its argv; as a decoder (-f rawvideo ... -) it emits FAKE_FRAMES frames of FAKE_FB bytes
 echo "$@" >> "$FAKE_LOG"
 case "$*" in
-  *"-f rawvideo"*" -") i=0; while [ $i -lt ${FAKE_FRAMES:-0} ]; do head -c ${FAKE_FB:-0} /dev/zero; i=$((i+1)); done; exit ${FAKE_RC:-0};;
+  *"-f rawvideo"*" -") if [ -n "$FAKE_STDERR_KB" ]; then head -c $((FAKE_STDERR_KB*1024)) /dev/zero | tr '\\0' 'e' >&2; fi; i=0; while [ $i -lt ${FAKE_FRAMES:-0} ]; do head -c ${FAKE_FB:-0} /dev/zero; i=$((i+1)); done; exit ${FAKE_RC:-0};;
 esac
 for a in "$@"; do last="$a"; done
 : > "$last"
@@ -55,6 +55,25 @@ def test_pipe_clip_checks_exit_status_and_frame_count(fake_ffmpeg, tmp_path, mon
     clip10.close()
 
 
+def test_pipe_clip_survives_a_decoder_that_floods_stderr(fake_ffmpeg, tmp_path, monkeypatch):
+    """a damaged input can make `ffmpeg -v error` write more than a pipe buffer (64 KiB) to stderr before its first frame; with stderr
+    on a pipe that nobody reads the child blocked there while frames() blocked on stdout.  Now: the frames arrive, the exit status decides."""
+    import threading
+    fb = 64 * 48 * 3 // 2
+    monkeypatch.setenv("FAKE_FB", str(fb))
+    monkeypatch.setenv("FAKE_FRAMES", "4")
+    monkeypatch.setenv("FAKE_STDERR_KB", "300")
+    got = []
+    t = threading.Thread(target=lambda: got.append(len(list(yuvio.open_any(tmp_path / "a.mkv", _info(n=4)).frames()))), daemon=True)
+    t.start()
+    t.join(30)
+    assert not t.is_alive(), "frames() hangs behind a full stderr pipe"
+    assert got == [4]
+    monkeypatch.setenv("FAKE_RC", "1")
+    with pytest.raises(RuntimeError, match="ffmpeg decode failed.*eeee"):
+        list(yuvio.open_any(tmp_path / "a.mkv", _info(n=4)).frames())
+
+
 def test_audio_remux_uses_the_reference_audio_flags(fake_ffmpeg, tmp_path):
     from hevc_amd.transcoder import get_audio_flags
     info = _info(audio=6)
@@ -74,6 +93,9 @@ def test_bit_depth_follows_the_sample_format():
     assert encoder.bit_depth_of(_info()) == 8
     assert encoder.bit_depth_of(_info(pix="yuv420p10le")) == 10 and encoder.bit_depth_of(_info(pix="p010le")) == 10
     assert encoder.bit_depth_of(_info(hdr=True)) == 10
+    # the depth is read from the END of the name: 8-bit formats whose chroma layout spells a "10" or "11" stay 8 bit
+    assert [encoder.bit_depth_of(_info(pix=f)) for f in ("yuv410p", "yuvj411p", "yuv411p", "nv12", "yuv444p")] == [8] * 5
+    assert [encoder.bit_depth_of(_info(pix=f)) for f in ("p016le", "yuv420p12le", "yuv422p10be", "p010")] == [10] * 4
     cfg = encoder.config_for(_info(pix="yuv420p10le"), 19, 600, 720, 90, "3", "main")
     assert cfg.bit_depth == 10 and cfg.hdr10 == 0 and cfg.colour_primaries == 1       # Main10 without the HDR10 SEI set
 
