@@ -9,6 +9,7 @@
  * The reference (uingei/hevc) has no decoder of its own; it relies on ffmpeg (core/transcoder.py:506).
  */
 #include "hevc_oracle.h"
+#include "hevc_dec_recon.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -186,6 +187,7 @@ struct orc_decoder {
     int slice_type, slice_qp, sao_luma, sao_chroma, max_merge, ref_idx;
     /* slices of the current picture: full-width bands of CTU rows [band_row0[k], band_row0[k + 1]); the slice being decoded starts at luma row slice_y0 */
     int n_bands, band_row0[24], slice_y0, pic_sao, pic_lf_across;
+    unsigned char band_lf_across[24];     /* per slice: slice_loop_filter_across_slices_enabled_flag (inferred from the PPS flag when absent) */
     size_t *epb; int n_epb, cap_epb;   /* positions (escaped payload offsets after the NAL header) of the removed 0x03 bytes */
     int poc;
     cabac cb;
@@ -710,21 +712,16 @@ static int residual_coding(orc_decoder *d, int log2n, int c_idx, int scan_idx, i
     return c->err ? -1 : 0;
 }
 
-/* reconstruct one TU: dequant + inverse transform + add to prediction already stored in the picture */
+/* reconstruct one TU: scaling + inverse transform + add to the prediction already stored in the picture — the decoder's own arithmetic
+ * (hevc_dec_recon.c), not the oracle's */
 static void add_residual(orc_decoder *d, int c_idx, int x, int y, int log2n, const int16_t *lvl, int qp, int dst)
 {
-    int n = 1 << log2n, maxv = (1 << d->bit_depth) - 1;
-    int16_t coef[32 * 32], res[32 * 32];
-    orc_dequant(lvl, coef, log2n, qp, d->bit_depth);
-    orc_inv_transform(coef, res, n, log2n, dst, d->bit_depth);
-    pix *p = d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x;
-    for (int j = 0; j < n; j++)
-        for (int i = 0; i < n; i++) { int v = p[j * d->cur.stride[c_idx] + i] + res[j * n + i]; p[j * d->cur.stride[c_idx] + i] = (pix)CLIP3(0, maxv, v); }
+    d2_residual_add(d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x, d->cur.stride[c_idx], lvl, log2n, qp, d->bit_depth, dst);
 }
 
 static void intra_predict_block(orc_decoder *d, int c_idx, int x, int y, int log2n, int mode)
 {
-    pix ref[129], filt[129];
+    pix ref[129];
     int s = c_idx ? 1 : 0;
     /* 8.4.4.2.2 with 6.4.1: a neighbour is available when it lies in the picture, in the current slice and tile, and earlier in decoding
      * order (avail_z: explicit tile boundaries, the slice's first row); then the substitution process */
@@ -749,8 +746,7 @@ static void intra_predict_block(orc_decoder *d, int c_idx, int x, int y, int log
             for (int i = 1; i < total; i++) if (!av[i]) ref[i] = ref[i - 1];
         }
     }
-    orc_intra_filter_ref(ref, filt, log2n, mode, c_idx, d->bit_depth, d->strong_intra);
-    orc_intra_pred(filt, d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x, d->cur.stride[c_idx], log2n, mode, c_idx, d->bit_depth);
+    d2_intra_pred(ref, d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x, d->cur.stride[c_idx], log2n, mode, c_idx, d->bit_depth, d->strong_intra);
 }
 
 static int intra_scan_idx(int log2n_block, int c_idx, int mode)
@@ -802,7 +798,7 @@ static int transform_tree(orc_decoder *d, int x0, int y0, int xb, int yb, int lo
     int do_chroma = log2n > 2 || blk == 3;
     if (do_chroma) {
         int xc = (log2n > 2 ? x0 : xb) >> 1, yc = (log2n > 2 ? y0 : yb) >> 1, l2c = log2n > 2 ? log2n - 1 : 2;
-        int qpc = orc_chroma_qp(d->slice_qp);
+        int qpc = d2_chroma_qp(d->slice_qp);
         for (int ci = 1; ci < 3; ci++) {
             int cbf = ci == 1 ? cbf_cb : cbf_cr;
             if (intra) intra_predict_block(d, ci, xc, yc, l2c, chroma_mode);
@@ -1084,18 +1080,19 @@ static size_t epb_before(const orc_decoder *d, size_t r)
 static void finish_picture(orc_decoder *d)
 {
     if (!d->cur_valid) return;
-    const int wc = (d->w + ORC_CTU - 1) >> ORC_CTU_LOG2, w8 = d->w >> 3;
     picture out; memset(&out, 0, sizeof out);
     if (d->pic_sao) { alloc_pic(d, &out); out.poc = d->poc; }
-    for (int k = 0; k < d->n_bands; k++) {
-        const int r0 = d->band_row0[k], r1 = d->band_row0[k + 1];
-        const int y0 = r0 << ORC_CTU_LOG2, y1 = (r1 << ORC_CTU_LOG2) < d->h ? (r1 << ORC_CTU_LOG2) : d->h, bh = y1 - y0;
-        if (d->n_bands > 1 && d->pic_lf_across) { set_err(d, "several slices with loop filtering across them are parsed but not filtered"); break; }
-        pix *py = d->cur.pl[0] + (size_t)y0 * d->cur.stride[0], *pu = d->cur.pl[1] + (size_t)(y0 / 2) * d->cur.stride[1], *pv = d->cur.pl[2] + (size_t)(y0 / 2) * d->cur.stride[1];
-        orc_deblock_frame(py, pu, pv, d->cur.stride[0], d->cur.stride[1], d->w, bh, d->cu + (size_t)(y0 >> 3) * w8, d->bit_depth, d->cb_off);
+    {   /* in-loop filters over the whole picture with the slice / tile boundary rules of 8.7.2 / 8.7.3 (hevc_dec_recon.c: the decoder's own) */
+        d2_picture_info pi;
+        memset(&pi, 0, sizeof pi);
+        pi.w = d->w; pi.h = d->h; pi.bit_depth = d->bit_depth; pi.cu = d->cu; pi.sao = d->sao;
+        pi.cb_qp_offset = d->cb_off; pi.cr_qp_offset = d->cr_off;
+        pi.n_bands = d->n_bands; pi.band_row0 = d->band_row0; pi.band_lf_across = d->band_lf_across;
+        pi.tile_cols = d->tiles ? d->tile_cols : 1; pi.tile_rows = d->tiles ? d->tile_rows : 1; pi.lf_across_tiles = d->tiles ? d->lf_across_tiles : 1;
+        pi.col_bd = d->col_bd; pi.row_bd = d->row_bd;
+        d2_deblock_picture(&pi, d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1]);
         if (d->pic_sao)
-            orc_sao_apply_frame(py, pu, pv, d->cur.stride[0], d->cur.stride[1], out.pl[0] + (size_t)y0 * out.stride[0], out.pl[1] + (size_t)(y0 / 2) * out.stride[1],
-                                out.pl[2] + (size_t)(y0 / 2) * out.stride[1], out.stride[0], out.stride[1], d->w, bh, d->bit_depth, d->sao + (size_t)r0 * wc);
+            d2_sao_picture(&pi, d->cur.pl[0], d->cur.pl[1], d->cur.pl[2], d->cur.stride[0], d->cur.stride[1], out.pl[0], out.pl[1], out.pl[2], out.stride[0], out.stride[1]);
     }
     if (d->pic_sao) { free_pic(&d->cur); d->cur = out; }
     if (d->band_row0[d->n_bands] != ((d->h + ORC_CTU - 1) >> ORC_CTU_LOG2)) set_err(d, "picture incomplete: slices cover %d of %d CTU rows", d->band_row0[d->n_bands], (d->h + ORC_CTU - 1) >> ORC_CTU_LOG2);
@@ -1145,7 +1142,8 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
         d->max_merge = 5 - (int)br_ue(&b);
     }
     d->slice_qp = d->init_qp + br_se(&b);
-    if (d->lf_across) br_bit(&b);      /* slice_loop_filter_across_slices_enabled_flag: deblocking is on, so present */
+    int slice_lf_across = d->lf_across;      /* 7.4.7.1: when absent, inferred equal to pps_loop_filter_across_slices_enabled_flag */
+    if (d->lf_across) slice_lf_across = br_bit(&b);      /* slice_loop_filter_across_slices_enabled_flag: deblocking is on, so present */
     int n_entry = 0;
     uint32_t entry[20 * 22];
     if (d->tiles) {
@@ -1241,6 +1239,7 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
         } else if (!ended) { set_err(d, "slice data ends without end_of_slice_segment_flag"); goto done; }
         sub_start = sub_end;
     }
+    d->band_lf_across[d->n_bands] = (unsigned char)slice_lf_across;
     d->n_bands++;
     d->band_row0[d->n_bands] = row_end;
     ok = 0;

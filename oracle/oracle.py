@@ -20,7 +20,7 @@ _lib = None
 
 def build(force: bool = False) -> Path:
     so = HERE / "liboracle.so"
-    srcs = [HERE / "hevc_oracle.c", HERE / "hevc_dec.c", HERE / "hevc_oracle.h"]
+    srcs = [HERE / "hevc_oracle.c", HERE / "hevc_dec.c", HERE / "hevc_dec_recon.c", HERE / "hevc_oracle.h", HERE / "hevc_dec_recon.h"]
     if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs if s.exists()):
         subprocess.run(["make", "-C", str(HERE), "-s"], check=True)
     return so
