@@ -41,6 +41,7 @@ void mihevc_config_default(mihevc_config *c)
     c->md_white[0] = 15635; c->md_white[1] = 16450; c->md_max_lum = 10000000; c->md_min_lum = 50;
     c->max_cll = 1000; c->max_fall = 400;
     c->me_range = 0; c->gops_in_flight = 0; c->host_threads = 0; c->sao = 1; c->intra_tiles = 1; c->intra_nxn = 0; c->intra_in_p = 0; c->pre_search = 1; c->rdo_zero = 1; c->chroma_modes = 1; c->scenecut = 1; c->gop_balance = 1; c->rdo_cg = 0;
+    c->p_tiles = -1;
 }
 
 // lambda_mode = 0.57 * 2^((qp-12)/3) (the usual HM/x265 relation); SAD/SATD-domain lambda is its square root.
@@ -86,6 +87,14 @@ int mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows)
 {
     if (!config_ok(cfg) || !cols || !rows) return MIHEVC_EINVAL;
     TileGrid g = tile_grid(*cfg);
+    *cols = g.cols; *rows = g.rows;
+    return MIHEVC_OK;
+}
+
+int mihevc_p_tile_grid(const mihevc_config *cfg, int *cols, int *rows)
+{
+    if (!config_ok(cfg) || !cols || !rows) return MIHEVC_EINVAL;
+    TileGrid g = p_tile_grid(*cfg);
     *cols = g.cols; *rows = g.rows;
     return MIHEVC_OK;
 }

@@ -261,10 +261,26 @@ TileGrid tile_grid(const mihevc_config &cfg)
     return g;
 }
 
+// P pictures (PPS 0): a coarse uniform grid, one tile per 1920x1080 of picture — large tiles cost next to nothing in bits (contexts restart and
+// merge / AMVP candidates end at 16 boundaries of a 4320p picture instead of 440) and give the host one CABAC job per tile
+TileGrid p_tile_grid(const mihevc_config &cfg)
+{
+    TileGrid g;
+    CodedSize cs = coded_size(cfg.width, cfg.height);
+    g.wc = (cs.w + kCtu - 1) >> kCtuLog2; g.hc = (cs.h + kCtu - 1) >> kCtuLog2;
+    if (cfg.p_tiles == 0 || sliced(cfg)) return g;        // the slices of a sliced picture already are one job each
+    int max_cols, max_rows;
+    level_tile_limits(cfg.level_idc, max_cols, max_rows);
+    const int floor_ = cfg.p_tiles > 0 ? 2 : 1;
+    g.cols = std::max(1, std::min({max_cols, g.wc / (256 / kCtu), std::max(floor_, cs.w / 1920)}));
+    g.rows = std::max(1, std::min({max_rows, g.hc / (64 / kCtu), std::max(floor_, cs.h / 1080)}));
+    return g;
+}
+
 void write_pps(const mihevc_config &cfg, int pps_id, std::vector<uint8_t> &out)
 {
     BitWriter w;
-    TileGrid g = pps_id == 1 ? tile_grid(cfg) : TileGrid();
+    TileGrid g = pps_id == 1 ? tile_grid(cfg) : p_tile_grid(cfg);
     int rows_total = g.rows;
     if (pps_id == 1 && sliced(cfg)) {          // every slice splits ITS rows uniformly: the picture's grid is the concatenation, spelled out
         rows_total = 0;
@@ -408,7 +424,7 @@ void write_parameter_sets(const mihevc_config &c, std::vector<uint8_t> &out)
     write_vps(c, out);
     write_sps(c, out);
     write_pps(c, 0, out);
-    if (idr_tiles_on(c)) write_pps(c, 1, out);
+    if (idr_tiles_on(c) || p_tile_grid(c).on()) write_pps(c, 1, out);      // IDR pictures never use PPS 0 when it carries the P pictures' tile grid
     if (c.hdr10) write_sei_hdr10(c, out);
 }
 
@@ -610,7 +626,7 @@ public:
         wc_ = (w_ + kCtu - 1) >> kCtuLog2; hc_ = (h_ + kCtu - 1) >> kCtuLog2;
         skip_.assign((size_t)w8_ * (h_ >> 3), 0);
         depth_.assign((size_t)w8_ * (h_ >> 3), 0);
-        if (pic.slice_type == 2) grid_ = tile_grid(cfg);
+        grid_ = pic.slice_type == 2 ? tile_grid(cfg) : p_tile_grid(cfg);
         grid_.wc = wc_; grid_.hc = hc_;
     }
     const TileGrid &grid() const { return grid_; }
@@ -1060,7 +1076,28 @@ private:
 
 }  // namespace
 
-size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out, bool with_aud)
+static TileGrid picture_grid(const mihevc_config &cfg, const PictureSyms &pic) { return pic.slice_type == 2 ? tile_grid(cfg) : p_tile_grid(cfg); }
+
+int picture_tiles(const mihevc_config &cfg, const PictureSyms &pic)
+{
+    const TileGrid g = picture_grid(cfg, pic);
+    return g.cols * g.rows;
+}
+
+size_t encode_tiles(const mihevc_config &cfg, const PictureSyms &pic, int t0, int t1, std::vector<std::vector<uint8_t>> &sub)
+{
+    SliceCoder coder(cfg, pic);          // its neighbourhood state (skip flags, depths) is only ever read inside the tile that wrote it
+    const TileGrid &grid = coder.grid();
+    size_t bins = 0;
+    for (int t = t0; t < t1; t++) {
+        sub[(size_t)t].clear();
+        sub[(size_t)t].reserve(1 << 14);
+        bins += coder.run_tile(t % grid.cols, t / grid.cols, sub[(size_t)t]);
+    }
+    return bins;
+}
+
+void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const std::vector<std::vector<uint8_t>> &sub, std::vector<uint8_t> &out, bool with_aud)
 {
     if (cfg.aud && with_aud) write_aud(pic.slice_type, out);
     // slice_segment_header (7.3.6.1)
@@ -1069,9 +1106,9 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
     const bool first = !sliced(cfg) || cfg.slice_index == 0;
     w.put1(first);                   // first_slice_segment_in_pic_flag
     if (idr) w.put1(0);              // no_output_of_prior_pics_flag
-    const TileGrid grid = idr ? tile_grid(cfg) : TileGrid();
-    const bool pps_tiles = idr && idr_tiles_on(cfg);
-    w.ue(pps_tiles ? 1 : 0);         // slice_pic_parameter_set_id: PPS 1 carries the IDR tile grid
+    const TileGrid grid = picture_grid(cfg, pic);
+    const bool pps_tiles = idr ? idr_tiles_on(cfg) : grid.on();
+    w.ue(idr && (pps_tiles || p_tile_grid(cfg).on()) ? 1 : 0);  // slice_pic_parameter_set_id: PPS 1 carries the IDR tile grid, PPS 0 the P pictures' (or none)
     if (!first) {                    // slice_segment_address: the slice's first CTB in raster order, Ceil(Log2(PicSizeInCtbsY)) bits
         const CodedSize pc = coded_size(cfg.width, picture_height(cfg));
         const int wc = (pc.w + kCtu - 1) >> kCtuLog2, hc = (pc.h + kCtu - 1) >> kCtuLog2;
@@ -1094,14 +1131,7 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
     }
     w.se(pic.qp - 26);               // slice_qp_delta
     if (!sliced(cfg)) w.put1(1);     // slice_loop_filter_across_slices_enabled_flag (present only when the PPS flag is set)
-    SliceCoder coder(cfg, pic);
     const int n_tiles = grid.cols * grid.rows;
-    std::vector<std::vector<uint8_t>> sub((size_t)n_tiles);
-    size_t bins = 0;
-    for (int t = 0; t < n_tiles; t++) {
-        sub[(size_t)t].reserve(1 << 14);
-        bins += coder.run_tile(t % grid.cols, t / grid.cols, sub[(size_t)t]);
-    }
     if (pps_tiles) {
         // entry points (7.4.7.1): substream sizes in bytes of the NAL payload, emulation prevention bytes included.  Every
         // substream (and the header) ends in a byte that holds its final '1' bit, so the zero run that triggers an 0x03
@@ -1134,6 +1164,14 @@ size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vec
     rbsp.reserve(total);
     for (const auto &v : sub) rbsp.insert(rbsp.end(), v.begin(), v.end());
     append_nal(out, idr ? 19 : 1, rbsp);
+}
+
+size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out, bool with_aud)
+{
+    const int n_tiles = picture_tiles(cfg, pic);
+    std::vector<std::vector<uint8_t>> sub((size_t)n_tiles);
+    const size_t bins = encode_tiles(cfg, pic, 0, n_tiles, sub);
+    assemble_picture(cfg, pic, sub, out, with_aud);
     return bins;
 }
 

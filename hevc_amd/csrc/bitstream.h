@@ -68,6 +68,7 @@ struct TileGrid {
     bool on() const { return cols > 1 || rows > 1; }
 };
 TileGrid tile_grid(const mihevc_config &cfg);        // of what the session codes: the picture, or its slice (cfg.slice_count > 1)
+TileGrid p_tile_grid(const mihevc_config &cfg);      // P pictures (PPS 0, cfg.p_tiles); 1x1 when off or when the picture is coded as several slices
 // sliced pictures (cfg.slice_count > 1): height of the whole picture, first CTU row of a slice, tile rows PPS 1 gives a slice
 inline bool sliced(const mihevc_config &c) { return c.slice_count > 1; }
 inline int picture_height(const mihevc_config &c) { return sliced(c) ? c.pic_height : c.height; }
@@ -101,5 +102,11 @@ struct PictureSyms {
 // with_aud: prepend the access unit delimiter when cfg.aud (callers that put parameter sets / SEI into the same access unit write
 // the AUD themselves, it must come first: 7.4.2.4.4)
 size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out, bool with_aud = true);
+// The same in pieces, so that the tiles of one picture can be coded by several host threads: every tile is its own CABAC substream and looks at
+// nothing outside itself.  picture_tiles: substreams of this picture; encode_tiles: tiles [t0, t1) into sub[t] (any thread, any order, each range
+// once); assemble_picture: slice header + entry points + substreams -> one NAL.  encode_picture = all three in one thread.
+int picture_tiles(const mihevc_config &cfg, const PictureSyms &pic);
+size_t encode_tiles(const mihevc_config &cfg, const PictureSyms &pic, int t0, int t1, std::vector<std::vector<uint8_t>> &sub);
+void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const std::vector<std::vector<uint8_t>> &sub, std::vector<uint8_t> &out, bool with_aud);
 
 }  // namespace mihevc

@@ -40,7 +40,7 @@ template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_
 // per-picture sum of squared error into args.sse[0..2] (u64, accumulated with atomics: zero the targets first)
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch);
 constexpr int MAX_LANES = 16;
-struct StepParams { CostParams prm[MAX_LANES]; };      // one P step's cost parameters per lane, passed by value
+struct StepParams { CostParams prm[MAX_LANES]; int p_tile_cols, p_tile_rows; };      // one P step's cost parameters per lane, passed by value; the P pictures' tile grid (intra second pass: availability)
 template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch);
 // head of a P step in one launch: border pad of the pictures `prev` describes (nullptr: none), 1/4-size pictures for `pre` (nullptr: none), then launch_begin_p_step's work
 template <typename T> hipError_t launch_prep_p_step(hipStream_t st, const SaoArgs<T> *prev, const PreArgs<T> *pre, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa,

@@ -227,7 +227,7 @@ template <typename T> __global__ __launch_bounds__(64) void k_begin_p_step(Intra
     if (threadIdx.x == 0) {
         CostParams c = p.prm[g];
         ea[g].prm = c; sa[g].prm = c;
-        c.tile_cols = c.tile_rows = 1;      // P pictures use PPS 0 (one tile)
+        c.tile_cols = p.p_tile_cols; c.tile_rows = p.p_tile_rows;      // P pictures use PPS 0 (one tile, or cfg.p_tiles' grid)
         ia[g].prm = c;
     }
     if (threadIdx.x < 4) sa[g].sse[threadIdx.x] = 0;
@@ -257,7 +257,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep_p_step(const
     if (threadIdx.x == 0) {
         CostParams c = p.prm[g];
         ea[g].prm = c; sa[g].prm = c;
-        c.tile_cols = c.tile_rows = 1;      // P pictures use PPS 0 (one tile)
+        c.tile_cols = p.p_tile_cols; c.tile_rows = p.p_tile_rows;      // P pictures use PPS 0 (one tile, or cfg.p_tiles' grid)
         ia[g].prm = c;
     }
     if (threadIdx.x < 4) sa[g].sse[threadIdx.x] = 0;
@@ -648,7 +648,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
         IntraArgs<T> ia;
         for (int i = 0; i < 3; i++) { ia.src[i] = a.src[i]; ia.rec[i] = a.rec[i]; ia.coef[i] = a.coef[i]; }
         ia.w = w; ia.h = h; ia.ctus_w = ctus_w; ia.ctus_h = (h + CTU - 1) / CTU;
-        ia.prm = a.prm; ia.prm.tile_cols = ia.prm.tile_rows = 1;
+        ia.prm = a.prm;        // tile_cols / tile_rows: the P pictures' own grid (1x1 unless the caller passes cfg.p_tiles' grid)
         ia.cu = a.cu; ia.diagonal = 0; ia.est = a.est; ia.sparse_coef = 0; ia.ip = a.ip; ia.plan = nullptr;
         CK(diargs.alloc(sizeof ia));
         CK(hipMemcpy(diargs.p, &ia, sizeof ia, hipMemcpyHostToDevice));

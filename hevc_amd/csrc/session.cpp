@@ -176,6 +176,7 @@ struct mihevc_session {
     int device = 0;
     int w = 0, h = 0, ctus_w = 0, ctus_h = 0, n_ctu = 0;      // coded size
     TileGrid tiles;                                            // IDR pictures (PPS 1); 1x1 when cfg.intra_tiles == 0
+    TileGrid ptiles;                                           // P pictures (PPS 0, cfg.p_tiles); 1x1 when off
     int keyint = 90, lanes = 4, me_range = 16, qp_p = 22, qp_i = 19;
     bool is16 = false, keep_recon = false, flushed = false, failed = false, flushing = false;
     std::string err;
@@ -208,6 +209,7 @@ struct mihevc_session {
     std::condition_variable cv;
     int jobs_open[kRing] = {0};
     int ring = 8;                 // slots in use (<= kRing)
+    int host_threads = 2;         // CABAC worker threads this session asked the process-wide pool for
     std::map<int64_t, Packet> packets;     // by output index
     int64_t next_out = 0, frames_in = 0, frames_done = 0;
     std::vector<uint8_t> headers, cur_packet;
@@ -311,35 +313,54 @@ template <typename T> struct StepView {
 template <typename T> Plane<T> mk(void *p, int stride) { return Plane<T>{(T *)p, stride}; }
 template <typename T> Plane<const T> mkc(void *p, int stride) { return Plane<const T>{(const T *)p, stride}; }
 
-// CABAC job: wait for the step's copy, code the picture, publish the packet
-void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t pts, int slice_type, int poc, int qp, bool first_of_stream, int prev_gop_len)
+// CABAC of one picture: `parts` host jobs share its tiles (cfg.p_tiles / the IDR grid: every tile is its own substream), the last one to finish
+// puts the access unit together and publishes the packet.  One part = the whole picture in one job, as before round 3.
+struct PictureJob {
+    mihevc_session *s;
+    int slot, lane_i, slice_type, poc, qp, prev_gop_len, parts, n_tiles;
+    int64_t index, pts;
+    bool first_of_stream;
+    PictureSyms pic;
+    std::vector<std::vector<uint8_t>> sub;
+    std::atomic<int> left;
+    std::atomic<long long> ns{0};
+};
+
+void picture_symbols(mihevc_session *s, int slot, int lane_i, PictureSyms &pic)
 {
-    auto t0 = std::chrono::steady_clock::now();
     SymLayout sl(s->w, s->h);
     const uint8_t *b = s->lane[lane_i].sym_host[slot];
-    PictureSyms pic;
-    pic.slice_type = slice_type; pic.poc = poc; pic.qp = qp;
     pic.cu = (const mihevc_cu_rec *)(b + sl.cu);
     pic.coef[0] = (const int16_t *)(b + sl.cy); pic.coef[1] = (const int16_t *)(b + sl.cu_); pic.coef[2] = (const int16_t *)(b + sl.cv);
     pic.sao = s->cfg.sao ? (const mihevc_sao_ctu *)(b + sl.sao) : nullptr;
+}
+
+// last part of a picture: access unit = AUD first (7.4.2.4.4), parameter sets (+ HDR10 SEI), buffering period at the IDR, picture timing, the slice
+void publish_picture(PictureJob *j)
+{
+    mihevc_session *s = j->s;
+    auto t0 = std::chrono::steady_clock::now();
+    SymLayout sl(s->w, s->h);
+    const uint8_t *b = s->lane[j->lane_i].sym_host[j->slot];
     Packet pk;
-    pk.pts = pts; pk.key = slice_type == 2;
-    // access unit: AUD first (7.4.2.4.4), parameter sets (+ HDR10 SEI), buffering period at the IDR, picture timing, the slice
+    pk.pts = j->pts; pk.key = j->slice_type == 2;
     // a picture's later slices (sessions on other devices, cfg.slice_index > 0) contribute their slice NAL unit only: the access unit's
     // delimiter, parameter sets and SEI come with slice 0
     const bool au_head = s->cfg.slice_count <= 1 || s->cfg.slice_index == 0;
-    if (s->cfg.aud && au_head) write_aud(slice_type, pk.data);
-    if (au_head && slice_type == 2 && (first_of_stream || s->cfg.repeat_headers)) pk.data.insert(pk.data.end(), s->headers.begin(), s->headers.end());
+    if (s->cfg.aud && au_head) write_aud(j->slice_type, pk.data);
+    if (au_head && j->slice_type == 2 && (j->first_of_stream || s->cfg.repeat_headers)) pk.data.insert(pk.data.end(), s->headers.begin(), s->headers.end());
     if (s->cfg.hrd && au_head) {
-        if (slice_type == 2) write_sei_buffering_period(s->cfg, pk.data);
+        if (j->slice_type == 2) write_sei_buffering_period(s->cfg, pk.data);
         // clock ticks since the previous buffering period: position in the GOP, or the previous GOP's length at an IDR
-        write_sei_pic_timing(s->cfg, (uint32_t)(poc > 0 ? poc - 1 : (index > 0 ? prev_gop_len - 1 : 0)), pk.data);
+        write_sei_pic_timing(s->cfg, (uint32_t)(j->poc > 0 ? j->poc - 1 : (j->index > 0 ? j->prev_gop_len - 1 : 0)), pk.data);
     }
-    encode_picture(s->cfg, pic, pk.data, false);
+    assemble_picture(s->cfg, j->pic, j->sub, pk.data, false);
     const unsigned long long *sse = (const unsigned long long *)(b + sl.sse);
     pk.ready = true;
     auto t1 = std::chrono::steady_clock::now();
-    s->entropy_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    s->entropy_ns += j->ns.load() + std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+    const int slot = j->slot;
+    const int64_t index = j->index;
     {
         std::lock_guard<std::mutex> l(s->m);
         s->stats.sse_y += (double)sse[0]; s->stats.sse_u += (double)sse[1]; s->stats.sse_v += (double)sse[2];
@@ -352,9 +373,19 @@ void entropy_job(mihevc_session *s, int slot, int lane_i, int64_t index, int64_t
         }
         s->packets[index] = std::move(pk);
         s->frames_done++;
+        delete j;
         s->jobs_open[slot]--;
         s->cv.notify_all();      // under the lock: mihevc_close may delete the session as soon as its last job has let go of the mutex
     }
+}
+
+void entropy_part(PictureJob *j, int part)
+{
+    auto t0 = std::chrono::steady_clock::now();
+    const int t_a = (int)((long long)j->n_tiles * part / j->parts), t_b = (int)((long long)j->n_tiles * (part + 1) / j->parts);
+    encode_tiles(j->s->cfg, j->pic, t_a, t_b, j->sub);
+    j->ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    if (j->left.fetch_sub(1) == 1) publish_picture(j);
 }
 
 // sum of |a - b| over every 4th sample of every 4th row of consecutive pending source pictures: out[i] for the pair (i - 1, i), out[0] = 0
@@ -541,7 +572,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.inter.ip = ipass ? L.ip : nullptr;
             A.intra.ip = ipass ? L.ip : nullptr;
             A.intra.plan = t == 0 ? L.plan : nullptr;      // P pictures' second pass plans and codes a CTU inside one workgroup
-            if (t > 0) { A.intra.prm.tile_cols = A.intra.prm.tile_rows = 1; }
+            if (t > 0) { A.intra.prm.tile_cols = s->ptiles.cols; A.intra.prm.tile_rows = s->ptiles.rows; }
             A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
             A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
             A.sao.sse = (unsigned long long *)(sym + sl.sse);
@@ -617,7 +648,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     auto patch_qp = [&](int t, int g, int qp) {
         StepView<T> hv(ha, lay, t);
         hv.intra[g].prm = hv.inter[g].prm = hv.sao[g].prm = prm_for(qp);
-        if (t > 0) { hv.intra[g].prm.tile_cols = hv.intra[g].prm.tile_rows = 1; }
+        if (t > 0) { hv.intra[g].prm.tile_cols = s->ptiles.cols; hv.intra[g].prm.tile_rows = s->ptiles.rows; }
         std::lock_guard<std::mutex> l(s->m);
         auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + t)];
         fr.qp = qp; fr.type = t == 0 ? 2 : 1;
@@ -777,6 +808,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 // The same launch pads the border of the previous step's pictures (nothing before this step's searches reads it) and makes the 1/4-size
                 // pictures: one launch boundary on the compute stream instead of three (~6 us each, profiles/r02_e: kernel time 733 of 797 us per step).
                 StepParams sp{};
+                sp.p_tile_cols = s->ptiles.cols; sp.p_tile_rows = s->ptiles.rows;
                 for (int g = 0; g < B; g++) sp.prm[g] = hv.inter[g].prm;
                 StepView<T> pv(da, lay, t - 1);
                 HIPCK(s, launch_prep_p_step<T>(s->st_compute, pv.sao, (const PreArgs<T> *)nullptr, dv.intra, dv.inter, dv.sao, sp, s->w, s->h, B));
@@ -825,19 +857,27 @@ template <typename T> int encode_chunk(mihevc_session *s)
             std::lock_guard<std::mutex> l(s->m);
             for (int g = 0; g < B; g++) s->jobs_open[lane_slot[g]]++;
         }
+        // host jobs per picture: the pool's threads shared by the pictures of this step (their tiles, when the picture has several: cfg.p_tiles / IDR grid)
+        const int parts_wanted = std::max(1, s->host_threads / std::max(1, B));
         for (int g = 0; g < B; g++) {
             int fi = gstart[(size_t)g] + t;
-            int64_t index = s->frames_in - n + fi, pts = s->pending[fi].pts;
-            const int pgl = prev_len[(size_t)g];
-            const int slot = lane_slot[g];
-            hipEvent_t ev = s->ev_copy[slot];
-            int st = t == 0 ? 2 : 1, qp = qp_step[g];
-            bool first = index == 0;
-            s->pool->submit([s, slot, g, index, pts, st, t, qp, first, ev, pgl] {
-                (void)hipSetDevice(s->device);          // worker threads start on device 0: wait on the event in its own device's context
-                (void)hipEventSynchronize(ev);
-                entropy_job(s, slot, g, index, pts, st, t, qp, first, pgl);
-            });
+            PictureJob *j = new PictureJob();
+            j->s = s; j->slot = lane_slot[g]; j->lane_i = g; j->index = s->frames_in - n + fi; j->pts = s->pending[fi].pts;
+            j->prev_gop_len = prev_len[(size_t)g];
+            j->slice_type = t == 0 ? 2 : 1; j->poc = t; j->qp = qp_step[g]; j->first_of_stream = j->index == 0;
+            j->pic.slice_type = j->slice_type; j->pic.poc = t; j->pic.qp = j->qp;
+            picture_symbols(s, j->slot, g, j->pic);
+            j->n_tiles = picture_tiles(s->cfg, j->pic);
+            j->parts = std::min(j->n_tiles, parts_wanted);
+            j->sub.resize((size_t)j->n_tiles);
+            j->left.store(j->parts);
+            hipEvent_t ev = s->ev_copy[j->slot];
+            for (int part = 0; part < j->parts; part++)
+                s->pool->submit([s, j, part, ev] {
+                    (void)hipSetDevice(s->device);          // worker threads start on device 0: wait on the event in its own device's context
+                    (void)hipEventSynchronize(ev);
+                    entropy_part(j, part);
+                });
         }
     }
 #undef STAGE
@@ -928,6 +968,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->w = cs.w; s->h = cs.h;
     s->ctus_w = (s->w + CTU - 1) / CTU; s->ctus_h = (s->h + CTU - 1) / CTU; s->n_ctu = s->ctus_w * s->ctus_h;
     s->tiles = tile_grid(s->cfg);
+    s->ptiles = p_tile_grid(s->cfg);
     s->ring = cfg->level_idc >= 150 ? kRing : 8;
     s->is16 = cfg->bit_depth > 8;
     s->keyint = cfg->keyint;
@@ -957,6 +998,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     }
     int threads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
     s->pool = &ThreadPool::shared(threads);
+    s->host_threads = threads;
     *out = s;
     return MIHEVC_OK;
 }

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define MIHEVC_ABI_VERSION 2
+#define MIHEVC_ABI_VERSION 3
 
 typedef enum {
     MIHEVC_OK = 0,
@@ -96,6 +96,12 @@ typedef struct mihevc_config {
     int32_t rdo_cg;                   /* k > 0: RD zero-out of the 4x4 coefficient groups of inter TUs ("RDOQ-lite"): a group of levels is dropped when the
                                        * squared error it removes is worth less than lambda x k / 2 x its bits.  Default 0 (off): over whole GOPs of the bench
                                        * clip it buys nothing that a higher QP would not (k = 2: -0.6 % bits / -0.006 dB, k = 5: -8.5 % / -0.16 dB at QP 27) */
+    /* ---- ABI 3 ---- */
+    int32_t p_tiles;                  /* P pictures as a uniform tile grid of their own (PPS 0), one CABAC substream and ONE HOST JOB per tile: what lets the host keep up
+                                       * with the device when few pictures are in flight (4320p: one GOP lane, 1.5 Mbit of CABAC per picture; x265 gets the same from WPP
+                                       * under `-threads 0`, core/transcoder.py:410-411).  -1 (default): one tile per 1920x1080 of picture (4320p 4x4, 2160p 2x2, up to
+                                       * 1080p-class none: tiles that large cost ~0.2 % bits); 0: off; 1: as -1 but at least 2x2 when the level allows.  Motion
+                                       * compensation, deblocking and SAO cross tile boundaries; merge / AMVP candidates and CABAC contexts do not */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -169,6 +175,8 @@ void mihevc_cost_params_for_qp(int qp, int bit_depth, int me_range, mihevc_cost_
 /* Tile grid of IDR pictures for this configuration: the most columns/rows Table A.8 allows at cfg->level_idc with every
  * column >= 256 and every row >= 64 luma samples (A.4.1), uniform spacing; 1x1 when cfg->intra_tiles == 0. */
 int  mihevc_tile_grid(const mihevc_config *cfg, int *cols, int *rows);
+/* the same for P pictures (cfg->p_tiles): 1x1 when off */
+int  mihevc_p_tile_grid(const mihevc_config *cfg, int *cols, int *rows);
 
 /* per-8x8-block record produced by the analysis kernels and consumed by deblocking and the host entropy coder */
 typedef struct mihevc_cu_rec {

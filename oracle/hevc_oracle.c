@@ -1277,8 +1277,7 @@ static void intra_in_p_pass(const pix *src_y, const pix *src_u, const pix *src_v
                             const orc_params *prm, pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
                             orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, const uint8_t *cand, const uint64_t *jinter)
 {
-    orc_params ip = *prm;
-    ip.tile_cols = ip.tile_rows = 1;               /* P pictures use PPS 0: one tile */
+    orc_params ip = *prm;                          /* prm->tile_cols / tile_rows: the P pictures' own grid (PPS 0; 1x1 unless the session codes P pictures as tiles) */
     intra_ctx c;
     c.src[0] = src_y; c.src[1] = src_u; c.src[2] = src_v;
     c.sstride[0] = src_stride; c.sstride[1] = c.sstride[2] = src_cstride;

@@ -185,7 +185,7 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
         IntraArgs<T> ia;
         for (int i = 0; i < 3; i++) { ia.src[i] = a.src[i]; ia.rec[i] = a.rec[i]; ia.coef[i] = a.coef[i]; }
         ia.w = w; ia.h = h; ia.ctus_w = a.ctus_w; ia.ctus_h = (h + CTU - 1) / CTU;
-        ia.prm = a.prm; ia.prm.tile_cols = ia.prm.tile_rows = 1;
+        ia.prm = a.prm;        // tile_cols / tile_rows: the P pictures' own grid
         ia.cu = cu; ia.diagonal = 0; ia.est = est; ia.sparse_coef = 0; ia.ip = a.ip; ia.plan = nullptr;
         for (int round = 0; round < 2; round++)
             for (int c = 0; c < n_ctu; c++) {

@@ -22,6 +22,7 @@ def encode_pictures(cfg, srcs, qp, bd, me_range=8, keyint=1000, nxn=0, intra_in_
     prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)       # IDR pictures are analysed for the grid PPS 1 signals
     prm_i.intra_nxn = prm_p.intra_nxn = nxn
     prm_p.intra_in_p = intra_in_p
+    prm_p.tile_cols, prm_p.tile_rows = _lib.p_tile_grid(cfg)   # P pictures: PPS 0's own grid (cfg.p_tiles), which the intra second pass must respect
     cus = []
     for i, src in enumerate(srcs):
         intra = i % keyint == 0
@@ -287,3 +288,35 @@ def test_mp4_hvc1_container(tmp_path):
     assert hv[0] == 1 and hv[1] == 1 and hv[12] == 120 and hv[22] == 3     # version, Main, level 4.0, three arrays
     for nal in mp4.split_annexb(headers):
         assert nal in hv
+
+
+@pytest.mark.parametrize("w,h,level,grid,qp,bd,ipass", [(544, 320, 120, (2, 2), 30, 8, 0), (544, 320, 120, (2, 2), 34, 8, 1), (800, 224, 93, (2, 2), 26, 10, 0), (1056, 160, 150, (2, 2), 30, 8, 0)])
+def test_p_picture_tiles_decode_to_the_oracle_reconstruction(w, h, level, grid, qp, bd, ipass):
+    """cfg.p_tiles: P pictures carry a tile grid of their own in PPS 0 (one CABAC substream and one host job per tile).  Merge / AMVP candidates, the
+    skip / split contexts and SAO merge stop at tile borders, motion compensation and the in-loop filters do not; IDR pictures keep PPS 1.  The
+    pieces (encode_tiles per range + assemble_picture) are what the session's host jobs run; here the whole-picture entry point codes them."""
+    cfg = make_cfg(w, h, bd, level_idc=level, p_tiles=1, aud=1)
+    assert _lib.p_tile_grid(cfg) == grid
+    off = make_cfg(w, h, bd, level_idc=level, p_tiles=0, aud=1)
+    assert _lib.p_tile_grid(off) == (1, 1)
+    srcs = [util.synth_frame(h, w, seed=31, shift=(5 * i, 2 * i), bit_depth=bd) for i in range(4)]
+    _, stream, recs, packets = encode_pictures(cfg, srcs, qp, bd, keyint=3, intra_in_p=ipass)
+    frames, info = O.decode(stream)
+    assert len(frames) == 4 and info["count.aud"] == 4
+    for i, (f, r) in enumerate(zip(frames, recs)):
+        assert f.same(r), f"picture {i} differs after decode"
+    if ipass:
+        assert any((~cu["flags"][1:] & 1).any() for cu in encode_pictures.last_cus[1:3]), "no intra CU in a P picture: the case is not exercised"
+    # the same pictures without P tiles: same reconstruction when no intra CU depends on availability, a few more bytes with tiles (contexts restart)
+    _, stream0, recs0, packets0 = encode_pictures(off, srcs, qp, bd, keyint=3, intra_in_p=0)
+    if not ipass:
+        assert all(a.same(b) for a, b in zip(recs, recs0))
+        p_bytes, p_bytes0 = sum(len(p[0]) for p in packets if not p[2]), sum(len(p[0]) for p in packets0 if not p[2])
+        assert p_bytes0 <= p_bytes <= 1.08 * p_bytes0 + 64, (p_bytes, p_bytes0)
+
+
+def test_default_p_tile_grid_is_one_tile_per_1080p_area():
+    for w, h, level, want in [(1920, 1080, 120, (1, 1)), (2560, 1440, 150, (1, 1)), (3840, 2160, 150, (2, 2)), (7680, 4320, 180, (4, 4)), (4096, 2160, 153, (2, 2))]:
+        assert _lib.p_tile_grid(make_cfg(w, h, level_idc=level)) == want, (w, h)
+    sl = make_cfg(7680, 544, 10, level_idc=180, pic_height=4320, slice_count=8, slice_index=0)
+    assert _lib.p_tile_grid(sl) == (1, 1)              # a sliced picture's slices already are one host job each

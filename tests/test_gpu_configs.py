@@ -56,8 +56,7 @@ def session_params(lib, cfg, qp, idr):
     """oracle + device cost parameters of one picture of a session opened with cfg (the knobs the session passes to its kernels)"""
     from hevc_amd import _lib
     cp = _lib.cost_params(qp, cfg.bit_depth, cfg.me_range if cfg.me_range > 0 else 15)
-    if idr:
-        cp.tile_cols, cp.tile_rows = _lib.tile_grid(cfg)
+    cp.tile_cols, cp.tile_rows = _lib.tile_grid(cfg) if idr else _lib.p_tile_grid(cfg)
     cp.intra_nxn, cp.intra_in_p, cp.pre_search, cp.rdo_zero, cp.chroma_modes = cfg.intra_nxn, cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.chroma_modes
     prm = O.Params(cp.qp, cp.qp_c, cp.bit_depth, cp.lambda_sad_q4, cp.lambda_q4, cp.me_range, cp.tile_cols, cp.tile_rows, cp.intra_nxn, cp.intra_in_p,
                    cp.pre_search, cp.rdo_zero, cp.chroma_modes)
