@@ -181,6 +181,9 @@ struct mihevc_session {
     bool is16 = false, keep_recon = false, flushed = false, failed = false, flushing = false;
     std::string err;
     hipStream_t st_compute = nullptr, st_copy = nullptr, st_pre = nullptr;      // st_pre: the chunk's pre-search, beside the IDR step
+    hipStream_t st_up = nullptr;       // uploads of host frames (mihevc_send_frame / _async); the chunk's first launch waits for ev_up
+    hipEvent_t ev_up = nullptr;
+    bool up_pending = false;
     // source pictures of the current chunk (device), in display order
     struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; bool borrowed; };      // borrowed: the caller's device planes, not copied
     size_t plane_bytes[2][3] = {{0}};   // [padded][plane] allocation sizes (for the buffer cache)
@@ -930,6 +933,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
 int run_chunk(mihevc_session *s)
 {
     if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
+    if (s->up_pending) {       // frames still on their way up (mihevc_send_frame_async, device-to-device copies): everything the chunk launches comes behind them
+        HIPCK(s, hipEventRecord(s->ev_up, s->st_up));
+        HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_up, 0));
+        HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_up, 0));
+        s->up_pending = false;
+    }
     return s->is16 ? encode_chunk<uint16_t>(s) : encode_chunk<uint8_t>(s);
 }
 
@@ -981,15 +990,18 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->rc_on = cfg->qp < 0 && cfg->vbv_maxrate_kbps > 0;
     write_parameter_sets(s->cfg, s->headers);
     bool ok = StreamCache::get().acquire(s->device, &s->st_compute) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_copy) == hipSuccess &&
-              StreamCache::get().acquire(s->device, &s->st_pre) == hipSuccess;
+              StreamCache::get().acquire(s->device, &s->st_pre) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_up) == hipSuccess;
     for (int i = 0; ok && i < kRing; i++)
         ok = hipEventCreateWithFlags(&s->ev_compute[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_args, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s->ev_pre, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_args, hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&s->ev_up, hipEventDisableTiming) == hipSuccess;
     if (!ok) {               // give back what was acquired (event handles of the slots never reached stay null)
         for (int i = 0; i < kRing; i++) { if (s->ev_compute[i]) (void)hipEventDestroy(s->ev_compute[i]); if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]); }
         if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
         if (s->ev_args) (void)hipEventDestroy(s->ev_args);
+        if (s->ev_up) (void)hipEventDestroy(s->ev_up);
+        StreamCache::get().release(s->device, s->st_up);
         StreamCache::get().release(s->device, s->st_compute);
         StreamCache::get().release(s->device, s->st_copy);
         StreamCache::get().release(s->device, s->st_pre);
@@ -1003,7 +1015,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     return MIHEVC_OK;
 }
 
-static int ingest(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts, bool device_src)
+static int ingest(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts, bool device_src, bool async)
 {
     if (!s || !y || !u || !v) return MIHEVC_EINVAL;
     if (s->failed) return MIHEVC_EDEVICE;
@@ -1027,22 +1039,21 @@ static int ingest(mihevc_session *s, const void *y, const void *u, const void *v
     }
     if (int e = get_src(s, src)) return e;
     src.pts = pts; src.borrowed = false;
+    // uploads run on a stream of their own; the chunk's first launch waits for the event behind the last one.  The synchronous entry point waits
+    // here (the caller may reuse its buffers on return), the asynchronous one returns with the copies in flight
     for (int i = 0; i < 3; i++) {
         int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h;               // coded plane size
         int sw = i ? s->cfg.width / 2 : s->cfg.width, sh = i ? s->cfg.height / 2 : s->cfg.height, pitch = i ? pitch_c : pitch_y;
         if (pitch < sw) return MIHEVC_EINVAL;
-        if (device_src) {
-            HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, hipMemcpyDeviceToDevice, s->st_compute));
-        } else {
-            HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, hipMemcpyHostToDevice, s->st_compute));
-        }
+        HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st_up));
         // replicate the last column/row into the coded-size margin (the conformance window crops it again)
         if (pw > sw || ph > sh) {
-            if (s->is16) HIPCK(s, launch_extend_margin<uint16_t>(s->st_compute, Plane<uint16_t>{(uint16_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
-            else HIPCK(s, launch_extend_margin<uint8_t>(s->st_compute, Plane<uint8_t>{(uint8_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
+            if (s->is16) HIPCK(s, launch_extend_margin<uint16_t>(s->st_up, Plane<uint16_t>{(uint16_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
+            else HIPCK(s, launch_extend_margin<uint8_t>(s->st_up, Plane<uint8_t>{(uint8_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
         }
     }
-    if (!device_src) HIPCK(s, hipStreamSynchronize(s->st_compute));     // caller's buffers may be reused on return
+    if (!device_src && !async) HIPCK(s, hipStreamSynchronize(s->st_up));     // caller's buffers may be reused on return
+    else s->up_pending = true;
     s->pending.push_back(src);
     s->frames_in++;
     s->stats.frames_in = s->frames_in;
@@ -1052,11 +1063,24 @@ static int ingest(mihevc_session *s, const void *y, const void *u, const void *v
 
 int mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts)
 {
-    return ingest(s, y, u, v, pitch_y, pitch_c, pts, false);
+    return ingest(s, y, u, v, pitch_y, pitch_c, pts, false, false);
+}
+int mihevc_send_frame_async(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts)
+{
+    return ingest(s, y, u, v, pitch_y, pitch_c, pts, false, true);
 }
 int mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, const void *v, int pitch_y, int pitch_c, int64_t pts)
 {
-    return ingest(s, y, u, v, pitch_y, pitch_c, pts, true);
+    return ingest(s, y, u, v, pitch_y, pitch_c, pts, true, false);
+}
+int mihevc_sync_uploads(mihevc_session *s)
+{
+    if (!s) return MIHEVC_EINVAL;
+    if (s->failed) return MIHEVC_EDEVICE;
+    if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
+    HIPCK(s, hipStreamSynchronize(s->st_up));
+    s->up_pending = false;
+    return MIHEVC_OK;
 }
 
 int mihevc_flush(mihevc_session *s)
@@ -1156,6 +1180,7 @@ void mihevc_close(mihevc_session *s)
     if (s->st_compute) (void)hipStreamSynchronize(s->st_compute);
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
     if (s->st_pre) (void)hipStreamSynchronize(s->st_pre);
+    if (s->st_up) (void)hipStreamSynchronize(s->st_up);
     BufferCache &bc = BufferCache::get();
     SymLayout sl(s->w, s->h);
     auto free3 = [&](void *b[3], int padded) { for (int i = 0; i < 3; i++) bc.release(s->device, s->plane_bytes[padded][i], false, b[i]); };
@@ -1173,11 +1198,12 @@ void mihevc_close(mihevc_session *s)
     bc.release(s->device, s->args_cap, true, s->h_args);
     for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(s->ev_pre); (void)hipEventDestroy(s->ev_args);
+    (void)hipEventDestroy(s->ev_pre); (void)hipEventDestroy(s->ev_args); (void)hipEventDestroy(s->ev_up);
     bc.release(s->device, s->low_cap, false, s->d_low);
     StreamCache::get().release(s->device, s->st_compute);       // both idle: synchronised above
     StreamCache::get().release(s->device, s->st_copy);
     StreamCache::get().release(s->device, s->st_pre);
+    StreamCache::get().release(s->device, s->st_up);
     delete s;
 }
 

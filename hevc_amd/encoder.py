@@ -133,6 +133,23 @@ class Encoder:
         self._pts = pts + 1
         self._check(self._lib.mihevc_send_frame(self._s, y.ctypes.data, u.ctypes.data, v.ctypes.data, y.shape[1], u.shape[1], pts), "send_frame")
 
+    def send_async(self, y: np.ndarray, u: np.ndarray, v: np.ndarray, pts: Optional[int] = None):
+        """mihevc_send_frame_async: returns with the upload in flight.  The arrays must already have the session's sample type and be C-contiguous (no
+        copy is made here, that is the point) and must stay alive and unmodified until sync_uploads() or flush(); page-locked memory makes the copies DMA."""
+        c = self.cfg
+        dt = np.uint8 if c.bit_depth == 8 else np.uint16
+        for p in (y, u, v):
+            if p.dtype != dt or not p.flags.c_contiguous:
+                raise ValueError("send_async needs C-contiguous planes of the session's sample type")
+        if y.shape != (c.height, c.width) or u.shape != (c.height // 2, c.width // 2) or v.shape != u.shape:
+            raise ValueError(f"plane shapes {y.shape}/{u.shape}/{v.shape} do not match the session's {c.width}x{c.height} 4:2:0")
+        pts = self._pts if pts is None else pts
+        self._pts = pts + 1
+        self._check(self._lib.mihevc_send_frame_async(self._s, y.ctypes.data, u.ctypes.data, v.ctypes.data, y.shape[1], u.shape[1], pts), "send_frame_async")
+
+    def sync_uploads(self):
+        self._check(self._lib.mihevc_sync_uploads(self._s), "sync_uploads")
+
     def send_device(self, y_ptr: int, u_ptr: int, v_ptr: int, pitch_y: int, pitch_c: int, pts: Optional[int] = None):
         pts = self._pts if pts is None else pts
         self._pts = pts + 1

@@ -131,6 +131,13 @@ int  mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out);
 /* Caller-owned host planes (8-bit: 1 byte/sample, 10-bit: 2 bytes little endian), copied/uploaded before return. */
 int  mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const void *v,
                        int pitch_y, int pitch_c, int64_t pts);
+/* The same without waiting for the upload: the copies are enqueued on the session's upload stream and the call returns.  The caller's planes must stay
+ * valid and unmodified until mihevc_sync_uploads() or mihevc_flush() has returned (a decoder that feeds the session from a ring of N frame buffers calls
+ * mihevc_sync_uploads before it reuses the oldest).  For the copies to run as DMA beside the caller the planes have to be page-locked host memory
+ * (hipHostMalloc / hipHostRegister; torch: pin_memory()); with pageable memory the call is correct but as slow as mihevc_send_frame. */
+int  mihevc_send_frame_async(mihevc_session *s, const void *y, const void *u, const void *v,
+                             int pitch_y, int pitch_c, int64_t pts);
+int  mihevc_sync_uploads(mihevc_session *s);         /* every frame handed over so far has left the caller's buffers */
 /* Frames already resident in device memory (same layout, device pointers): the benchmark path.  Stream ordering contract: the copy
  * into the session's own pitch-aligned picture is ENQUEUED on the session's stream and the call returns before it has run, and it is not
  * ordered against any stream of the caller.  So (1) the producer of y/u/v must have finished before the call (synchronise its stream or
