@@ -24,7 +24,7 @@ class Config(C.Structure):
         [("md_primaries", (C.c_uint16 * 2) * 3), ("md_white", C.c_uint16 * 2), ("md_max_lum", C.c_uint32), ("md_min_lum", C.c_uint32),
          ("max_cll", C.c_uint16), ("max_fall", C.c_uint16)] +
         [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages", "intra_tiles", "intra_nxn", "intra_in_p", "hrd", "pre_search", "rdo_zero", "chroma_modes", "pic_height", "slice_count", "slice_index")] +
-        [("slice_ctu_rows", C.c_int32 * 16), ("rate_share_q16", C.c_int32), ("scenecut", C.c_int32), ("gop_balance", C.c_int32), ("rdo_cg", C.c_int32), ("p_tiles", C.c_int32)])
+        [("slice_ctu_rows", C.c_int32 * 16), ("rate_share_q16", C.c_int32), ("scenecut", C.c_int32), ("gop_balance", C.c_int32), ("rdo_cg", C.c_int32), ("p_tiles", C.c_int32), ("slice_halo", C.c_int32), ("slice_group", C.c_int32)])
 
 
 class Stats(C.Structure):
@@ -43,7 +43,7 @@ class CostParams(C.Structure):
 # every symbol include/mihevc.h declares; tests/test_abi.py checks the header against this list and the .so
 EXPORTS = (
     "mihevc_abi_version", "mihevc_device_count", "mihevc_device_numa_node", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_async", "mihevc_sync_uploads", "mihevc_send_frame_device",
-    "mihevc_receive_packet", "mihevc_flush", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
+    "mihevc_receive_packet", "mihevc_flush", "mihevc_abort", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
     "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_tile_grid", "mihevc_p_tile_grid", "mihevc_k_transform",
     "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_write_parameter_sets",
     "mihevc_encode_picture_host",
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
     lib.mihevc_sync_uploads.argtypes = [vp]
     lib.mihevc_receive_packet.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
     lib.mihevc_flush.argtypes = [vp]
+    lib.mihevc_abort.argtypes = [vp]
     lib.mihevc_close.argtypes = [vp]
     lib.mihevc_close.restype = None
     lib.mihevc_get_stats.argtypes = [vp, C.POINTER(Stats)]

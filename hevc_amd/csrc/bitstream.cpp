@@ -323,7 +323,8 @@ void write_pps(const mihevc_config &cfg, int pps_id, std::vector<uint8_t> &out)
         }
         w.put1(1);                        // loop_filter_across_tiles_enabled_flag
     }
-    w.put1(!sliced(cfg)); // pps_loop_filter_across_slices_enabled_flag: slices of a picture live on different devices and never look at each other
+    w.put1(!sliced(cfg) || cfg.slice_halo != 0); // pps_loop_filter_across_slices_enabled_flag: the slices of a picture live on different devices; they filter across
+                          // their seams only when they exchange rows (cfg.slice_halo)
     w.put1(0);            // deblocking_filter_control_present_flag
     w.put1(0);            // pps_scaling_list_data_present_flag
     w.put1(0);            // lists_modification_present_flag
@@ -1130,7 +1131,7 @@ void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const st
         w.ue(5 - kMaxMergeCand);     // five_minus_max_num_merge_cand
     }
     w.se(pic.qp - 26);               // slice_qp_delta
-    if (!sliced(cfg)) w.put1(1);     // slice_loop_filter_across_slices_enabled_flag (present only when the PPS flag is set)
+    if (!sliced(cfg) || cfg.slice_halo != 0) w.put1(1);     // slice_loop_filter_across_slices_enabled_flag (present only when the PPS flag is set)
     const int n_tiles = grid.cols * grid.rows;
     if (pps_tiles) {
         // entry points (7.4.7.1): substream sizes in bytes of the NAL payload, emulation prevention bytes included.  Every

@@ -52,6 +52,9 @@ template <typename T> hipError_t launch_scene_diff(hipStream_t st, const ScenePi
 
 template <typename T> hipError_t launch_extend_margin(hipStream_t st, Plane<T> p, int sw, int sh, int pw, int ph);
 
+// rows between the slices of one picture (csrc/slice_group.h): jobs[i] for i < n_jobs, one grid row of `blocks_per_job` workgroups each
+hipError_t launch_copy_rows(hipStream_t st, const RowCopy *d_jobs, int n_jobs, int blocks_per_job);
+
 int gfx950_device_count();
 
 }  // namespace mihevc

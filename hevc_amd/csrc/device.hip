@@ -245,11 +245,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_prep_p_step(const
         const SaoArgs<T> &a = prev[g];
         const int ny = pad_border_quads(a.w, a.h, PAD_Y), ncp = pad_border_quads(a.w >> 1, a.h >> 1, PAD_C);
         int i = b * 256 + (int)threadIdx.x;
-        if (i < ny) { pad_border_quad<T>(a.out[0], a.w, a.h, PAD_Y, i); return; }
+        if (i < ny) { pad_border_quad<T>(a.out[0], a.w, a.h, PAD_Y, i, a.halo_top, a.halo_bottom); return; }
         i -= ny;
-        if (i < ncp) { pad_border_quad<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i); return; }
+        if (i < ncp) { pad_border_quad<T>(a.out[1], a.w >> 1, a.h >> 1, PAD_C, i, a.halo_top >> 1, a.halo_bottom >> 1); return; }
         i -= ncp;
-        if (i < ncp) pad_border_quad<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i);
+        if (i < ncp) pad_border_quad<T>(a.out[2], a.w >> 1, a.h >> 1, PAD_C, i, a.halo_top >> 1, a.halo_bottom >> 1);
         return;
     }
     b -= n_pad_blocks;
@@ -390,6 +390,17 @@ template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_
 {
     int n = pad_border_quads(w, h, PAD_Y) + 2 * pad_border_quads(w >> 1, h >> 1, PAD_C);
     hipLaunchKernelGGL(k_pad<T>, dim3((unsigned)((n + 255) / 256), (unsigned)batch), dim3(256), 0, st, d_args);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy_rows(const RowCopy *jobs)
+{
+    copy_rows_item(jobs[blockIdx.y], (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+hipError_t launch_copy_rows(hipStream_t st, const RowCopy *d_jobs, int n_jobs, int blocks_per_job)
+{
+    if (n_jobs <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)blocks_per_job, (unsigned)n_jobs), dim3(256), 0, st, d_jobs);
     return hipGetLastError();
 }
 
@@ -675,7 +686,7 @@ template <typename T> int stage_deblock(void *ry, void *ru, void *rv, int w, int
     DeblockArgs<T> a[2];
     for (int d = 0; d < 2; d++) {
         for (int i = 0; i < 3; i++) a[d].rec[i] = rec.p[i].pl;
-        a[d].w = w; a[d].h = h; a[d].cu = dcu.as<mihevc_cu_rec>(); a[d].bit_depth = bit_depth; a[d].dir = d;
+        a[d].w = w; a[d].h = h; a[d].cu = dcu.as<mihevc_cu_rec>(); a[d].bit_depth = bit_depth; a[d].dir = d; a[d].y_org = 0;
     }
     CK(hipMemcpy(dargs.p, a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_deblock<T>(0, dargs.as<DeblockArgs<T>>(), dargs.as<DeblockArgs<T>>() + 1, w, h, 1));
@@ -696,7 +707,7 @@ int stage_sao(const void *sy, const void *su, const void *sv, const void *dy, co
     CK(dsao.alloc((size_t)n_ctu * sizeof(mihevc_sao_ctu))); CK(dargs.alloc(sizeof(SaoArgs<T>)));
     SaoArgs<T> a;
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.dbk[i] = {dbk.p[i].pl.p, dbk.p[i].pl.stride}; a.out[i] = out.p[i].pl; }
-    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.sao = dsao.as<mihevc_sao_ctu>(); a.sse = nullptr;
+    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.sao = dsao.as<mihevc_sao_ctu>(); a.sse = nullptr; a.halo_top = a.halo_bottom = 0;
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_sao<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1, true));
     CK(launch_pad<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1));

@@ -18,6 +18,8 @@ template <typename T> struct DeblockArgs {
     int w, h;
     const mihevc_cu_rec *cu;
     int bit_depth, dir;          // dir 0: vertical edges, 1: horizontal edges
+    int y_org;                   // rows in front of the picture's own first row that belong to the slice above (csrc/slice_group.h: its last kSeamRows rows, so that the
+                                 // seam is an inner edge); the coding-block and chroma grids count from the picture's own row 0.  0: plain picture
 };
 
 DEV int edge_bs(const mihevc_cu_rec &p, const mihevc_cu_rec &q)      // 8.7.2.4 with CU = PU = TU
@@ -36,7 +38,8 @@ template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_
     const int blk = seg_index >> 1, seg = seg_index & 1, bx = blk % w8, by = blk / w8, x = bx * 8, y = by * 8, dir = a.dir;
     const mihevc_cu_rec q = a.cu[blk];
     const int mask = (1 << q.log2_size) - 1;
-    if (dir == 0 ? (x == 0 || (x & mask)) : (y == 0 || (y & mask))) return;
+    const int yg = y - a.y_org;
+    if (dir == 0 ? (x == 0 || (x & mask)) : (y == 0 || (yg & mask))) return;
     const mihevc_cu_rec p = a.cu[dir == 0 ? blk - 1 : blk - w8];
     const int bs = edge_bs(p, q);
     if (!bs) return;
@@ -78,7 +81,7 @@ template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_
             }
         }
     }
-    if (bs == 2 && ((dir == 0 ? x : y) & 15) == 0) {      // chroma edge on the 8-sample chroma grid (8.7.2.5.5)
+    if (bs == 2 && ((dir == 0 ? x : yg) & 15) == 0) {      // chroma edge on the 8-sample chroma grid (8.7.2.5.5)
         const int tcc = g_tab.tc[clip3(0, 53, chroma_qp_of(qpl) + 2)] * sc;
         for (int ci = 1; ci < 3; ci++) {
             const int s = dir == 0 ? 1 : a.rec[ci].stride, t = dir == 0 ? a.rec[ci].stride : 1;
@@ -103,6 +106,10 @@ template <typename T> struct SaoArgs {
     CostParams prm;
     mihevc_sao_ctu *sao;
     unsigned long long *sse;     // optional: 3 x u64 sum of squared error (source vs out), see k_frame_sse
+    int halo_top, halo_bottom;   // > 0: the picture is one slice (a band of CTU rows) of a picture whose other slices are coded elsewhere and whose filters run
+                                 // ACROSS the seams: that many rows above row 0 / below row h - 1 hold the neighbour slices' samples (dbk: deblocked rows, at
+                                 // least one; out: up to PAD rows of the final reconstruction, copied in before the border pad, which replicates the outermost
+                                 // of them where the whole picture ends earlier); 0: a picture edge
 };
 
 constexpr int SAO_TS_Y = 40, SAO_TS_C = 24;      // tile row strides in samples
@@ -174,6 +181,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
         // before its first LDS store.  Rows and columns outside the picture are read from clamped addresses: the statistics never look at them.
         // (One sample per item with its plane and position taken by division was half of this kernel's VALU work, profiles/r02_b.)
         const int x0 = cx * 32, y0 = cy * 32, wc = a.w >> 1, hc = a.h >> 1;
+        const int ylo = a.halo_top > 0 ? -1 : 0, yup = a.halo_bottom > 0 ? 1 : 0;      // rows -1 / h exist when a neighbour slice lies there
         auto quad_at = [&](int it, int &pl, int &ty, int &q) {       // item -> plane, tile row, quad of the row
             if (it < 34 * 8) { pl = 0; ty = it >> 3; q = it & 7; return; }
             it -= 34 * 8;
@@ -192,7 +200,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
                 int pl, ty, q;
                 quad_at(it, pl, ty, q);
                 const int pw = pl ? wc : a.w, ph = pl ? hc : a.h;
-                const int gx = imin((pl ? x0 >> 1 : x0) + 4 * q, pw - 4), gy = clip3(0, ph - 1, (pl ? y0 >> 1 : y0) + ty - 1);
+                const int gx = imin((pl ? x0 >> 1 : x0) + 4 * q, pw - 4), gy = clip3(ylo, ph - 1 + yup, (pl ? y0 >> 1 : y0) + ty - 1);
                 __builtin_memcpy(qv[k], a.dbk[pl].p + (ptrdiff_t)gy * a.dbk[pl].stride + gx, sizeof qv[k]);
             }
         }
@@ -200,7 +208,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             int pl, ty, side;
             halo_at(tid, pl, ty, side);
             const int pw = pl ? wc : a.w, ph = pl ? hc : a.h, n = pl ? 16 : 32;
-            const int gx = clip3(0, pw - 1, (pl ? x0 >> 1 : x0) + (side ? n : -1)), gy = clip3(0, ph - 1, (pl ? y0 >> 1 : y0) + ty - 1);
+            const int gx = clip3(0, pw - 1, (pl ? x0 >> 1 : x0) + (side ? n : -1)), gy = clip3(ylo, ph - 1 + yup, (pl ? y0 >> 1 : y0) + ty - 1);
             hvl = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
         }
         load_ctu_source<T>((T *)s.src, a.src, x0, y0, a.w, a.h, tid);
@@ -236,7 +244,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             for (int j = 0; j < N + 1; j++) h[j] = sgn3(mid[j + 1] - mid[j]);
             const T *sp = (const T *)s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
             unsigned *pv = s.priv[pl][tid & 15];
-            const bool yin = gy > 0 && gy < ph - 1;
+            const bool yin = (gy > 0 || a.halo_top > 0) && (gy < ph - 1 || a.halo_bottom > 0);
 #pragma unroll
             for (int i = 0; i < N; i++) {
                 const int r = mid[i + 1], d = (int)sp[i] - r;
@@ -341,7 +349,8 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
                 int out = r;
                 if (type == 2) {
                     const int xa = gx + i + kEoDx[cls][0], ya = gy + kEoDy[cls][0], xb = gx + i + kEoDx[cls][1], yb = gy + kEoDy[cls][1];
-                    if (!(xa < 0 || xb < 0 || ya < 0 || yb < 0 || xa >= pw || xb >= pw || ya >= ph || yb >= ph)) {
+                    const int ylo = a.halo_top > 0 ? -1 : 0, yhi = a.halo_bottom > 0 ? ph : ph - 1;
+                    if (!(xa < 0 || xb < 0 || ya < ylo || yb < ylo || xa >= pw || xb >= pw || ya > yhi || yb > yhi)) {
                         const int e = 2 + sgn3(r - tp[ti + 1 + i + kEoDy[cls][0] * ts + kEoDx[cls][0]]) + sgn3(r - tp[ti + 1 + i + kEoDy[cls][1] * ts + kEoDx[cls][1]]);
                         const int k = e == 2 ? 0 : e < 2 ? e + 1 : e;
                         if (k) out = clip3(0, maxv, r + o.offset[pl][k - 1]);
@@ -427,7 +436,9 @@ template <typename T> DEV void pad_border_sample(Plane<T> p, int w, int h, int p
 // the same border in quads of four samples (pad, plane width and row pitch are multiples of 4: a quad is border on one side of the picture or
 // a copy of picture columns, never both): one aligned store per lane instead of four byte stores, a quarter of the index arithmetic
 HDI int pad_border_quads(int w, int h, int pad) { return pad_border_count(w, h, pad) >> 2; }
-template <typename T> DEV void pad_border_quad(Plane<T> p, int w, int h, int pad, int j)
+// top / bottom: that many pad rows above / below hold neighbour slices' samples (columns [0, w)): only their left and right ends are filled in, and
+// rows further out replicate the outermost of them (the whole picture ends there)
+template <typename T> DEV void pad_border_quad(Plane<T> p, int w, int h, int pad, int j, int top = 0, int bottom = 0)
 {
     const int qpr = (w + 2 * pad) >> 2, band = pad * qpr, side = pad >> 2;      // quads per padded row / per band above or below / per side of a picture row
     int x, y;
@@ -439,11 +450,24 @@ template <typename T> DEV void pad_border_quad(Plane<T> p, int w, int h, int pad
         if (r >= h) return;
         y = r; x = c < side ? c * 4 - pad : w + (c - side) * 4;
     }
-    const T *row = p.p + (ptrdiff_t)clip3(0, h - 1, y) * p.stride;
+    const T *row = p.p + (ptrdiff_t)clip3(-top, h - 1 + bottom, y) * p.stride;
     int v[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) v[i] = (int)row[clip3(0, w - 1, x + i)];
     store4(p.p + (ptrdiff_t)y * p.stride + x, v[0], v[1], v[2], v[3]);
+}
+
+// ------------------------------------------------------------------------------------------ rows between the slices of one picture
+// one job = `rows` rows of `row_bytes` bytes (a multiple of 4, 4-byte aligned at both ends) from src to dst; src may live in another device's memory
+// (peer access over xGMI): the halo exchange of csrc/slice_group.h is a handful of these per lane and step
+struct RowCopy { const void *src; void *dst; int row_bytes, rows, src_pitch, dst_pitch; };
+DEV void copy_rows_item(const RowCopy &j, int i, int n_items)
+{
+    const int per = j.row_bytes >> 2, total = per * j.rows;
+    for (int k = i; k < total; k += n_items) {
+        const int r = k / per, c = k % per;
+        ((uint32_t *)((uint8_t *)j.dst + (ptrdiff_t)r * j.dst_pitch))[c] = ((const uint32_t *)((const uint8_t *)j.src + (ptrdiff_t)r * j.src_pitch))[c];
+    }
 }
 
 }  // namespace mihevc

@@ -26,6 +26,7 @@
 
 #include "bitstream.h"
 #include "device.h"
+#include "slice_group.h"
 
 using namespace mihevc;
 
@@ -153,13 +154,15 @@ struct Packet {
 
 // symbol block of one picture: [cu | coef Y | coef U | coef V | sao | sse[3] | rate estimate]
 struct SymLayout {
-    size_t cu, cy, cu_, cv, sao, sse, est, total;
+    size_t cu, cu_bytes, cy, cu_, cv, sao, sse, est, total;
     SymLayout(int w, int h)
     {
         size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h, nctu = (size_t)((w + 31) / 32) * ((h + 31) / 32);
+        const size_t row = (size_t)(w / 8) * sizeof(mihevc_cu_rec);
         auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-        cu = 0;
-        cy = al(cu + n8 * sizeof(mihevc_cu_rec));
+        cu = al(row);                 // one row of records in front of the picture's and one behind: where the neighbour slices' rows go (slice_group.h)
+        cu_bytes = n8 * sizeof(mihevc_cu_rec);
+        cy = al(cu + cu_bytes + row);
         cu_ = al(cy + ny * 2);
         cv = al(cu_ + ny / 2);
         sao = al(cv + ny / 2);
@@ -168,6 +171,8 @@ struct SymLayout {
         total = al(est + sizeof(unsigned long long));
     }
 };
+
+constexpr int kSeamRows = 8;      // rows of the pre-deblock reconstruction exchanged either side of a seam (deblocking reads 4 and writes 3; one 8x8 grid row)
 
 }  // namespace
 
@@ -186,7 +191,7 @@ struct mihevc_session {
     bool up_pending = false;
     // source pictures of the current chunk (device), in display order
     struct Src { void *base[3]; void *p[3]; int stride[3]; int64_t pts; bool borrowed; };      // borrowed: the caller's device planes, not copied
-    size_t plane_bytes[2][3] = {{0}};   // [padded][plane] allocation sizes (for the buffer cache)
+    size_t plane_bytes[3][3] = {{0}};   // [kind: plain / padded reference / work][plane] allocation sizes (for the buffer cache)
     std::vector<Src> pending;
     std::vector<Src> free_src;
     // per lane
@@ -229,9 +234,19 @@ struct mihevc_session {
     void *d_low = nullptr; size_t low_cap = 0;       // per chunk: 1/4-size SOURCE pictures of every picture, then the search centres of every picture (pre-search)
     hipEvent_t ev_pre = nullptr, ev_args = nullptr;  // the chunk's centres are ready (st_pre) / the IDR step's k_intra_plan is through (compute stream: the argument blocks are on the device too)
     void *d_scene = nullptr; size_t scene_cap = 0;   // per chunk: picture pointers / pitches in, difference sums out (k_scene_diff)
-    struct FrameRec { int qp = 0, type = 0; long long bits = -1; unsigned long long est_q4 = 0; bool est_known = false; };
+    struct FrameRec { int qp = 0, type = 0; long long bits = -1, bits_local = -1; unsigned long long est_q4 = 0, est_local = 0; bool est_known = false; };      // with slices that share one rate plan (group): bits / est_q4 are sums over the slices, bits_local this slice's
     std::vector<FrameRec> frames;             // by output index
     std::atomic<long long> entropy_ns{0};
+    // ---- one slice of a picture whose slices exchange rows (cfg.slice_halo; csrc/slice_group.h)
+    std::shared_ptr<SliceGroup> group;
+    int band = 0, n_bands = 1;
+    int band_h[kMaxBands] = {0};              // coded heights of all bands
+    long long gstep = 0, chunk_no = 0;        // steps / chunks since the session was opened: the same in every band of the group
+    hipEvent_t ev_x1[2] = {nullptr, nullptr}, ev_x2[2] = {nullptr, nullptr};
+    void *x1_export[2] = {nullptr, nullptr};
+    size_t x1_part_bytes = 0, x1_lane_bytes = 0, x1_bytes = 0;
+    void *d_jobs = nullptr; uint8_t *h_jobs = nullptr; size_t jobs_cap = 0;
+    std::vector<int> peers_enabled;
 };
 
 namespace {
@@ -242,20 +257,23 @@ namespace {
         if (e_ != hipSuccess) {                                                           \
             (s)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                 \
             (s)->failed = true;                                                           \
+            if ((s)->group) (s)->group->fail();                                           \
             return MIHEVC_EDEVICE;                                                        \
         }                                                                                 \
     } while (0)
 
 size_t esize(const mihevc_session *s) { return s->is16 ? 2 : 1; }
 
-int alloc_planes(mihevc_session *s, void *base[3], void *p[3], int stride[3], bool padded)
+// padded 0: a plain picture; 1: a reference picture with its PAD border all round; 2: a work picture with kSeamRows rows above and below (the rows the
+// neighbour slices hand over for deblocking across seams; unused otherwise)
+int alloc_planes(mihevc_session *s, void *base[3], void *p[3], int stride[3], int padded)
 {
     for (int i = 0; i < 3; i++) {
-        int w = i ? s->w / 2 : s->w, h = i ? s->h / 2 : s->h, pad = padded ? (i ? PAD_C : PAD_Y) : 0;
+        int w = i ? s->w / 2 : s->w, h = i ? s->h / 2 : s->h, pad = padded == 1 ? (i ? PAD_C : PAD_Y) : 0, vm = padded == 2 ? (i ? kSeamRows / 2 : kSeamRows) : pad;
         stride[i] = (w + 2 * pad + 63) & ~63;
-        s->plane_bytes[padded][i] = (size_t)stride[i] * (h + 2 * pad) * esize(s);
+        s->plane_bytes[padded][i] = (size_t)stride[i] * (h + 2 * vm) * esize(s);
         HIPCK(s, BufferCache::get().alloc(s->device, s->plane_bytes[padded][i], false, &base[i]));
-        p[i] = (uint8_t *)base[i] + ((size_t)pad * stride[i] + pad) * esize(s);
+        p[i] = (uint8_t *)base[i] + ((size_t)vm * stride[i] + pad) * esize(s);
     }
     return 0;
 }
@@ -263,7 +281,7 @@ int alloc_planes(mihevc_session *s, void *base[3], void *p[3], int stride[3], bo
 int get_src(mihevc_session *s, mihevc_session::Src &out)
 {
     if (!s->free_src.empty()) { out = s->free_src.back(); s->free_src.pop_back(); return 0; }
-    return alloc_planes(s, out.base, out.p, out.stride, false);
+    return alloc_planes(s, out.base, out.p, out.stride, 0);
 }
 
 int ensure_lanes(mihevc_session *s, int n)
@@ -273,8 +291,8 @@ int ensure_lanes(mihevc_session *s, int n)
         mihevc_session::Lane L;
         memset(&L, 0, sizeof L);
         for (int k = 0; k < 2; k++)
-            if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, true)) return e;
-        if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, false)) return e;
+            if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, 1)) return e;
+        if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, 2)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, (void **)&L.plan));
@@ -370,9 +388,13 @@ void publish_picture(PictureJob *j)
         s->stats.bytes_out += (int64_t)pk.data.size();
         if ((size_t)index < s->frames.size()) {
             auto &fr = s->frames[(size_t)index];
-            fr.bits = (long long)pk.data.size() * 8;
-            fr.est_q4 = *(const unsigned long long *)(b + sl.est);
-            fr.est_known = true;
+            fr.bits_local = (long long)pk.data.size() * 8;
+            fr.est_local = *(const unsigned long long *)(b + sl.est);
+            if (!s->group) {          // (slices with one rate plan: the step loop sums sizes and estimates over the slices at fixed points)
+                fr.bits = fr.bits_local;
+                fr.est_q4 = *(const unsigned long long *)(b + sl.est);
+                fr.est_known = true;
+            }
         }
         s->packets[index] = std::move(pk);
         s->frames_done++;
@@ -411,6 +433,44 @@ template <typename T> int scene_differences(mihevc_session *s, int n, std::vecto
     HIPCK(s, launch_scene_diff<T>(s->st_compute, (const ScenePic<T> *)s->d_scene, d_out, s->w, s->h, n));
     HIPCK(s, hipMemcpyAsync(out.data(), d_out, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost, s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_compute));
+    return 0;
+}
+
+// ---- the slices of one picture exchange rows (cfg.slice_halo; csrc/slice_group.h) ------------------------------------------------------------
+// job tables of one step: [export: lanes x 8][import: lanes x 8][pull: lanes x 3 x reach], RowCopy each
+struct JobLayout {
+    int lanes, reach;
+    size_t exp, imp, pull, total;
+    JobLayout(int lanes_, int reach_) : lanes(lanes_), reach(reach_)
+    {
+        exp = 0; imp = exp + (size_t)lanes * 8 * sizeof(RowCopy); pull = imp + (size_t)lanes * 8 * sizeof(RowCopy);
+        total = (pull + (size_t)lanes * 3 * (size_t)std::max(1, reach) * sizeof(RowCopy) + 255) & ~(size_t)255;
+    }
+};
+
+// bands whose rows lie within PAD_Y rows above (dir -1) / below (dir +1) this band, nearest first, with the rows each contributes
+static void bands_in_reach(const mihevc_session *s, int dir, std::vector<std::pair<int, int>> &out)
+{
+    int left = PAD_Y;
+    for (int b = s->band + dir; b >= 0 && b < s->n_bands && left > 0; b += dir) {
+        const int rows = std::min(left, s->band_h[b]);
+        out.push_back({b, rows});
+        left -= rows;
+    }
+}
+static int rows_in_reach(const mihevc_session *s, int dir)
+{
+    std::vector<std::pair<int, int>> v;
+    bands_in_reach(s, dir, v);
+    int n = 0;
+    for (auto &x : v) n += x.second;
+    return n;
+}
+
+static int group_sum(mihevc_session *s, std::vector<double> &v)
+{
+    if (!s->group) return 0;
+    if (!s->group->allreduce(v)) { s->failed = true; s->err = "another slice of the picture failed"; return MIHEVC_EDEVICE; }
     return 0;
 }
 
@@ -483,6 +543,48 @@ template <typename T> int encode_chunk(mihevc_session *s)
     if (int e = ensure_lanes(s, gops)) return e;
     SymLayout sl(s->w, s->h);
     const int steps = glen[0];
+    // ---- slices that exchange rows: what the neighbours need to know about this band's buffers, then everybody's (csrc/slice_group.h)
+    const bool grp = (bool)s->group;
+    const int up = grp && s->band > 0 ? 1 : 0, dn = grp && s->band + 1 < s->n_bands ? 1 : 0;
+    std::vector<std::pair<int, int>> reach_up, reach_dn;
+    if (grp) { bands_in_reach(s, -1, reach_up); bands_in_reach(s, +1, reach_dn); }
+    const int halo_top = grp ? rows_in_reach(s, -1) : 0, halo_bottom = grp ? rows_in_reach(s, +1) : 0;
+    const int reach = (int)(reach_up.size() + reach_dn.size());
+    const JobLayout jl(gops, reach);
+    uint8_t *hj = nullptr, *dj = nullptr;
+    if (grp) {
+        if (gops > kHaloLanes) { s->err = "too many GOP lanes for sliced pictures"; return MIHEVC_EINVAL; }
+        BandPub &me = s->group->pub(s->band);
+        me.device = s->device; me.w = s->w; me.h = s->h; me.is16 = s->is16;
+        for (int g = 0; g < gops; g++)
+            for (int k = 0; k < 2; k++)
+                for (int i = 0; i < 3; i++) me.rec_p[g][k][i] = s->lane[g].rec_p[k][i];
+        for (int i = 0; i < 3; i++) me.rec_stride[i] = s->lane[0].rec_stride[i];
+        for (int k = 0; k < 2; k++) { me.x1_export[k] = s->x1_export[k]; me.ev_x1[k] = s->ev_x1[k]; me.ev_x2[k] = s->ev_x2[k]; }
+        me.x1_lane_bytes = s->x1_lane_bytes;
+        if (!s->group->barrier()) { s->failed = true; s->err = "another slice of the picture failed"; return MIHEVC_EDEVICE; }
+        for (auto &v : {reach_up, reach_dn})
+            for (auto &br : v) {
+                const int dev = s->group->pub(br.first).device;
+                if (dev == s->device || std::find(s->peers_enabled.begin(), s->peers_enabled.end(), dev) != s->peers_enabled.end()) continue;
+                hipError_t e = hipDeviceEnablePeerAccess(dev, 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); s->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); s->failed = true; s->group->fail(); return MIHEVC_EDEVICE; }
+                (void)hipGetLastError();
+                s->peers_enabled.push_back(dev);
+            }
+        const size_t jneed = (size_t)steps * jl.total;
+        if (jneed > s->jobs_cap) {
+            BufferCache &bc = BufferCache::get();
+            bc.release(s->device, s->jobs_cap, false, s->d_jobs); bc.release(s->device, s->jobs_cap, true, s->h_jobs);
+            s->d_jobs = nullptr; s->h_jobs = nullptr; s->jobs_cap = 0;
+            const size_t cap = (jneed + 0xffff) & ~(size_t)0xffff;
+            HIPCK(s, bc.alloc(s->device, cap, false, &s->d_jobs));
+            HIPCK(s, bc.alloc(s->device, cap, true, (void **)&s->h_jobs));
+            s->jobs_cap = cap;
+        }
+        hj = s->h_jobs; dj = (uint8_t *)s->d_jobs;
+        memset(hj, 0, jneed);
+    }
     const int ring = s->ring;
     auto slot_of = [ring](int t) { return t == 0 ? 0 : 1 + (t - 1) % (ring - 1); };
     // ---- build every step's argument blocks, upload once ----
@@ -506,6 +608,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (want > s->low_cap) {
             BufferCache &bc = BufferCache::get();
             bc.release(s->device, s->low_cap, false, s->d_low);
+    bc.release(s->device, s->jobs_cap, false, s->d_jobs); bc.release(s->device, s->jobs_cap, true, s->h_jobs);
+    for (int k = 0; k < 2; k++) {
+        bc.release(s->device, s->x1_bytes, false, s->x1_export[k]);
+        if (s->ev_x1[k]) (void)hipEventDestroy(s->ev_x1[k]);
+        if (s->ev_x2[k]) (void)hipEventDestroy(s->ev_x2[k]);
+    }
             s->d_low = nullptr; s->low_cap = 0;
             const size_t cap = (want + 0xfffff) & ~(size_t)0xfffff;
             HIPCK(s, bc.alloc(s->device, cap, false, &s->d_low));
@@ -518,7 +626,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         mihevc_cost_params c;
         mihevc_cost_params_for_qp(qp, s->cfg.bit_depth, s->me_range, &c);
         return CostParams{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, s->tiles.cols, s->tiles.rows, s->cfg.intra_nxn != 0, s->cfg.intra_in_p != 0, s->cfg.pre_search != 0, s->cfg.rdo_zero != 0, s->cfg.chroma_modes != 0,
-                          s->cfg.slice_count > 1 && s->cfg.slice_index > 0, s->cfg.slice_count > 1 && s->cfg.slice_index < s->cfg.slice_count - 1, std::max(0, s->cfg.rdo_cg)};
+                          s->cfg.slice_count > 1 && !s->cfg.slice_halo && s->cfg.slice_index > 0, s->cfg.slice_count > 1 && !s->cfg.slice_halo && s->cfg.slice_index < s->cfg.slice_count - 1, std::max(0, s->cfg.rdo_cg)};
     };
     const int64_t first_index = s->frames_in - n;
     {
@@ -553,6 +661,62 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.prm = A.inter.prm = A.sao.prm = P;
             A.intra.cu = A.inter.cu = (mihevc_cu_rec *)(sym + sl.cu);
             A.dbk_v.cu = A.dbk_h.cu = (const mihevc_cu_rec *)(sym + sl.cu);
+            A.sao.halo_top = halo_top; A.sao.halo_bottom = halo_bottom;
+            if (grp) {
+                // deblocking runs over the band EXTENDED by the rows the neighbours hand over (kSeamRows of their pre-deblock reconstruction + one row of CU
+                // records either side): the seams are inner edges of that picture
+                const int w8 = s->w >> 3;
+                for (int i = 0; i < 3; i++) {
+                    const int tr = up ? (i ? kSeamRows / 2 : kSeamRows) : 0;
+                    A.dbk_v.rec[i] = A.dbk_h.rec[i] = mk<T>((T *)L.work_p[i] - (ptrdiff_t)tr * L.work_stride[i], L.work_stride[i]);
+                }
+                A.dbk_v.h = A.dbk_h.h = s->h + kSeamRows * (up + dn);
+                A.dbk_v.cu = A.dbk_h.cu = (const mihevc_cu_rec *)(sym + sl.cu) - (up ? w8 : 0);
+                // the step's row copies
+                const long long G = s->gstep + t;
+                const size_t es = sizeof(T), part = s->x1_part_bytes;
+                RowCopy *je = (RowCopy *)(hj + (size_t)t * jl.total + jl.exp) + (size_t)g * 8, *ji = (RowCopy *)(hj + (size_t)t * jl.total + jl.imp) + (size_t)g * 8;
+                RowCopy *jp = (RowCopy *)(hj + (size_t)t * jl.total + jl.pull) + (size_t)g * 3 * std::max(1, reach);
+                uint8_t *xe = (uint8_t *)s->x1_export[G & 1] + (size_t)g * s->x1_lane_bytes;
+                const size_t off_pl[3] = {0, (size_t)kSeamRows * s->w * es, (size_t)kSeamRows * s->w * es + (size_t)(kSeamRows / 2) * (s->w / 2) * es};
+                const size_t off_cu = off_pl[2] + (size_t)(kSeamRows / 2) * (s->w / 2) * es;
+                mihevc_cu_rec *cu0 = (mihevc_cu_rec *)(sym + sl.cu);
+                for (int side = 0; side < 2; side++) {          // export: this band's first / last rows -> [top part | bottom part]
+                    for (int i = 0; i < 3; i++) {
+                        const int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h, rows = i ? kSeamRows / 2 : kSeamRows;
+                        je[side * 4 + i] = RowCopy{(const uint8_t *)L.work_p[i] + (size_t)(side ? ph - rows : 0) * L.work_stride[i] * es, xe + side * part + off_pl[i], (int)(pw * es), rows,
+                                                   (int)(L.work_stride[i] * es), (int)(pw * es)};
+                    }
+                    je[side * 4 + 3] = RowCopy{cu0 + (size_t)(side ? (s->h >> 3) - 1 : 0) * w8, xe + side * part + off_cu, (int)(w8 * sizeof(mihevc_cu_rec)), 1, 0, 0};
+                }
+                for (int side = 0; side < 2; side++) {          // import: the upper neighbour's bottom part -> the rows above this band; the lower neighbour's top part -> below
+                    if (!(side ? dn : up)) continue;
+                    const BandPub &nb = s->group->pub(s->band + (side ? 1 : -1));
+                    const uint8_t *xs = (const uint8_t *)nb.x1_export[G & 1] + (size_t)g * nb.x1_lane_bytes + (side ? 0 : part);
+                    for (int i = 0; i < 3; i++) {
+                        const int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h, rows = i ? kSeamRows / 2 : kSeamRows;
+                        ji[side * 4 + i] = RowCopy{xs + off_pl[i], (uint8_t *)L.work_p[i] + ((ptrdiff_t)(side ? ph : -rows) * L.work_stride[i]) * (ptrdiff_t)es, (int)(pw * es), rows,
+                                                   (int)(pw * es), (int)(L.work_stride[i] * es)};
+                    }
+                    ji[side * 4 + 3] = RowCopy{xs + off_cu, side ? cu0 + (size_t)(s->h >> 3) * w8 : cu0 - w8, (int)(w8 * sizeof(mihevc_cu_rec)), 1, 0, 0};
+                }
+                if (t > 0) {                                    // pull: the final reconstruction either side of the seams -> the border rows of this band's reference
+                    int k = 0;
+                    for (int side = 0; side < 2; side++) {
+                        int done = 0;
+                        for (auto &br : side ? reach_dn : reach_up) {
+                            const BandPub &nb = s->group->pub(br.first);
+                            for (int i = 0; i < 3; i++) {
+                                const int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h, nh = i ? nb.h / 2 : nb.h, rows = i ? br.second / 2 : br.second, dn_ = i ? done / 2 : done;
+                                const uint8_t *src = (const uint8_t *)nb.rec_p[g][prev][i] + (size_t)(side ? 0 : nh - rows) * nb.rec_stride[i] * es;
+                                uint8_t *dst = (uint8_t *)L.rec_p[prev][i] + ((ptrdiff_t)(side ? ph + dn_ : -(dn_ + rows)) * L.rec_stride[i]) * (ptrdiff_t)es;
+                                jp[k++] = RowCopy{src, dst, (int)(pw * es), rows, (int)(nb.rec_stride[i] * es), (int)(L.rec_stride[i] * es)};
+                            }
+                            done += br.second;
+                        }
+                    }
+                }
+            }
             // levels go straight to the pinned host block (device-mapped): only TUs with a non-zero level are stored, so the
             // 6 MB/picture coefficient planes never cross PCIe as a blit (profiles/r01: copyBuffer was 17 % of GPU time)
             uint8_t *symh = L.sym_host[slot_of(t)];
@@ -577,11 +741,13 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.plan = t == 0 ? L.plan : nullptr;      // P pictures' second pass plans and codes a CTU inside one workgroup
             if (t > 0) { A.intra.prm.tile_cols = s->ptiles.cols; A.intra.prm.tile_rows = s->ptiles.rows; }
             A.dbk_v.bit_depth = A.dbk_h.bit_depth = s->cfg.bit_depth; A.dbk_v.dir = 0; A.dbk_h.dir = 1;
+            A.dbk_v.y_org = A.dbk_h.y_org = up ? kSeamRows : 0;
             A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
             A.sao.sse = (unsigned long long *)(sym + sl.sse);
             A.intra.est = A.inter.est = (unsigned long long *)(sym + sl.est);
         }
     HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
+    if (grp) HIPCK(s, hipMemcpyAsync(dj, hj, (size_t)steps * jl.total, hipMemcpyHostToDevice, s->st_compute));
     // cfg.pre_search: the search centres of EVERY picture of the chunk come from the 1/4-size SOURCE pictures (this picture against the one before it: nothing
     // in it waits for a reconstruction), in two launches on a stream of their own in the IDR step below: the work (7 % of a clip's device time when it ran
     // inside every step) sits beside the anti-diagonal chain, which leaves most of the device idle.  The first P step waits for ev_pre.
@@ -593,7 +759,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
     // level at the next IDR is at least the assumed one again (tests replay the produced sizes through the Annex C arrival / removal schedule).
     const double fps = (double)s->cfg.fps_num / s->cfg.fps_den;
     // a slice of a picture (one device of several) plans with its share of the picture's rate and buffer
-    const double share = (s->cfg.slice_count > 1 && s->cfg.rate_share_q16 > 0) ? s->cfg.rate_share_q16 / 65536.0 : 1.0;
+    // (slices that share one rate plan — cfg.slice_halo — plan the whole picture's rate from inputs summed over the slices)
+    const double share = grp ? 1.0 : (s->cfg.slice_count > 1 && s->cfg.rate_share_q16 > 0) ? s->cfg.rate_share_q16 / 65536.0 : 1.0;
     std::vector<int> qp_prev(gops, s->qp_p), gop_len(gops, 0);
     std::vector<double> budget(gops, 0.0);
     for (int g = 0; g < gops; g++) {
@@ -678,17 +845,32 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         StepView<T> dv(da, lay, t), hv(ha, lay, t);
         std::vector<int> qp_step(B), lane_slot(B, slot0);
+        if (grp && s->rc_on && t - p_slots >= 1) {
+            // the pictures of step t - p_slots have left the CABAC jobs of EVERY slice once all slices are here: their sizes summed over the slices
+            const int j = t - p_slots;
+            std::vector<double> v((size_t)batch[j]);
+            {
+                std::lock_guard<std::mutex> l(s->m);
+                for (int g = 0; g < batch[j]; g++) v[(size_t)g] = (double)s->frames[(size_t)(first_index + gstart[(size_t)g] + j)].bits_local;
+            }
+            if (int e = group_sum(s, v)) return e;
+            std::lock_guard<std::mutex> l(s->m);
+            for (int g = 0; g < batch[j]; g++) s->frames[(size_t)(first_index + gstart[(size_t)g] + j)].bits = (long long)v[(size_t)g];
+        }
         if (t >= 2) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_copy[slot_of(t - 2)], 0));      // the SSE pass of step t - 2 still reads the picture buffer this step reuses
         if (s->rc_on && t >= 3) {
             // rate feedback with a fixed lag of two steps: wait for the symbol copy of step t-2 (step t-1 is already queued behind
             // it, so the device never idles) and take its estimates.  A fixed lag makes the QP sequence reproducible.
             const int j = t - 2;
             HIPCK(s, hipEventSynchronize(s->ev_copy[slot_of(j)]));
+            std::vector<double> v((size_t)batch[j]);
+            for (int g = 0; g < batch[j]; g++) v[(size_t)g] = (double)*(const unsigned long long *)(s->lane[g].sym_host[slot_of(j)] + sl.est);
+            if (int e = group_sum(s, v)) return e;          // slices with one rate plan: the picture's estimate is the sum over its slices
             {
                 std::lock_guard<std::mutex> l(s->m);
                 for (int g = 0; g < batch[j]; g++) {
                     auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + j)];
-                    if (!fr.est_known) { fr.est_q4 = *(const unsigned long long *)(s->lane[g].sym_host[slot_of(j)] + sl.est); fr.est_known = true; }
+                    if (!fr.est_known) { fr.est_q4 = (unsigned long long)v[(size_t)g]; fr.est_known = true; }
                 }
             }
         }
@@ -717,6 +899,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 std::vector<unsigned long long> ev((size_t)B);
                 std::vector<int> qa(qp_step);                       // QP each lane's current analysis was made at
                 for (int g = 0; g < B; g++) HIPCK(s, hipMemcpy(&ev[(size_t)g], s->lane[g].sym_dev[0] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (grp) {
+                    std::vector<double> v(ev.begin(), ev.end());
+                    if (int e = group_sum(s, v)) return e;
+                    for (int g = 0; g < B; g++) ev[(size_t)g] = (unsigned long long)v[(size_t)g];
+                }
                 auto want_for = [&](int g, double rho) {
                     const double ib_a = std::max(1.0, (double)ev[(size_t)g] / 16.0 * s->ratio_i);
                     int pick = 51;
@@ -750,6 +937,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         qp_trial[(size_t)g] = std::min(51, want[(size_t)g] + 3);
                         tv.sao[g] = hv.sao[g];
                         tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr;
+                        tv.sao[g].halo_top = tv.sao[g].halo_bottom = 0;      // the trial predicts from this band's own unfiltered picture with a replicated border
                         tv.inter[g] = h1.inter[g];
                         for (int i = 0; i < 3; i++) tv.inter[g].rec[i] = mk<T>(L.rec_p[1][i], L.rec_stride[i]);
                         tv.inter[g].prm = prm_for(qp_trial[(size_t)g]);
@@ -765,9 +953,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     HIPCK(s, hipStreamSynchronize(s->st_compute));
                     double lg = 0;
                     int nl = 0;
+                    std::vector<double> epv((size_t)B1, 0.0);
                     for (int g = 0; g < B1; g++) {
                         unsigned long long ep = 0;
                         HIPCK(s, hipMemcpy(&ep, s->lane[g].sym_dev[slot_of(1)] + sl.est, sizeof ep, hipMemcpyDeviceToHost));
+                        epv[(size_t)g] = (double)ep;
+                    }
+                    if (int e = group_sum(s, epv)) return e;
+                    for (int g = 0; g < B1; g++) {
+                        const unsigned long long ep = (unsigned long long)epv[(size_t)g];
                         if (!ep || !ev[(size_t)g]) continue;
                         // both estimates brought to one QP: the P picture from its trial QP, the IDR picture from the QP it was analysed at
                         lg += std::log2((double)ep / (double)ev[(size_t)g]) + (qp_trial[(size_t)g] - qa[(size_t)g]) / 6.0;
@@ -793,7 +987,14 @@ template <typename T> int encode_chunk(mihevc_session *s)
                     HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
                     STAGE(0, (int)redo.size(), launch_intra_picture<T>(s->st_compute, dv.intra + B, s->ctus_w, s->ctus_h, (int)redo.size(), s->tiles.cols, s->tiles.rows, nullptr));
                     HIPCK(s, hipStreamSynchronize(s->st_compute));
-                    for (int g : redo) HIPCK(s, hipMemcpy(&ev[(size_t)g], s->lane[g].sym_dev[0] + sl.est, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                    std::vector<double> v(redo.size(), 0.0);
+                    for (size_t k = 0; k < redo.size(); k++) {
+                        unsigned long long e2 = 0;
+                        HIPCK(s, hipMemcpy(&e2, s->lane[redo[k]].sym_dev[0] + sl.est, sizeof e2, hipMemcpyDeviceToHost));
+                        v[k] = (double)e2;
+                    }
+                    if (int e = group_sum(s, v)) return e;
+                    for (size_t k = 0; k < redo.size(); k++) ev[(size_t)redo[k]] = (unsigned long long)v[k];
                 }
                 int sum_q = 0;
                 for (int g = 0; g < B; g++) {
@@ -814,6 +1015,17 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 sp.p_tile_cols = s->ptiles.cols; sp.p_tile_rows = s->ptiles.rows;
                 for (int g = 0; g < B; g++) sp.prm[g] = hv.inter[g].prm;
                 StepView<T> pv(da, lay, t - 1);
+                if (grp && reach > 0) {
+                    // X2: the final reconstruction either side of the seams, straight out of the neighbours' pictures of the previous step, into the border
+                    // rows of this band's reference pictures (the pad below fills in their left / right ends and whatever lies beyond the whole picture)
+                    const long long G = s->gstep + t;
+                    for (auto *v : {&reach_up, &reach_dn})
+                        for (auto &br : *v) {
+                            if (!s->group->wait_for(br.first, 2, G - 1)) { s->failed = true; s->err = "another slice of the picture failed"; return MIHEVC_EDEVICE; }
+                            HIPCK(s, hipStreamWaitEvent(s->st_compute, s->group->pub(br.first).ev_x2[(G - 1) & 1], 0));
+                        }
+                    HIPCK(s, launch_copy_rows(s->st_compute, (const RowCopy *)(dj + (size_t)t * jl.total + jl.pull), B * 3 * reach, 16));
+                }
                 HIPCK(s, launch_prep_p_step<T>(s->st_compute, pv.sao, (const PreArgs<T> *)nullptr, dv.intra, dv.inter, dv.sao, sp, s->w, s->h, B));
                 if (t == 1 && s->cfg.pre_search) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_pre, 0));      // the chunk's search centres (st_pre, under the IDR step)
             }
@@ -824,8 +1036,27 @@ template <typename T> int encode_chunk(mihevc_session *s)
             STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
             if (s->cfg.intra_in_p) STAGE(7, B, launch_intra_p<T>(s->st_compute, dv.intra, s->n_ctu, B));
         }
-        STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h, B));
+        if (grp) {
+            // X1: kSeamRows rows of the pre-deblock reconstruction + one row of CU records either side of every seam.  Every band puts its own first and last
+            // rows where its neighbours can read them (the band's picture is deblocked in place right after), then takes the neighbours'
+            const long long G = s->gstep + t;
+            HIPCK(s, launch_copy_rows(s->st_compute, (const RowCopy *)(dj + (size_t)t * jl.total + jl.exp), B * 8, 8));
+            HIPCK(s, hipEventRecord(s->ev_x1[G & 1], s->st_compute));
+            s->group->announce(s->band, 1, G);
+            for (auto *v : {&reach_up, &reach_dn})
+                for (auto &br : *v) {
+                    if (!s->group->wait_for(br.first, 1, G)) { s->failed = true; s->err = "another slice of the picture failed"; return MIHEVC_EDEVICE; }
+                    HIPCK(s, hipStreamWaitEvent(s->st_compute, s->group->pub(br.first).ev_x1[G & 1], 0));
+                }
+            if (up + dn) HIPCK(s, launch_copy_rows(s->st_compute, (const RowCopy *)(dj + (size_t)t * jl.total + jl.imp), B * 8, 8));
+        }
+        STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h + (grp ? kSeamRows * (up + dn) : 0), B));
         STAGE(4, B, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
+        if (grp) {
+            const long long G = s->gstep + t;
+            HIPCK(s, hipEventRecord(s->ev_x2[G & 1], s->st_compute));
+            s->group->announce(s->band, 2, G);
+        }
         HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));      // (the border pad of these pictures is part of the next step's first launch)
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot0], 0));
         // the SSE pass (statistics only) runs on the copy stream, in front of the symbol copies that carry its sums: 14 us per step off the
@@ -835,7 +1066,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         for (int g = 0; g < B; g++)
         {   // CU records, then SAO parameters + SSE + rate estimate (the level planes were written to the host block directly)
             uint8_t *hd = s->lane[g].sym_host[lane_slot[g]], *dd = s->lane[g].sym_dev[lane_slot[g]];
-            HIPCK(s, hipMemcpyAsync(hd, dd, sl.cy, hipMemcpyDeviceToHost, s->st_copy));
+            HIPCK(s, hipMemcpyAsync(hd + sl.cu, dd + sl.cu, sl.cu_bytes, hipMemcpyDeviceToHost, s->st_copy));
             HIPCK(s, hipMemcpyAsync(hd + sl.sao, dd + sl.sao, sl.total - sl.sao, hipMemcpyDeviceToHost, s->st_copy));
         }
         if (s->keep_recon) {
@@ -902,6 +1133,20 @@ template <typename T> int encode_chunk(mihevc_session *s)
     {   // all CABAC jobs of the chunk
         std::unique_lock<std::mutex> l(s->m);
         s->cv.wait(l, [&] { int n = 0; for (int k = 0; k < kRing; k++) n += s->jobs_open[k]; return n == 0; });
+    }
+    s->gstep += steps;
+    s->chunk_no++;
+    if (grp && s->rc_on) {        // the sizes of every picture of the chunk, summed over the slices (estimates were summed step by step)
+        std::vector<double> v((size_t)2 * n);
+        {
+            std::lock_guard<std::mutex> l(s->m);
+            for (int i = 0; i < n; i++) { const auto &fr = s->frames[(size_t)(first_index + i)]; v[(size_t)i] = (double)fr.bits_local; v[(size_t)(n + i)] = (double)fr.est_local; }
+        }
+        if (int e = group_sum(s, v)) return e;
+        std::lock_guard<std::mutex> l(s->m);
+        for (int i = 0; i < n; i++) { auto &fr = s->frames[(size_t)(first_index + i)]; fr.bits = (long long)v[(size_t)i]; fr.est_q4 = (unsigned long long)v[(size_t)(n + i)]; fr.est_known = true; }
+    } else if (grp) {
+        if (!s->group->barrier()) { s->failed = true; return MIHEVC_EDEVICE; }      // no band leaves a chunk (and reuses its buffers) while another still reads them
     }
     if (s->rc_on) {
         // learn from the finished chunk (all CABAC sizes are known now, so this is deterministic): CABAC bits per estimated
@@ -1008,6 +1253,24 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
         delete s;
         return MIHEVC_EDEVICE;
     }
+    if (cfg->slice_count > 1 && cfg->slice_halo) {
+        // one slice of a picture whose slices exchange rows: meet the others (csrc/slice_group.h), and get the buffers the neighbours read
+        s->n_bands = cfg->slice_count; s->band = cfg->slice_index;
+        for (int k = 0, y0 = 0; k < cfg->slice_count; k++) {
+            const int y1 = std::min(cfg->pic_height, y0 + 32 * cfg->slice_ctu_rows[k]);
+            s->band_h[k] = coded_size(cfg->width, y1 - y0).h;
+            y0 = y1;
+        }
+        const size_t es = s->is16 ? 2 : 1;
+        s->x1_part_bytes = (((size_t)kSeamRows * s->w + (size_t)kSeamRows * (s->w / 2)) * es + (size_t)(s->w >> 3) * sizeof(mihevc_cu_rec) + 255) & ~(size_t)255;
+        s->x1_lane_bytes = 2 * s->x1_part_bytes;
+        s->x1_bytes = s->x1_lane_bytes * kHaloLanes;
+        for (int k = 0; ok && k < 2; k++)
+            ok = BufferCache::get().alloc(s->device, s->x1_bytes, false, &s->x1_export[k]) == hipSuccess &&
+                 hipEventCreateWithFlags(&s->ev_x1[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s->ev_x2[k], hipEventDisableTiming) == hipSuccess;
+        if (!ok || cfg->slice_group == 0) { mihevc_close(s); return cfg->slice_group == 0 ? MIHEVC_EINVAL : MIHEVC_EDEVICE; }
+        s->group = SliceGroup::join(cfg->slice_group, cfg->slice_count);
+    }
     int threads = cfg->host_threads > 0 ? cfg->host_threads : (int)std::min(16u, std::max(2u, std::thread::hardware_concurrency()));
     s->pool = &ThreadPool::shared(threads);
     s->host_threads = threads;
@@ -1092,6 +1355,15 @@ int mihevc_flush(mihevc_session *s)
     int e = run_chunk(s);
     s->flushed = true;
     return e;
+}
+
+int mihevc_abort(mihevc_session *s)
+{
+    if (!s) return MIHEVC_EINVAL;
+    s->failed = true;
+    if (s->err.empty()) s->err = "aborted by the caller";
+    if (s->group) s->group->fail();
+    return MIHEVC_OK;
 }
 
 int mihevc_receive_packet(mihevc_session *s, const uint8_t **data, size_t *size, int64_t *pts, int64_t *dts, int *keyframe)
@@ -1187,7 +1459,7 @@ void mihevc_close(mihevc_session *s)
     for (auto &x : s->pending) if (!x.borrowed) free3(x.base, 0);
     for (auto &x : s->free_src) free3(x.base, 0);
     for (auto &L : s->lane) {
-        free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 0);
+        free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 2);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, L.plan);
@@ -1196,10 +1468,18 @@ void mihevc_close(mihevc_session *s)
     bc.release(s->device, s->args_cap, false, s->d_args);
     bc.release(s->device, s->scene_cap, false, s->d_scene);
     bc.release(s->device, s->args_cap, true, s->h_args);
-    for (int i = 0; i < kRing; i++) { (void)hipEventDestroy(s->ev_compute[i]); (void)hipEventDestroy(s->ev_copy[i]); }
+    for (int i = 0; i < kRing; i++) { if (s->ev_compute[i]) (void)hipEventDestroy(s->ev_compute[i]); if (s->ev_copy[i]) (void)hipEventDestroy(s->ev_copy[i]); }
     for (auto e : s->ev_pool) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(s->ev_pre); (void)hipEventDestroy(s->ev_args); (void)hipEventDestroy(s->ev_up);
+    if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
+    if (s->ev_args) (void)hipEventDestroy(s->ev_args);
+    if (s->ev_up) (void)hipEventDestroy(s->ev_up);
     bc.release(s->device, s->low_cap, false, s->d_low);
+    bc.release(s->device, s->jobs_cap, false, s->d_jobs); bc.release(s->device, s->jobs_cap, true, s->h_jobs);
+    for (int k = 0; k < 2; k++) {
+        bc.release(s->device, s->x1_bytes, false, s->x1_export[k]);
+        if (s->ev_x1[k]) (void)hipEventDestroy(s->ev_x1[k]);
+        if (s->ev_x2[k]) (void)hipEventDestroy(s->ev_x2[k]);
+    }
     StreamCache::get().release(s->device, s->st_compute);       // both idle: synchronised above
     StreamCache::get().release(s->device, s->st_copy);
     StreamCache::get().release(s->device, s->st_pre);

@@ -158,6 +158,11 @@ class Encoder:
     def flush(self):
         self._check(self._lib.mihevc_flush(self._s), "flush")
 
+    def abort(self):
+        """mihevc_abort: give the session up (every later call fails; sessions of the same picture's other slices stop waiting for it)"""
+        if self._s:
+            self._lib.mihevc_abort(self._s)
+
     def packets(self) -> Iterator[Tuple[bytes, int, bool]]:
         """Drain every packet that is ready: (annexb bytes, pts, keyframe)."""
         data, size = C.POINTER(C.c_uint8)(), C.c_size_t()
@@ -324,16 +329,21 @@ def slice_rows(height: int, n: int):
 class SlicedEncoder:
     """One PICTURE over several MI355X (BASELINE configs[4]): the picture is cut into full-width bands of CTU rows, band k is coded by its own
     session on devices[k] as one slice (own CABAC stream, slice_segment_address in its header), and the slices of a picture are put together
-    into one access unit.  Nothing is exchanged between the devices: motion vectors never reach across a band's edge, the in-loop filters
-    stop there (pps_loop_filter_across_slices_enabled_flag = 0) and every band runs its own rate controller on its share of the rate.  The
-    price is the prediction lost at the seams; the alternative — a halo of reconstructed rows copied between neighbours per picture — is
-    DESIGN.md's next step.  `devices` may name a device several times (tests: two slices on one GPU)."""
+    into one access unit.  halo=True (default): the sessions exchange rows per picture (include/mihevc.h slice_halo; SURVEY §8e's neighbour halo:
+    point-to-point pulls over xGMI, no collective) — the reference rows either side of every seam, so motion vectors cross seams as in a whole
+    picture, and the pre-deblock rows + CU records, so deblocking and SAO run across the seams; the rate controller plans the whole picture from
+    inputs summed over the bands.  halo=False: nothing is exchanged (motion-constrained slices, filters stop at the seams, one rate controller
+    per band: round 2's form, -1.5 dB at 4320p over 8).  `devices` may name a device several times (tests: all bands on one GPU)."""
 
-    def __init__(self, cfg: _lib.Config, devices, keep_recon: bool = False):
+    _group_ids = iter(range(1, 1 << 30))
+
+    def __init__(self, cfg: _lib.Config, devices, keep_recon: bool = False, halo: bool = True):
         import queue
         self.cfg, self.devices = cfg, list(devices)
         self.rows = slice_rows(cfg.height, len(self.devices))
         self.devices = self.devices[:len(self.rows)]
+        self.halo = bool(halo) and len(self.rows) > 1
+        group = next(SlicedEncoder._group_ids) if self.halo else 0
         self._bands, self._cfgs, y0 = [], [], 0
         for k, r in enumerate(self.rows):
             c = type(cfg).from_buffer_copy(bytes(cfg))
@@ -342,10 +352,18 @@ class SlicedEncoder:
             for i, rr in enumerate(self.rows):
                 c.slice_ctu_rows[i] = rr
             c.rate_share_q16 = max(1, round(65536 * r / sum(self.rows)))
+            c.slice_halo, c.slice_group = int(self.halo), group
             self._cfgs.append(c)
             self._bands.append((y0, y1))
             y0 = y1
-        self._encs = [Encoder(c, device=d, keep_recon=keep_recon) for c, d in zip(self._cfgs, self.devices)]
+        self._encs = []
+        try:
+            for c, d in zip(self._cfgs, self.devices):
+                self._encs.append(Encoder(c, device=d, keep_recon=keep_recon))
+        except Exception:
+            for e in self._encs:
+                e.close()
+            raise
         self._q = [queue.Queue(maxsize=8) for _ in self._encs]
         self._out = [dict() for _ in self._encs]            # per slice: pts -> (data, key)
         self._lock = threading.Lock()
@@ -371,6 +389,8 @@ class SlicedEncoder:
                 self._collect(k)
         except Exception as exc:
             self._err.append(exc)
+            for e in self._encs:                    # the other bands may be waiting for this one inside a native call: let them go
+                e.abort()
 
     def _collect(self, k):
         got = list(self._encs[k].packets())
@@ -413,6 +433,8 @@ class SlicedEncoder:
 
     def abort(self):
         self._aborted = True
+        for e in self._encs:                        # a band blocked in a native call waiting for its neighbours returns with an error
+            e.abort()
         self._stop_workers(drain=True)
 
     def headers(self) -> bytes:

@@ -102,6 +102,13 @@ typedef struct mihevc_config {
                                        * under `-threads 0`, core/transcoder.py:410-411).  -1 (default): one tile per 1920x1080 of picture (4320p 4x4, 2160p 2x2, up to
                                        * 1080p-class none: tiles that large cost ~0.2 % bits); 0: off; 1: as -1 but at least 2x2 when the level allows.  Motion
                                        * compensation, deblocking and SAO cross tile boundaries; merge / AMVP candidates and CABAC contexts do not */
+    int32_t slice_halo;               /* slice_count > 1 only.  1: the sessions of one picture's slices EXCHANGE rows (they find each other through slice_group and must
+                                       * live in one process): the PAD rows of the final reconstruction either side of every seam, so motion vectors cross seams as in a
+                                       * whole picture, and 8 rows of the pre-deblock reconstruction + one row of CU records, so deblocking and SAO run across the seams
+                                       * (pps_loop_filter_across_slices_enabled_flag = 1); rate control takes its inputs summed over the slices: one plan per picture.
+                                       * Point-to-point pulls out of the neighbour's device memory (xGMI peer access), no collective.  0: nothing is exchanged — motion
+                                       * constrained slices, filters stop at the seams, every slice its own rate controller (round 2: -1.5 dB at 4320p over 8) */
+    int32_t slice_group;              /* slice_halo: any non-zero number shared by the sessions of one picture's slices and by nobody else in the process */
 } mihevc_config;
 
 typedef struct mihevc_session mihevc_session;
@@ -150,6 +157,9 @@ int  mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, c
 int  mihevc_receive_packet(mihevc_session *s, const uint8_t **data, size_t *size,
                            int64_t *pts, int64_t *dts, int *keyframe);
 int  mihevc_flush(mihevc_session *s);                /* no more input; drain with receive_packet until MIHEVC_EOF */
+/* Give the session up: it fails every later call, and if it codes one slice of a picture with slice_halo, the sessions of the other slices
+ * stop waiting for it (their calls return MIHEVC_EDEVICE).  For a driver whose thread hit an error; mihevc_close is still due. */
+int  mihevc_abort(mihevc_session *s);
 void mihevc_close(mihevc_session *s);
 int  mihevc_get_stats(const mihevc_session *s, mihevc_stats *out);
 /* VPS+SPS+PPS (Annex-B) for the muxer's hvcC box; valid until close. */

@@ -233,11 +233,13 @@ static int intra_frame(const T *sy, const T *su, const T *sv, int w, int h, cons
     return 0;
 }
 
-template <typename T> static int deblock(T *y, T *u, T *v, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
+// row0 / y_org: deblock rows [row0, row0 + h) of a whole picture's planes as a picture of its own whose first y_org rows belong to the slice above
+// (DeblockArgs::y_org; the band extended by the rows its neighbours hand over, csrc/slice_group.h)
+template <typename T> static int deblock(T *y, T *u, T *v, int w, int h, const mihevc_cu_rec *cu, int bit_depth, int row0 = 0, int y_org = 0)
 {
     DeblockArgs<T> a;
-    a.rec[0] = {y, w}; a.rec[1] = {u, w / 2}; a.rec[2] = {v, w / 2};
-    a.w = w; a.h = h; a.cu = cu; a.bit_depth = bit_depth;
+    a.rec[0] = {y + (ptrdiff_t)row0 * w, w}; a.rec[1] = {u + (ptrdiff_t)(row0 / 2) * (w / 2), w / 2}; a.rec[2] = {v + (ptrdiff_t)(row0 / 2) * (w / 2), w / 2};
+    a.w = w; a.h = h; a.cu = cu + (ptrdiff_t)(row0 / 8) * (w / 8); a.bit_depth = bit_depth; a.y_org = y_org;
     for (int dir = 0; dir < 2; dir++) {
         a.dir = dir;
         for (int i = 0; i < (w / 8) * (h / 8) * 2; i++) deblock_segment<T>(a, i);
@@ -245,15 +247,18 @@ template <typename T> static int deblock(T *y, T *u, T *v, int w, int h, const m
     return 0;
 }
 
+// y0 / halo: the planes are those of a whole picture of which rows [y0, y0 + h) are coded here as one slice whose filters run across the seams
+// (SaoArgs::halo; csrc/slice_group.h): the kernel then sees its band as the picture and finds the neighbour rows where the exchange puts them
 template <typename T>
 static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, const T *dv, int w, int h, const mihevc_cost_params *prm,
-               T *oy, T *ou, T *ov, mihevc_sao_ctu *out)
+               T *oy, T *ou, T *ov, mihevc_sao_ctu *out, int y0 = 0, int halo = 0)
 {
     SaoArgs<T> a;
-    a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
-    a.dbk[0] = {dy, w}; a.dbk[1] = {du, w / 2}; a.dbk[2] = {dv, w / 2};
-    a.out[0] = {oy, w}; a.out[1] = {ou, w / 2}; a.out[2] = {ov, w / 2};
-    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.prm = to_prm(prm); a.sao = out; a.sse = nullptr;
+    const ptrdiff_t oy_ = (ptrdiff_t)y0 * w, oc_ = (ptrdiff_t)(y0 / 2) * (w / 2);
+    a.src[0] = {sy + oy_, w}; a.src[1] = {su + oc_, w / 2}; a.src[2] = {sv + oc_, w / 2};
+    a.dbk[0] = {dy + oy_, w}; a.dbk[1] = {du + oc_, w / 2}; a.dbk[2] = {dv + oc_, w / 2};
+    a.out[0] = {oy + oy_, w}; a.out[1] = {ou + oc_, w / 2}; a.out[2] = {ov + oc_, w / 2};
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.prm = to_prm(prm); a.sao = out; a.sse = nullptr; a.halo_top = (halo & 1) ? 1 : 0; a.halo_bottom = (halo & 2) ? 1 : 0;
     SeqExec ex; ex.order = emu_order();
     int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU);
     for (int c = 0; c < n_ctu; c++) {
@@ -286,6 +291,20 @@ int emu_deblock(void *y, void *u, void *v, int w, int h, const mihevc_cu_rec *cu
 {
     if (bit_depth == 8) return deblock<uint8_t>((uint8_t *)y, (uint8_t *)u, (uint8_t *)v, w, h, cu, bit_depth);
     return deblock<uint16_t>((uint16_t *)y, (uint16_t *)u, (uint16_t *)v, w, h, cu, bit_depth);
+}
+int emu_deblock_band(void *y, void *u, void *v, int w, int row0, int h, int y_org, const mihevc_cu_rec *cu, int bit_depth)
+{
+    if (bit_depth == 8) return deblock<uint8_t>((uint8_t *)y, (uint8_t *)u, (uint8_t *)v, w, h, cu, bit_depth, row0, y_org);
+    return deblock<uint16_t>((uint16_t *)y, (uint16_t *)u, (uint16_t *)v, w, h, cu, bit_depth, row0, y_org);
+}
+int emu_sao_band(const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int y0, int h, int halo,
+                 const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *out)
+{
+    if (prm->bit_depth == 8)
+        return sao<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (const uint8_t *)dy, (const uint8_t *)du, (const uint8_t *)dv, w, h, prm,
+                            (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, out, y0, halo);
+    return sao<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)dy, (const uint16_t *)du, (const uint16_t *)dv, w, h, prm,
+                         (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, out, y0, halo);
 }
 int emu_sao(const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int h,
             const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *out)

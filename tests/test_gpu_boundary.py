@@ -128,7 +128,7 @@ def test_one_picture_as_slices_over_several_sessions(lib, w, h, bd, n_slices, le
         cfg.qp = 27
     n = 10
     frames = [util.synth_frame(h, w, seed=5, shift=(2 * i, 7 * i), bit_depth=bd) for i in range(n)]      # 7 rows of vertical motion per picture
-    sl = SlicedEncoder(cfg, [0] * n_slices, keep_recon=True)
+    sl = SlicedEncoder(cfg, [0] * n_slices, keep_recon=True, halo=False)        # nothing is exchanged: motion-constrained slices (round 2's form)
     try:
         assert sl.rows == slice_rows(h, n_slices) and len(sl.rows) == n_slices
         got = []
@@ -150,6 +150,59 @@ def test_one_picture_as_slices_over_several_sessions(lib, w, h, bd, n_slices, le
     assert all(st.frames_out == n for st in stats)
     if w >= 512:
         assert info["pps.tile_cols"] == 2 and info["pps.tile_rows"] >= n_slices        # IDR pictures: tiles inside every slice
+
+
+@pytest.mark.parametrize("w,h,bd,n_slices,level,rc", [(544, 320, 8, 3, 120, 0), (320, 200, 10, 2, 93, 1), (160, 160, 8, 4, 63, 1)])
+def test_slices_that_exchange_rows_equal_the_whole_picture_pipeline(lib, w, h, bd, n_slices, level, rc):
+    """BASELINE configs[4] as SURVEY §8e describes it, with the devices [0, 0(, 0 ...)]: the bands' sessions pull rows out of each other's pictures per
+    step (cfg.slice_halo: reference rows for motion across the seams, pre-deblock rows + CU records for deblocking / SAO across them; on one device the
+    peer pointers are ordinary device pointers) and plan ONE rate per picture.  The stacked reconstructions must equal, bit for bit, the oracle's
+    WHOLE-PICTURE pipeline replayed with the session's QPs (tests/test_sliced_cpu.py halo_pipeline: only IDR analysis and search centres are per band),
+    and the merged stream must decode to them.  (160x160 over 4: bands of 2 + 1 + 1 + 1 CTU rows, shorter than the 80 reference rows a band needs:
+    the rows come from two and three bands away.)"""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import SlicedEncoder, slice_rows
+    from tests.test_gpu_configs import session_params
+    from tests.test_sliced_cpu import halo_pipeline, mv_rows_ok
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.bit_depth, cfg.level_idc, cfg.keyint, cfg.min_keyint, cfg.me_range, cfg.gops_in_flight, cfg.aud = w, h, bd, level, 4, 2, 12, 2, 1
+    if rc:
+        cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits = 20, -1, 400, 480
+    else:
+        cfg.qp = 27
+    n = 10
+    frames = [util.synth_frame(h, w, seed=5, shift=(2 * i, 7 * i), bit_depth=bd) for i in range(n)]      # 7 rows of vertical motion per picture
+    sl = SlicedEncoder(cfg, [0] * n_slices, keep_recon=True)
+    try:
+        assert sl.halo and sl.rows == slice_rows(h, n_slices)
+        got = []
+        for f in frames:
+            sl.send(*util.planes(f, bd))
+            got += sl.ready()
+        got += sl.finish()
+        recs = [O.Frame(*sl.recon(i)) for i in range(n)]
+        infos = [[e.frame_info(i) for i in range(n)] for e in sl._encs]
+        cfgs = sl._cfgs
+    finally:
+        sl.close()
+    assert all([(q, t) for q, t, _ in inf] == [(q, t) for q, t, _ in infos[0]] for inf in infos), "the bands of a picture must agree on its type and QP (one rate plan)"
+    if rc:
+        assert len({q for q, t, _ in infos[0] if t == 1}) > 1 or max(q for q, _, _ in infos[0]) > cfg.crf + 2       # the cap had to bind
+    idr_at = {i for i, (_, t, _) in enumerate(infos[0]) if t == 2}
+    assert idr_at == {0, 4, 8}
+    crossing, k = 0, 0
+    ys = np.cumsum([0] + [32 * r for r in sl.rows])
+    for i, (intra, a, sao, ref) in enumerate(halo_pipeline(frames, sl.rows, cfgs, None, None, None, bd, prm_of=lambda i, intra: session_params(lib, cfgs[0], infos[0][i][0], False)[0], idr_at=idr_at)):
+        assert recs[i].same(ref), f"picture {i}: the bands' reconstructions != the whole-picture pipeline"
+        if not intra:
+            for (by, bx), r in np.ndenumerate(a.cu):
+                nn, k = 1 << int(r["log2_size"]), int(np.searchsorted(ys, by * 8, side="right")) - 1
+                crossing += not mv_rows_ok(((by * 8) & ~(nn - 1)) - ys[k], nn, int(r["mvy"]), min(h, ys[k + 1]) - ys[k], k > 0, k < n_slices - 1)
+    assert crossing > 0, "no motion vector crosses a seam: the exchange is not exercised"
+    dec, info = O.decode(b"".join(d for d, _, _ in got))
+    assert len(dec) == n and info["count.slices"] == n * n_slices and info["count.aud"] == n
+    for i in range(n):
+        assert O.Frame(dec[i].y[:h], dec[i].u[:h // 2], dec[i].v[:h // 2]).same(recs[i]), f"picture {i}: decoded picture != the slices' reconstructions"
 
 
 def test_convert_video_with_row_split(lib, tmp_path):

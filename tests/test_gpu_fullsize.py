@@ -2,7 +2,7 @@
 
 configs[4] — 7680x4320 Main10 HDR10, level 6 (reference operating point: core/transcoder.py:263-354 -> crf 20, vbv 47040 / 56448, keyint 60;
 HDR10 set of core/utils.py:58-69): (a) every picture as 8 slices of CTU rows, all eight band sessions on device 0 — what the 8-GPU split runs
-per device, minus the peer copies; (b) per-stage HIP vs oracle on the unsliced 4320p pictures (I + P, incl. the integer-search dump).
+per device, with the row exchange between the bands going through ordinary device pointers instead of xGMI peer mappings; (b) per-stage HIP vs oracle on the unsliced 4320p pictures (I + P, incl. the integer-search dump).
 configs[3] — one clip per GPU: `bench.py --gpus 2` with both ranks sharing device 0 (MIHEVC_BENCH_SHARE_GPU=1: the rank / rendezvous / MAX-over-ranks
 path with REAL encoders; the number it prints is no scaling figure and says so), and the headless batch queue over eight 1080p clips with two
 worker processes.  A node with 8 devices is not in reach of the test box: "unmeasured on more than one GPU" stays true."""
@@ -48,7 +48,7 @@ def test_config5_4320p_main10_hdr10_as_8_slices_on_device_0(lib, frames_4320p):
     assert (crf, maxrate, bufsize, gop, level) == (20, 47040, 56448, 60, "6") and cfg.bit_depth == 10          # SURVEY App. A golden
     sl = SlicedEncoder(cfg, [0] * 8, keep_recon=True)
     try:
-        assert sl.rows == slice_rows(4320, 8) == [17] * 7 + [16]
+        assert sl.halo and sl.rows == slice_rows(4320, 8) == [17] * 7 + [16]
         got = []
         for (y, u, v), _ in frames_4320p:
             sl.send(y, u, v)
@@ -56,8 +56,18 @@ def test_config5_4320p_main10_hdr10_as_8_slices_on_device_0(lib, frames_4320p):
         got += sl.finish()
         recs = [O.Frame(*sl.recon(i)) for i in range(n)]
         stats = sl.stats()
+        infos = [[e.frame_info(i) for i in range(n)] for e in sl._encs]
+        cfgs = sl._cfgs
     finally:
         sl.close()
+    # the eight bands exchange rows (cfg.slice_halo) and share one rate plan: same type and QP in every band, and the stacked reconstructions of the first
+    # two pictures equal the oracle's WHOLE-PICTURE pipeline replayed with those QPs (tests/test_sliced_cpu.py halo_pipeline), bit for bit
+    from tests.test_gpu_configs import session_params
+    from tests.test_sliced_cpu import halo_pipeline
+    assert all([(q, t) for q, t, _ in inf] == [(q, t) for q, t, _ in infos[0]] for inf in infos)
+    srcs = [f for _, f in frames_4320p[:2]]
+    for i, (intra, a, sao, ref) in enumerate(halo_pipeline(srcs, sl.rows, cfgs, None, None, None, 10, prm_of=lambda i, intra: session_params(lib, cfgs[0], infos[0][i][0], False)[0], idr_at={0})):
+        assert recs[i].same(ref), f"picture {i}: the bands' reconstructions != the whole-picture pipeline"
     assert [p for _, p, _ in got] == list(range(n)) and [k for _, _, k in got] == [True, False, False]
     dec, info = O.decode(b"".join(d for d, _, _ in got))
     assert len(dec) == n and info["count.slices"] == 8 * n and info["count.aud"] == n
