@@ -15,6 +15,8 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -608,12 +610,6 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (want > s->low_cap) {
             BufferCache &bc = BufferCache::get();
             bc.release(s->device, s->low_cap, false, s->d_low);
-    bc.release(s->device, s->jobs_cap, false, s->d_jobs); bc.release(s->device, s->jobs_cap, true, s->h_jobs);
-    for (int k = 0; k < 2; k++) {
-        bc.release(s->device, s->x1_bytes, false, s->x1_export[k]);
-        if (s->ev_x1[k]) (void)hipEventDestroy(s->ev_x1[k]);
-        if (s->ev_x2[k]) (void)hipEventDestroy(s->ev_x2[k]);
-    }
             s->d_low = nullptr; s->low_cap = 0;
             const size_t cap = (want + 0xfffff) & ~(size_t)0xfffff;
             HIPCK(s, bc.alloc(s->device, cap, false, &s->d_low));
