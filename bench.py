@@ -40,33 +40,55 @@ SHARE_GPU = os.environ.get("MIHEVC_BENCH_SHARE_GPU") == "1"
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
-def cpu_baseline(width, height, qp, me_range, budget_frames=3):
-    """The oracle (scalar C port of the same path) on ONE host core, on the first frames of the same clip:
-    1 I + (budget_frames-1) P pictures through analysis + deblock + SAO.  Reported baseline, not the target."""
+def cpu_baseline(width, height, qp, me_range, gop_pictures=4):
+    """The oracle (scalar C port of the same path: analysis + deblocking + SAO) PLUS the host CABAC coder, on ALL the host cores this process is bound to,
+    the way a CPU encoder of this design would use them: one closed GOP per core (closed GOPs are independent), every core codes `gop_pictures` pictures
+    (1 I + P) of the same clip from its own start picture.  value = pictures of all cores / wall time.  A bounded sample (a full 75-picture GOP per core
+    would take minutes on this scalar port); a reported baseline, not the target — and not libx265: see the `libx265` block for that."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor as Pool
+    from hevc_amd import _lib
     from hevc_amd.yuvio import SyntheticClip
     from oracle import oracle as O
-    clip = SyntheticClip("motion", 0, width, height, budget_frames)
+    cores = max(1, len(os.sched_getaffinity(0)))
     ch = (height + 7) & ~7
-    prm_i, prm_p = O.default_params(max(0, qp - 3), me_range=me_range), O.default_params(qp, me_range=me_range)
-    from hevc_amd import _lib
     cfg = _lib.default_config()
     cfg.width, cfg.height = width, height
-    prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and NxN trial the device path runs
-    prm_i.intra_nxn, prm_i.chroma_modes = cfg.intra_nxn, cfg.chroma_modes
-    prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
+    lib = _lib.load()
+    O.lib()
+    clip = SyntheticClip("motion", 0, width, height, cores * gop_pictures + 1)
+    clip.frame(0)
+
+    def one_gop(k):
+        prm_i, prm_p = O.default_params(max(0, qp - 3), me_range=me_range), O.default_params(qp, me_range=me_range)
+        prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)        # the same IDR tile grid and knobs the device path runs
+        prm_i.intra_nxn, prm_i.chroma_modes = cfg.intra_nxn, cfg.chroma_modes
+        prm_p.intra_in_p, prm_p.pre_search, prm_p.rdo_zero, prm_p.rdo_cg = cfg.intra_in_p, cfg.pre_search, cfg.rdo_zero, cfg.rdo_cg
+        buf = (C.c_uint8 * (8 << 20))()
+        ref = prev = None
+        nbytes = 0
+        for i in range(gop_pictures):
+            y, u, v = clip.frame(k * gop_pictures + i)
+            f = O.Frame(np.pad(y, ((0, ch - height), (0, 0)), mode="edge"), np.pad(u, ((0, (ch - height) // 2), (0, 0)), mode="edge"),
+                        np.pad(v, ((0, (ch - height) // 2), (0, 0)), mode="edge"))
+            cen = O.search_centres(f, prev, 8) if i and cfg.pre_search else None        # as the session: centres from the source pictures
+            a = O.analyze_intra(f, prm_i) if i == 0 else O.analyze_inter(f, ref, prm_p, centers=cen)
+            prev = f
+            prm = prm_i if i == 0 else prm_p
+            ref, sao = O.sao(f, O.deblock(a.rec, a.cu, 8), prm)
+            n = lib.mihevc_encode_picture_host(C.byref(cfg), 2 if i == 0 else 1, i, prm.qp, a.cu.ctypes.data, a.coef_y.ctypes.data, a.coef_u.ctypes.data, a.coef_v.ctypes.data,
+                                               sao.ctypes.data, buf, len(buf))
+            nbytes += max(0, n)
+        return nbytes
     t0 = time.perf_counter()
-    ref = prev = None
-    for i, (y, u, v) in enumerate(clip.frames()):
-        f = O.Frame(np.pad(y, ((0, ch - height), (0, 0)), mode="edge"), np.pad(u, ((0, (ch - height) // 2), (0, 0)), mode="edge"),
-                    np.pad(v, ((0, (ch - height) // 2), (0, 0)), mode="edge"))
-        cen = O.search_centres(f, prev, 8) if i and cfg.pre_search else None        # as the session: centres from the source pictures
-        a = O.analyze_intra(f, prm_i) if i == 0 else O.analyze_inter(f, ref, prm_p, centers=cen)
-        prev = f
-        ref, _ = O.sao(f, O.deblock(a.rec, a.cu, 8), prm_i if i == 0 else prm_p)
+    with Pool(max_workers=cores) as ex:          # ctypes releases the GIL inside the oracle and the coder: the GOPs run in parallel
+        sizes = list(ex.map(one_gop, range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": round(budget_frames / dt, 4), "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/hevc_oracle.c, first {budget_frames} pictures (1 I + {budget_frames - 1} P) of the same {width}x{height} clip, "
-                      f"analysis+deblock+SAO, no CABAC, {dt:.1f} s; for libx265 itself see the `libx265` block"}
+    n = cores * gop_pictures
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/hevc_oracle.c analysis + deblocking + SAO and the host CABAC coder, {cores} closed GOPs of {gop_pictures} pictures (1 I + {gop_pictures - 1} P) of the same "
+                      f"{width}x{height} clip, one GOP per bound core in parallel, {dt:.1f} s wall, {sum(sizes) * 8 * 30 / n / 1e3:.0f} kb/s at 30 fps; a bounded sample, "
+                      f"not a full {75}-picture GOP per core; for libx265 itself see the `libx265` block"}
 
 
 # ------------------------------------------------------------------------------------------------ libx265 (the reference's own command)
@@ -127,31 +149,36 @@ def libx265_baseline(info, frames, bit_depth, budget_s=120.0):
 
 
 # ------------------------------------------------------------------------------------------------ committed profile data
-def newest_profile(name):
-    files = sorted(glob.glob(str(ROOT / "profiles" / "r*" / name)))
-    return files[-1] if files else None
+def newest_profile_dir():
+    """the newest profiles/r*/ that holds a traffic.json (tools/profile_bench.sh); pmc.json (tools/pmc_kernels.sh) is only used from the SAME directory:
+    counters of one build say nothing about another (round 2 reported a VALU share from two builds before its traffic figures)"""
+    dirs = sorted(os.path.dirname(f) for f in glob.glob(str(ROOT / "profiles" / "r*" / "traffic.json")))
+    return dirs[-1] if dirs else None
 
 
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the newest committed PMC pass (profiles/r*/traffic.json, written by
     tools/profile_bench.sh from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  PMC passes cannot
     run inside the timed bench, so the figure is only reported for the default workload it was collected on."""
-    f = newest_profile("traffic.json")
-    if workload != (1920, 1080, 300, 15) or not f:
-        return None, None
+    d = newest_profile_dir()
+    if workload != (1920, 1080, 300, 15) or not d:
+        return None, None, None
     try:
-        k = json.load(open(f))["kernels"].get(kernel)
+        ks = json.load(open(os.path.join(d, "traffic.json")))["kernels"]
     except (OSError, ValueError, KeyError):
-        return None, None
-    return (k["hbm_bytes_per_launch"], os.path.relpath(f, ROOT)) if k else (None, None)
+        return None, None, None
+    k = ks.get(kernel)
+    return (k["hbm_bytes_per_launch"] if k else None, os.path.relpath(os.path.join(d, "traffic.json"), ROOT), ks)
 
 
 def measured_valu(kernel):
-    """VALU issue share of `kernel` from the newest committed SQ counter pass (profiles/r*/pmc.json, tools/pmc_kernels.sh):
+    """VALU issue share of `kernel` from the SQ counter pass that sits beside that traffic.json (pmc.json, tools/pmc_kernels.sh on the bench command):
     SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in quad-cycles over the same sampled waves) = share of a wave's resident time in which it
-    issues vector ALU work; times the resident waves per SIMD (from the kernel's launch bounds) = share of a SIMD's issue slots."""
-    f = newest_profile("pmc.json")
-    if not f:
+    issues vector ALU work; times the resident waves per SIMD (the kernel's launch bounds, read from csrc/device.hip) = share of a SIMD's issue slots.
+    None when that directory has no pmc.json."""
+    d = newest_profile_dir()
+    f = os.path.join(d, "pmc.json") if d else None
+    if not f or not os.path.exists(f):
         return None
     try:
         k = json.load(open(f))["kernels"].get(kernel)
@@ -160,7 +187,7 @@ def measured_valu(kernel):
     if not k:
         return None
     return {"valu_issue_frac": k["valu_issue_frac"], "valu_active_per_wave": k["valu_active_per_wave"], "waves_per_simd": k["waves_per_simd"],
-            "source": os.path.relpath(f, ROOT)}
+            "wait_frac": k.get("wait_frac"), "source": os.path.relpath(f, ROOT)}
 
 
 # ------------------------------------------------------------------------------------------------ stream check (oracle decoder)
@@ -485,7 +512,7 @@ def main():
             bytes_per_launch = per_pic[dom] * stage_pics[dom] / launches
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kname = "k_" + _lib.STAGE_NAMES[dom] if dom else "k_intra_diag"
-        traffic, traffic_src = measured_traffic(kname, (W, H, N, args.me_range))
+        traffic, traffic_src, traffic_all = measured_traffic(kname, (W, H, N, args.me_range))
         valu = measured_valu(kname)
         ok265, why265 = libx265_probe()
         out = {
@@ -514,6 +541,18 @@ def main():
                          "note": "integer-VALU/LDS bound path: the HBM fraction is small by construction (SURVEY.md §0.5); valu_issue_frac is the "
                                  "share of SIMD issue slots the kernel fills, from the committed SQ counter pass"},
         }
+        # the whole pipeline beside its dominant kernel: algorithmic bytes of a picture over ALL stages (an IDR picture reads its source and writes its
+        # reconstruction, a P picture also reads its reference once: SURVEY.md §8d) x pictures / step time, and the HBM bytes the counters saw for all kernels
+        n_idr = (N + gop - 1) // gop
+        alg_clip = n_idr * 2 * S + (N - n_idr) * 3 * S
+        pipe = {"algorithmic_bytes_per_picture": int(alg_clip / N), "achieved": round(world * args.steps * alg_clip / dt / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(world * args.steps * alg_clip / dt / 1e9 / HBM_PEAK_GBS, 6), "traffic_bytes_per_picture": None}
+        if traffic_all:
+            tot = sum(k["hbm_bytes_per_launch"] * k["dispatches"] for k in traffic_all.values())
+            pipe["traffic_bytes_per_picture"] = int(tot / N)          # the PMC passes run ONE step of this clip
+            pipe["traffic_over_algorithmic"] = round(tot / alg_clip, 2)
+            pipe["traffic_source"] = traffic_src
+        out["pipeline"] = pipe
         if not args.no_extras and world == 1:     # the untimed legs describe ONE device: at N > 1 the other ranks would only wait for rank 0
             # the boundary hands over HOST buffers (mihevc_send_frame): the same clip, upload inside the clock
             n_p = max(1, min(args.steps, 3))

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC passes for the per-CTU kernels on a short 1080p encode (tests/prof_clip.py): bash tools/pmc_kernels.sh <tag>
+# PMC passes for the per-CTU kernels on the BENCH command itself (bench.py's 300-frame 1080p clip, one timed step): bash tools/pmc_kernels.sh <tag>
 # Each --pmc group is its own rocprofv3 run (never combined with traces); summary -> gpurun_out/<tag>/pmc_summary.txt
 set -e
 tag=${1:-pmc}
@@ -13,12 +13,12 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_WAIT_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $out/p$i -o p --output-format csv -- python3 $root/tests/prof_clip.py 24 12 > $out/run$i.log 2>&1 || { tail -5 $out/run$i.log; exit 1; }
+  rocprofv3 --pmc $grp -d $out/p$i -o p --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/run$i.log 2>&1 || { tail -5 $out/run$i.log; exit 1; }
 done
 cd $root
-{ echo "# mean per dispatch of the SQ counters rocprofv3 wrote for each kernel (three separate --pmc passes of tests/prof_clip.py 24 12)."
-  echo "# Every value is the MEAN PER DISPATCH (not the sum over the run): k_inter_ctu's SQ_WAVES 16320 = 2 pictures x 2040 CTUs x 4 waves, all the"
-  echo "# waves of a launch.  Read RATIOS of counters of one pass, e.g. SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in units of 4 cycles) = share of a"
+{ echo "# mean per dispatch of the SQ counters rocprofv3 wrote for each kernel (three separate --pmc passes of: python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras)."
+  echo "# Every value is the MEAN PER DISPATCH (not the sum over the run): the SQ block of a subset of the shader engines is sampled, so"
+  echo "# absolute values are a sample.  Read RATIOS of counters of one pass, e.g. SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both in units of 4 cycles) = share of a"
   echo "# resident wave's life spent issuing VALU work; x waves per SIMD (occupancy) = share of SIMD issue slots: pmc.json, tools/prof_summary.py."
   python3 tools/prof_summary.py pmc $out/p1 $out/p2 $out/p3; } > $out/pmc_summary.txt
 python3 tools/prof_summary.py pmcjson $out/pmc.json $out/p1 $out/p2 $out/p3 > /dev/null

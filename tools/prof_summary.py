@@ -80,8 +80,25 @@ def traffic(fd, wd, outp):
     print(json.dumps(res, indent=1))
 
 
-# workgroups (= waves per SIMD: 256 threads = 4 waves over 4 SIMDs) per CU from the kernels' __launch_bounds__ in csrc/device.hip
-WAVES_PER_SIMD = {"k_inter_ctu": 4, "k_intra_plan": 3, "k_intra_diag": 2, "k_me_search": 5, "k_sao_decide": 8, "k_intra_p": 2, "k_pre_search": 8}
+def waves_per_simd_from_source():
+    """workgroups per CU (= waves per SIMD: 256 threads are 4 waves over the CU's 4 SIMDs) each kernel is BUILT for: the second argument of its
+    __launch_bounds__ in csrc/device.hip, read from the source so the table cannot go stale (round 2 kept it by hand and k_sao_decide was wrong).
+    Registers are allocated to fit that many and the LDS footprints are sized for it; kernels without the argument: 8 (the VGPR limit
+    of 64 at wave64 x 8 waves)."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hevc_amd", "csrc", "device.hip")).read()
+    src = re.sub(r"#define INTRA_OCC (\d+)", "", src)
+    occ = {}
+    for m in re.finditer(r"__launch_bounds__\((.*)\)\s*void\s+(k_\w+)", src):      # one kernel header per line
+        args = m.group(1).split(",", 1)
+        n = 8
+        if len(args) > 1:
+            d = re.findall(r"\d+", args[1].replace("INTRA_OCC", "3"))
+            if "sizeof" in args[1]:
+                d = d[1:]              # (sizeof(T) == 1 ? A : B): the 8-bit instantiation's A
+            n = int(d[0]) if d else 8
+        occ[m.group(2)] = n
+    return occ
 
 
 def pmcjson(outp, dirs):
@@ -93,15 +110,16 @@ def pmcjson(outp, dirs):
             name = k.split("::")[-1].split("<")[0]
             acc.setdefault(name, {}).update({c: v[0] / max(1, v[1]) for c, v in cs.items()})
     res = {}
+    occ_table = waves_per_simd_from_source()
     for name, c in acc.items():
         if not c.get("SQ_WAVE_CYCLES") or "SQ_ACTIVE_INST_VALU" not in c:
             continue
         per_wave = c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"]
-        occ = WAVES_PER_SIMD.get(name, 8)
+        occ = occ_table.get(name, 8)
         res[name] = {"valu_active_per_wave": round(per_wave, 4), "waves_per_simd": occ, "valu_issue_frac": round(min(1.0, per_wave * occ), 4),
                      "wait_frac": round(c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"], 4) if "SQ_WAIT_ANY" in c else None,
                      "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1) if c.get("SQ_WAVES") and "SQ_INSTS_VALU" in c else None}
-    json.dump({"source": "rocprofv3 --pmc SQ_* passes of tests/prof_clip.py (tools/pmc_kernels.sh); ratios of counters of one pass, see tools/prof_summary.py",
+    json.dump({"source": "rocprofv3 --pmc SQ_* passes of the bench command `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras` (tools/pmc_kernels.sh); ratios of counters of one pass, waves per SIMD from the kernels' __launch_bounds__ in csrc/device.hip, see tools/prof_summary.py",
                "kernels": res}, open(outp, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
