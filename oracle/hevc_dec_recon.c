@@ -245,8 +245,25 @@ static int edge_bs(const d2_picture_info *pi, int dir, int xq, int yq)
  * quarter-sample units.  The determination is made on the PICTURES referenced, not on list indices. */
 int d2_motion_differs(const orc_cu_rec *p, const orc_cu_rec *q, const int *poc_of_ref)
 {
-    (void)poc_of_ref;
-    return d2_abs(p->mvx - q->mvx) >= 4 || d2_abs(p->mvy - q->mvy) >= 4;
+    /* the pictures each block predicts from (poc_of_ref[list]: RefPicList0[0], RefPicList1[0]; NULL in P slices: one list) and its vectors */
+    int np = 0, nq = 0, rp[2], rq[2], vp[2][2], vq[2][2];
+    for (int l = 0; l < 2; l++) {
+        const int up = l ? (p->flags & ORC_F_L1) != 0 : !(p->flags & ORC_F_NOL0), uq = l ? (q->flags & ORC_F_L1) != 0 : !(q->flags & ORC_F_NOL0);
+        if (up) { rp[np] = poc_of_ref ? poc_of_ref[l] : l; vp[np][0] = l ? orc_mv1x(p) : p->mvx; vp[np][1] = l ? orc_mv1y(p) : p->mvy; np++; }
+        if (uq) { rq[nq] = poc_of_ref ? poc_of_ref[l] : l; vq[nq][0] = l ? orc_mv1x(q) : q->mvx; vq[nq][1] = l ? orc_mv1y(q) : q->mvy; nq++; }
+    }
+    if (np != nq) return 1;                                                      /* different number of motion vectors */
+#define FAR(a, b) (d2_abs((a)[0] - (b)[0]) >= 4 || d2_abs((a)[1] - (b)[1]) >= 4)
+    if (np == 1) return rp[0] != rq[0] || FAR(vp[0], vq[0]);
+    /* two vectors each */
+    if (!((rp[0] == rq[0] && rp[1] == rq[1]) || (rp[0] == rq[1] && rp[1] == rq[0]))) return 1;      /* different reference pictures */
+    if (rp[0] != rp[1]) {                                                        /* two different pictures: compare the vectors that refer to the same one */
+        const int swap = rp[0] != rq[0];
+        return FAR(vp[0], vq[swap ? 1 : 0]) || FAR(vp[1], vq[swap ? 0 : 1]);
+    }
+    /* both vectors of both blocks refer to one picture: either pairing may match */
+    return (FAR(vp[0], vq[0]) || FAR(vp[1], vq[1])) && (FAR(vp[0], vq[1]) || FAR(vp[1], vq[0]));
+#undef FAR
 }
 
 /* 8.7.2.5.3 decisions + 8.7.2.5.7 luma sample filtering for one 4-sample segment.  s points at q0 of line 0; `across` is the step from p to q,

@@ -940,6 +940,213 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
 }
 
 /* ================================================================================================
+ * K1 + K3 : B picture (two reference pictures, one per list)
+ * ================================================================================================ */
+/* 14-bit intermediate prediction samples of 8.5.3.3.3 (before the rounding of 8.5.3.3.4.2): luma at quarter-sample, chroma at eighth-sample vectors */
+static void interp14(const pix *ref, int rstride, int x, int y, int mvx, int mvy, int w, int h, int bit_depth, int chroma, int16_t *dst, int dstride)
+{
+    const int taps = chroma ? 4 : 8, half = chroma ? 1 : 3, fmask = chroma ? 7 : 3, fsh = chroma ? 3 : 2;
+    const int fx = mvx & fmask, fy = mvy & fmask, xi = x + (mvx >> fsh), yi = y + (mvy >> fsh);
+    const int shift1 = bit_depth - 8 < 4 ? bit_depth - 8 : 4, shift3 = 14 - bit_depth;
+    for (int j = 0; j < h; j++)
+        for (int i = 0; i < w; i++) {
+            const pix *p = ref + (yi + j) * rstride + xi + i;
+            int v;
+#define TAP(f, k) (chroma ? kChromaTap[f][k] : kLumaTap[f][k])
+            if (!fx && !fy) v = p[0] << shift3;
+            else if (!fy) { int a = 0; for (int k = 0; k < taps; k++) a += TAP(fx, k) * p[k - half]; v = a >> shift1; }
+            else if (!fx) { int a = 0; for (int k = 0; k < taps; k++) a += TAP(fy, k) * p[(k - half) * rstride]; v = a >> shift1; }
+            else {
+                int a = 0;
+                for (int r = 0; r < taps; r++) {
+                    int t = 0;
+                    for (int k = 0; k < taps; k++) t += TAP(fx, k) * p[(r - half) * rstride + k - half];
+                    a += TAP(fy, r) * (t >> shift1);
+                }
+                v = a >> 6;
+            }
+#undef TAP
+            dst[j * dstride + i] = (int16_t)v;
+        }
+}
+/* 8.5.3.3.4.2: default weighted sample prediction of a block from its list-0 and / or list-1 14-bit predictions (NULL = list not used) */
+static void weighted_default(const int16_t *p0, const int16_t *p1, int n, int bit_depth, pix *dst)
+{
+    const int maxv = (1 << bit_depth) - 1, shift1 = 14 - bit_depth, shift2 = 15 - bit_depth;
+    for (int i = 0; i < n; i++) {
+        int v;
+        if (p0 && p1) v = (p0[i] + p1[i] + (1 << (shift2 - 1))) >> shift2;
+        else v = ((p0 ? p0[i] : p1[i]) + (1 << (shift1 - 1))) >> shift1;
+        dst[i] = (pix)CLIP3(0, maxv, v);
+    }
+}
+
+/* the integer full search of orc_analyze_inter_frame for one CTU against one reference (no slice constraint: B pictures are not coded as slices) */
+static void ctu_integer_search(const pix *src_y, int src_stride, const pix *ref_y, int ref_stride, int x0, int y0, int sx, int sy, int R, int bd, int lam,
+                               const int *valid, const int *nx, const int *ny, uint32_t *sad8, int mvx[21], int mvy[21], uint32_t cost[21])
+{
+    const int spany = 2 * R + 1, spanx = (spany + 3) & ~3;
+    for (int b = 0; b < 16; b++) {
+        int nd = 5 + b;
+        if (!valid[nd]) continue;
+        for (int dy = -R; dy <= R; dy++)
+            for (int dx = -R; dx < -R + spanx; dx++)
+                sad8[(b * spany + dy + R) * spanx + dx + R] = sad_msb8(src_y + (y0 + ny[nd]) * src_stride + x0 + nx[nd], src_stride,
+                                                                         ref_y + (y0 + ny[nd] + sy + dy) * ref_stride + x0 + nx[nd] + sx + dx, ref_stride, bd - 8);
+    }
+    for (int nd = 0; nd < 21; nd++) {
+        mvx[nd] = mvy[nd] = 0; cost[nd] = 0;
+        if (!valid[nd]) continue;
+        uint64_t best = ~0ull;
+        for (int dy = -R; dy <= R; dy++)
+            for (int dx = -R; dx < -R + spanx; dx++) {
+                uint32_t s = 0;
+                int p = (dy + R) * spanx + dx + R;
+                if (nd == 0) for (int b = 0; b < 16; b++) s += sad8[b * spanx * spany + p];
+                else if (nd < 5) for (int b = 0; b < 4; b++) s += sad8[((nd - 1) * 4 + b) * spanx * spany + p];
+                else s = sad8[(nd - 5) * spanx * spany + p];
+                uint32_t c = (s << 4) + (uint32_t)(lam * (orc_mvd_bits(4 * dx) + orc_mvd_bits(4 * dy)));
+                uint64_t key = ((uint64_t)c << 16) | (uint32_t)p;
+                if (key < best) best = key;
+            }
+        int p = (int)(best & 0xffff);
+        mvx[nd] = 4 * (sx + p % spanx - R); mvy[nd] = 4 * (sy + p / spanx - R);
+        cost[nd] = (uint32_t)(best >> 16);
+    }
+}
+/* SATD << 4 + lambda * mvd bits of block (bx, by, n) at vector (mx, my) against ref, vectors priced against the search centre (sx, sy) */
+static uint32_t block_cost(const pix *src_y, int src_stride, const pix *ref_y, int ref_stride, int bx, int by, int n, int mx, int my, int sx, int sy, int bd, int lam)
+{
+    pix pred[32 * 32];
+    orc_interp_luma(ref_y, ref_stride, bx, by, mx, my, n, n, bd, pred, n);
+    return ((uint32_t)orc_satd(src_y + by * src_stride + bx, src_stride, pred, n, n, n) << 4) + (uint32_t)(lam * (orc_mvd_bits(mx - 4 * sx) + orc_mvd_bits(my - 4 * sy)));
+}
+/* half- then quarter-sample ring around (*mx, *my) whose cost is *c: the fractional refinement of orc_analyze_inter_frame */
+static void refine_fraction(const pix *src_y, int src_stride, const pix *ref_y, int ref_stride, int bx, int by, int n, int sx, int sy, int bd, int lam, int *mx, int *my, uint32_t *c)
+{
+    for (int step = 2; step >= 1; step--) {
+        uint64_t best = ((uint64_t)*c << 4) | 0;
+        for (int k = 0; k < 8; k++) {
+            int tx = *mx + kFracOff[k][0] * step, ty = *my + kFracOff[k][1] * step;
+            uint32_t cc = block_cost(src_y, src_stride, ref_y, ref_stride, bx, by, n, tx, ty, sx, sy, bd, lam);
+            uint64_t key = ((uint64_t)cc << 4) | (uint32_t)(k + 1);
+            if (key < best) best = key;
+        }
+        int k = (int)(best & 15);
+        if (k) { *mx += kFracOff[k - 1][0] * step; *my += kFracOff[k - 1][1] * step; }
+        *c = (uint32_t)(best >> 4);
+    }
+}
+
+void orc_analyze_b_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                         const pix *ref0_y, const pix *ref0_u, const pix *ref0_v, const pix *ref1_y, const pix *ref1_u, const pix *ref1_v,
+                         int ref_stride, int ref_cstride, int w, int h, const orc_params *prm, const int16_t *centers0, const int16_t *centers1,
+                         pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                         orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump0, int32_t *me_dump1, uint64_t *est)
+{
+    const int R = prm->me_range, spany = 2 * R + 1, spanx = (spany + 3) & ~3, bd = prm->bit_depth, lam = prm->lambda_sad_q4;
+    const int wc = (w + ORC_CTU - 1) / ORC_CTU, hc = (h + ORC_CTU - 1) / ORC_CTU, w8 = w >> 3;
+    uint32_t *sad8 = (uint32_t *)malloc(sizeof(uint32_t) * 16 * spanx * spany);
+    const pix *refy[2] = {ref0_y, ref1_y}, *refu[2] = {ref0_u, ref1_u}, *refv[2] = {ref0_v, ref1_v};
+    const int16_t *cen[2] = {centers0, centers1};
+    int32_t *dump[2] = {me_dump0, me_dump1};
+    for (int cy = 0; cy < hc; cy++)
+        for (int cx = 0; cx < wc; cx++) {
+            const int ctu = cy * wc + cx, x0 = cx * ORC_CTU, y0 = cy * ORC_CTU;
+            int valid[21], nx[21], ny[21], nl[21];
+            for (int nd = 0; nd < 21; nd++) {
+                node_geom(nd, &nx[nd], &ny[nd], &nl[nd]);
+                valid[nd] = x0 + nx[nd] + (1 << nl[nd]) <= w && y0 + ny[nd] + (1 << nl[nd]) <= h;
+            }
+            int mvx[2][21], mvy[2][21], sx[2], sy[2];
+            uint32_t cost[2][21];
+            for (int l = 0; l < 2; l++) {
+                sx[l] = cen[l] ? cen[l][2 * ctu] : 0; sy[l] = cen[l] ? cen[l][2 * ctu + 1] : 0;
+                ctu_integer_search(src_y, src_stride, refy[l], ref_stride, x0, y0, sx[l], sy[l], R, bd, lam, valid, nx, ny, sad8, mvx[l], mvy[l], cost[l]);
+                if (dump[l])
+                    for (int nd = 0; nd < 21; nd++) {
+                        dump[l][(ctu * 21 + nd) * 3 + 0] = valid[nd] ? mvx[l][nd] : 0;
+                        dump[l][(ctu * 21 + nd) * 3 + 1] = valid[nd] ? mvy[l][nd] : 0;
+                        dump[l][(ctu * 21 + nd) * 3 + 2] = valid[nd] ? (int32_t)cost[l][nd] : -1;
+                    }
+            }
+            /* quadtree on the list-0 search, as in a P picture */
+            uint32_t J[21], cint[21];
+            for (int nd = 0; nd < 21; nd++) {
+                J[nd] = cint[nd] = 0;
+                if (!valid[nd]) continue;
+                cint[nd] = block_cost(src_y, src_stride, refy[0], ref_stride, x0 + nx[nd], y0 + ny[nd], 1 << nl[nd], mvx[0][nd], mvy[0][nd], sx[0], sy[0], bd, lam);
+                J[nd] = cint[nd] + (uint32_t)(lam * 4);
+            }
+            int use16[4], use32;
+            uint32_t J16[4];
+            for (int q = 0; q < 4; q++) {
+                uint32_t js = (uint32_t)(lam * 2);
+                for (int s = 0; s < 4; s++) if (valid[5 + 4 * q + s]) js += J[5 + 4 * q + s];
+                use16[q] = valid[1 + q] && J[1 + q] <= js;
+                J16[q] = use16[q] ? J[1 + q] : js;
+            }
+            {
+                uint32_t js = (uint32_t)(lam * 2);
+                for (int q = 0; q < 4; q++) js += J16[q];
+                use32 = valid[0] && J[0] <= js;
+            }
+            for (int nd = 0; nd < 21; nd++) {
+                if (!valid[nd]) continue;
+                int chosen;
+                if (nd == 0) chosen = use32;
+                else if (nd < 5) chosen = !use32 && use16[nd - 1];
+                else chosen = !use32 && !use16[(nd - 5) >> 2];
+                if (!chosen) continue;
+                const int n = 1 << nl[nd], bx = x0 + nx[nd], by = y0 + ny[nd];
+                /* both lists: fractional refinement around the integer vector of THIS node's own search */
+                int mx[2], my[2];
+                uint32_t c[2];
+                for (int l = 0; l < 2; l++) {
+                    mx[l] = mvx[l][nd]; my[l] = mvy[l][nd];
+                    c[l] = l == 0 ? cint[nd] : block_cost(src_y, src_stride, refy[1], ref_stride, bx, by, n, mx[1], my[1], sx[1], sy[1], bd, lam);
+                    refine_fraction(src_y, src_stride, refy[l], ref_stride, bx, by, n, sx[l], sy[l], bd, lam, &mx[l], &my[l], &c[l]);
+                }
+                /* bi-prediction of the two refined vectors */
+                int16_t p14[2][32 * 32];
+                pix pred[32 * 32];
+                for (int l = 0; l < 2; l++) interp14(refy[l], ref_stride, bx, by, mx[l], my[l], n, n, bd, 0, p14[l], n);
+                weighted_default(p14[0], p14[1], n * n, bd, pred);
+                const uint32_t cb = ((uint32_t)orc_satd(src_y + by * src_stride + bx, src_stride, pred, n, n, n) << 4) +
+                                    (uint32_t)(lam * (orc_mvd_bits(mx[0] - 4 * sx[0]) + orc_mvd_bits(my[0] - 4 * sy[0]) + orc_mvd_bits(mx[1] - 4 * sx[1]) + orc_mvd_bits(my[1] - 4 * sy[1])));
+                const uint64_t k0 = (((uint64_t)c[0] + (uint64_t)(lam * 2)) << 2) | 0, k1 = (((uint64_t)c[1] + (uint64_t)(lam * 2)) << 2) | 1, k2 = (((uint64_t)cb + (uint64_t)lam) << 2) | 2;
+                const uint64_t kb = k0 <= k1 ? (k0 <= k2 ? k0 : k2) : (k1 <= k2 ? k1 : k2);
+                const int mode = (int)(kb & 3), use0 = mode != 1, use1 = mode != 0;
+                /* final prediction + residual */
+                int flags = ORC_F_INTER | (use1 ? ORC_F_L1 : 0) | (use0 ? 0 : ORC_F_NOL0);
+                weighted_default(use0 ? p14[0] : NULL, use1 ? p14[1] : NULL, n * n, bd, pred);
+                if (code_tu_inter(src_y + by * src_stride + bx, src_stride, pred, n, rec_y + by * rec_stride + bx, rec_stride, coef_y + by * w + bx, w, nl[nd], prm->qp, bd, prm))
+                    flags |= ORC_F_CBF_Y;
+                for (int ci = 0; ci < 2; ci++) {
+                    const pix *sp = ci ? src_v : src_u;
+                    pix *dp = ci ? rec_v : rec_u, pc[16 * 16];
+                    int16_t *cp = ci ? coef_v : coef_u, c14[2][16 * 16];
+                    for (int l = 0; l < 2; l++)
+                        if (l ? use1 : use0) interp14(ci ? refv[l] : refu[l], ref_cstride, bx / 2, by / 2, mx[l], my[l], n / 2, n / 2, bd, 1, c14[l], n / 2);
+                    weighted_default(use0 ? c14[0] : NULL, use1 ? c14[1] : NULL, (n / 2) * (n / 2), bd, pc);
+                    if (code_tu_inter(sp + (by / 2) * src_cstride + bx / 2, src_cstride, pc, n / 2, dp + (by / 2) * rec_cstride + bx / 2, rec_cstride,
+                                      cp + (by / 2) * (w / 2) + bx / 2, w / 2, nl[nd] - 1, prm->qp_c, bd, prm)) flags |= ci ? ORC_F_CBF_CR : ORC_F_CBF_CB;
+                }
+                for (int yy = 0; yy < n; yy += 8)
+                    for (int xx = 0; xx < n; xx += 8) {
+                        orc_cu_rec *r = &cu[((by + yy) >> 3) * w8 + ((bx + xx) >> 3)];
+                        memset(r, 0, sizeof *r);
+                        r->log2_size = (uint8_t)nl[nd]; r->flags = (uint8_t)flags; r->qp = (uint8_t)prm->qp; r->chroma_mode = 1;
+                        if (use0) { r->mvx = (int16_t)mx[0]; r->mvy = (int16_t)my[0]; }
+                        if (use1) orc_set_mv1(r, mx[1], my[1]);
+                    }
+            }
+        }
+    free(sad8);
+    if (est) *est = estimate_bits(cu, coef_y, coef_u, coef_v, w, h, centers0);
+}
+
+/* ================================================================================================
  * K2 + K3 : intra frame
  * ================================================================================================ */
 typedef struct {
@@ -1350,7 +1557,13 @@ static int edge_bs(const orc_cu_rec *p, const orc_cu_rec *q)
 {
     if (!(p->flags & ORC_F_INTER) || !(q->flags & ORC_F_INTER)) return 2;
     if ((p->flags & ORC_F_CBF_Y) || (q->flags & ORC_F_CBF_Y)) return 1;
-    if (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4) return 1;
+    /* 8.7.2.4, motion: different reference pictures or numbers of vectors -> 1; else a vector component differing by >= 4 quarter samples -> 1.
+     * Every list holds ONE picture and the two lists' pictures differ (the anchors before / after a B picture), so "the same reference pictures"
+     * means "the same lists", and the vectors to compare are those of the same list */
+    const int pu = p->flags & (ORC_F_L1 | ORC_F_NOL0), qu = q->flags & (ORC_F_L1 | ORC_F_NOL0);
+    if (pu != qu) return 1;
+    if (!(pu & ORC_F_NOL0) && (iabs(p->mvx - q->mvx) >= 4 || iabs(p->mvy - q->mvy) >= 4)) return 1;
+    if ((pu & ORC_F_L1) && (iabs(orc_mv1x(p) - orc_mv1x(q)) >= 4 || iabs(orc_mv1y(p) - orc_mv1y(q)) >= 4)) return 1;
     return 0;
 }
 

@@ -49,6 +49,14 @@ typedef struct {
 #define ORC_F_CBF_CB 4
 #define ORC_F_CBF_CR 8
 #define ORC_F_NXN 16
+#define ORC_F_L1 32      /* inter CU of a B picture: list 1 is used; its vector lives in intra_mode[0..3] (unused by inter CUs) as two little-endian int16 */
+#define ORC_F_NOL0 64    /* inter CU of a B picture: list 0 is NOT used (L1 only); neither flag: list 0 only, as in P pictures; ORC_F_L1 alone: bi-prediction */
+static inline int orc_mv1x(const orc_cu_rec *r) { return (int16_t)(r->intra_mode[0] | (r->intra_mode[1] << 8)); }
+static inline int orc_mv1y(const orc_cu_rec *r) { return (int16_t)(r->intra_mode[2] | (r->intra_mode[3] << 8)); }
+static inline void orc_set_mv1(orc_cu_rec *r, int x, int y)
+{
+    r->intra_mode[0] = (uint8_t)(x & 255); r->intra_mode[1] = (uint8_t)((x >> 8) & 255); r->intra_mode[2] = (uint8_t)(y & 255); r->intra_mode[3] = (uint8_t)((y >> 8) & 255);
+}
 
 typedef struct {
     uint8_t type[2];      /* [0] luma, [1] chroma: 0 off, 1 band, 2 edge */
@@ -116,6 +124,16 @@ void orc_analyze_inter_frame(const pix *src_y, const pix *src_u, const pix *src_
                              orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v,
                              int32_t *me_dump /* optional: per CTU 21*(mvx,mvy,cost) after integer search, or NULL */,
                              uint64_t *est /* optional: picture rate estimate in 1/16 bit */);
+/* K1+K3 for a B picture between two anchors: ref0_* = the anchor before it in display order (list 0), ref1_* = the one after it (list 1), both padded.
+ * The quadtree is decided on the list-0 search exactly as in a P picture; every CU of the tree then also refines its list-1 vector and tries the
+ * bi-prediction of the two refined vectors (8.5.3.3.4.2 default weighted average of the 14-bit predictions), and takes the cheapest of
+ * SATD << 4 + lambda * (mvd bits + inter_pred_idc bins): list 0 (2 bins), list 1 (2), both (1); ties in that order.  centers0 / centers1: search
+ * centres against the two anchors.  me_dump0 / me_dump1 as me_dump above. */
+void orc_analyze_b_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
+                         const pix *ref0_y, const pix *ref0_u, const pix *ref0_v, const pix *ref1_y, const pix *ref1_u, const pix *ref1_v,
+                         int ref_stride, int ref_cstride, int w, int h, const orc_params *prm, const int16_t *centers0, const int16_t *centers1,
+                         pix *rec_y, pix *rec_u, pix *rec_v, int rec_stride, int rec_cstride,
+                         orc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump0, int32_t *me_dump1, uint64_t *est);
 /* 1/4-size picture: every sample the rounded mean of a 4x4 luma block reduced to 8 bits (w, h multiples of 4) */
 void orc_lowres(const pix *src, int stride, int w, int h, int bit_depth, pix *dst /* (w/4) x (h/4), stride w/4 */);
 /* per CTU search centre (integer luma samples, 2 per CTU) from a +-14 full search of its 8x8 low-resolution block */
