@@ -91,8 +91,8 @@ void write_vps(const mihevc_config &c, std::vector<uint8_t> &out)
     w.put(0xffff, 16);
     profile_tier_level(w, c);
     w.put1(1);            // vps_sub_layer_ordering_info_present_flag
-    w.ue(1);              // vps_max_dec_pic_buffering_minus1: current + one reference
-    w.ue(0);              // vps_max_num_reorder_pics
+    w.ue(c.bframes > 0 ? 2 : 1);   // vps_max_dec_pic_buffering_minus1: current + one reference (+ the second anchor a B picture predicts from)
+    w.ue(c.bframes > 0 ? 1 : 0);   // vps_max_num_reorder_pics: an anchor precedes the B picture in front of it in decoding order
     w.ue(0);              // vps_max_latency_increase_plus1
     w.put(0, 6);          // vps_max_layer_id
     w.ue(0);              // vps_num_layer_sets_minus1
@@ -130,9 +130,9 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
     w.ue((uint32_t)c.bit_depth - 8);
     w.ue(4);              // log2_max_pic_order_cnt_lsb_minus4 -> 8 bits (keyint <= 240)
     w.put1(1);            // sps_sub_layer_ordering_info_present_flag
-    w.ue(1);
-    w.ue(0);
-    w.ue(0);
+    w.ue(c.bframes > 0 ? 2 : 1);   // sps_max_dec_pic_buffering_minus1
+    w.ue(c.bframes > 0 ? 1 : 0);   // sps_max_num_reorder_pics
+    w.ue(0);                       // sps_max_latency_increase_plus1
     w.ue(0);              // log2_min_luma_coding_block_size_minus3 -> 8
     w.ue(kCtuLog2 - 3);   // log2_diff_max_min_luma_coding_block_size -> CTB 32
     w.ue(0);              // log2_min_luma_transform_block_size_minus2 -> 4
@@ -143,11 +143,20 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
     w.put1(0);            // amp_enabled_flag
     w.put1(c.sao != 0);   // sample_adaptive_offset_enabled_flag
     w.put1(0);            // pcm_enabled_flag
+    if (c.bframes > 0) {
+        // three reference picture sets (7.3.7): 0 = {-1} (an anchor right behind its predecessor: the last picture of an even GOP), 1 = {-2} (an anchor
+        // two pictures on), 2 = {-1, +1} (the B picture between two anchors)
+        w.ue(3);          // num_short_term_ref_pic_sets
+        w.ue(1); w.ue(0); w.ue(0); w.put1(1);                                   // set 0: one negative picture, delta -1, used
+        w.put1(0); w.ue(1); w.ue(0); w.ue(1); w.put1(1);                        // set 1: inter_ref_pic_set_prediction_flag 0; one negative picture, delta -2, used
+        w.put1(0); w.ue(1); w.ue(1); w.ue(0); w.put1(1); w.ue(0); w.put1(1);    // set 2: one negative (-1, used), one positive (+1, used)
+    } else {
     w.ue(1);              // num_short_term_ref_pic_sets
     w.ue(1);              //   num_negative_pics
     w.ue(0);              //   num_positive_pics
     w.ue(0);              //   delta_poc_s0_minus1
     w.put1(1);            //   used_by_curr_pic_s0_flag
+    }
     w.put1(0);            // long_term_ref_pics_present_flag
     w.put1(0);            // sps_temporal_mvp_enabled_flag
     w.put1(1);            // strong_intra_smoothing_enabled_flag
@@ -403,19 +412,19 @@ void write_sei_buffering_period(const mihevc_config &c, std::vector<uint8_t> &ou
     append_sei(0, b, out);
 }
 
-void write_sei_pic_timing(const mihevc_config &c, uint32_t au_cpb_removal_delay_minus1, std::vector<uint8_t> &out)
+void write_sei_pic_timing(const mihevc_config &c, uint32_t au_cpb_removal_delay_minus1, std::vector<uint8_t> &out, uint32_t pic_dpb_output_delay)
 {
     if (!hrd_info(c).on) return;
     BitWriter b;                  // frame_field_info_present_flag = 0: only the CPB / DPB delays
     b.put(au_cpb_removal_delay_minus1 & 0xffffffu, 24);
-    b.put(0, 5);                  // pic_dpb_output_delay: no reordering
+    b.put(pic_dpb_output_delay & 31u, 5);      // clock ticks between removal from the CPB and output: 0 without reordering
     append_sei(1, b, out);
 }
 
 void write_aud(int slice_type, std::vector<uint8_t> &out)
 {
     BitWriter w;
-    w.put(slice_type == 2 ? 0u : 1u, 3);   // pic_type: 0 = I, 1 = P,I
+    w.put(slice_type == 2 ? 0u : slice_type == 1 ? 1u : 2u, 3);   // pic_type: 0 = I, 1 = P,I, 2 = B,P,I
     w.trailing();
     append_nal(out, 35, w.bytes());
 }
@@ -451,10 +460,10 @@ const uint8_t kNextLps[64] = {0, 0, 1, 2, 2, 4, 4, 5, 6, 7, 8, 9, 9, 11, 11, 12,
 enum Ctx {
     kSaoMerge = 0, kSaoType = 1, kSplitCu = 2, kSkip = 5, kPredMode = 8, kPartMode = 9, kPrevIntra = 13, kChromaMode = 14,
     kRqtRoot = 15, kMergeFlag = 16, kMergeIdx = 17, kMvp = 18, kSplitTu = 19, kCbfLuma = 22, kCbfChroma = 24, kMvdG0 = 29, kMvdG1 = 30,
-    kLastX = 31, kLastY = 49, kCsbf = 67, kSig = 71, kG1 = 115, kG2 = 139, kCtxCount = 145
+    kLastX = 31, kLastY = 49, kCsbf = 67, kSig = 71, kG1 = 115, kG2 = 139, kInterDir = 145, kCtxCount = 150
 };
 constexpr uint8_t U = 154;   // unused in this slice type
-// initValue per context for initType 0 (I slices) and 1 (P slices, cabac_init_flag = 0)
+// initValue per context for initType 0 (I slices), 1 (P slices) and 2 (B slices), cabac_init_flag = 0 (Tables 9-5 .. 9-37)
 const uint8_t kInitI[kCtxCount] = {
     153, 200, 139, 141, 157, U, U, U, U, 184, U, U, U, 184, 63, U, U, U, U, 153, 138, 138, 111, 141, 94, 138, 182, 154, 154, U, U,
     110, 110, 124, 125, 140, 153, 125, 127, 140, 109, 111, 143, 127, 111, 79, 108, 123, 63,
@@ -463,7 +472,8 @@ const uint8_t kInitI[kCtxCount] = {
     111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
     140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 141, 111,
     140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-    138, 153, 136, 167, 152, 152};
+    138, 153, 136, 167, 152, 152,
+    U, U, U, U, U};
 const uint8_t kInitP[kCtxCount] = {
     153, 185, 107, 139, 126, 197, 185, 201, 149, 154, 139, 154, 154, 154, 152, 79, 110, 122, 168, 124, 138, 94, 153, 111, 149, 107, 167, 154, 154, 140, 198,
     125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
@@ -472,15 +482,26 @@ const uint8_t kInitP[kCtxCount] = {
     155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
     170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
     154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-    107, 167, 91, 122, 107, 167};
+    107, 167, 91, 122, 107, 167,
+    95, 79, 63, 31, 31};
+const uint8_t kInitB[kCtxCount] = {
+    153, 160, 107, 139, 126, 197, 185, 201, 134, 154, 139, 154, 154, 183, 152, 79, 154, 137, 168, 224, 167, 122, 153, 111, 149, 92, 167, 154, 154, 169, 198,
+    125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
+    125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
+    121, 140, 61, 154,
+    170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
+    170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
+    154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
+    107, 167, 91, 107, 107, 167,
+    95, 79, 63, 31, 31};
 
 class Cabac {
 public:
     explicit Cabac(std::vector<uint8_t> &out) : out_p_(&out) {}
     void redirect(std::vector<uint8_t> &out) { out_p_ = &out; }
-    void init(bool intra_slice, int qp)
+    void init(int slice_type, int qp)          // slice_type 2 = I, 1 = P, 0 = B
     {
-        const uint8_t *iv = intra_slice ? kInitI : kInitP;
+        const uint8_t *iv = slice_type == 2 ? kInitI : slice_type == 1 ? kInitP : kInitB;
         qp = std::min(51, std::max(0, qp));
         for (int i = 0; i < kCtxCount; i++) {
             int m = (iv[i] >> 4) * 5 - 45, n = ((iv[i] & 15) << 3) - 16;
@@ -616,6 +637,11 @@ struct Scans {
 };
 const Scans kScans;
 
+// motion of a prediction block: which lists it uses and their vectors (every list holds one picture: reference indices are always 0)
+struct Mot {
+    int ok, f0, f1, x0, y0, x1, y1;
+    bool same(const Mot &o) const { return f0 == o.f0 && f1 == o.f1 && (!f0 || (x0 == o.x0 && y0 == o.y0)) && (!f1 || (x1 == o.x1 && y1 == o.y1)); }
+};
 struct Mv { int ok, x, y; };
 
 class SliceCoder {
@@ -637,7 +663,7 @@ public:
     size_t run_tile(int tx, int ty, std::vector<uint8_t> &out)
     {
         cabac_.redirect(out);
-        cabac_.init(pic_.slice_type == 2, pic_.qp);
+        cabac_.init(pic_.slice_type, pic_.qp);
         const bool last_tile = tx == grid_.cols - 1 && ty == grid_.rows - 1;
         const int x1 = grid_.col_bd(tx + 1), y1 = grid_.row_bd(ty + 1);
         for (int ry = grid_.row_bd(ty); ry < y1; ry++)
@@ -739,40 +765,80 @@ private:
         coding_unit(x0, y0, log2n);
     }
 
-    Mv nb(int xc, int yc, int xn, int yn) const
+    static Mot motion_of(const mihevc_cu_rec &r)
     {
-        Mv m{0, 0, 0};
+        Mot m{1, !(r.flags & F_NOL0), (r.flags & F_L1) != 0, 0, 0, 0, 0};
+        if (m.f0) { m.x0 = r.mvx; m.y0 = r.mvy; }
+        if (m.f1) { m.x1 = (int16_t)(r.intra_mode[0] | (r.intra_mode[1] << 8)); m.y1 = (int16_t)(r.intra_mode[2] | (r.intra_mode[3] << 8)); }
+        return m;
+    }
+    Mot nb(int xc, int yc, int xn, int yn) const
+    {
+        Mot m{0, 0, 0, 0, 0, 0, 0};
         if (!avail(xc, yc, xn, yn)) return m;
         const mihevc_cu_rec &r = cu(xn, yn);
         if (!(r.flags & F_INTER)) return m;
-        m.ok = 1; m.x = r.mvx; m.y = r.mvy;
-        return m;
+        return motion_of(r);
     }
-    static bool same_mv(const Mv &a, const Mv &b) { return a.ok && b.ok && a.x == b.x && a.y == b.y; }
-    // 8.5.3.2.2 - 8.5.3.2.5 (spatial + zero candidates; P slices with one reference picture)
-    void merge_list(int x, int y, int n, Mv out[kMaxMergeCand]) const
+    static bool same_mot(const Mot &a, const Mot &b) { return a.ok && b.ok && a.same(b); }
+    // 8.5.3.2.2 - 8.5.3.2.5: spatial candidates, (B slices) combined bi-predictive candidates, zero candidates; no temporal candidate
+    // (sps_temporal_mvp_enabled_flag = 0).  One reference picture per list, so every reference index is 0.
+    void merge_list(int x, int y, int n, Mot out[kMaxMergeCand]) const
     {
-        Mv a1 = nb(x, y, x - 1, y + n - 1), b1 = nb(x, y, x + n - 1, y - 1), b0 = nb(x, y, x + n, y - 1);
-        Mv a0 = nb(x, y, x - 1, y + n), b2 = nb(x, y, x - 1, y - 1);
-        int fa1 = a1.ok, fb1 = b1.ok && !same_mv(b1, a1), fb0 = b0.ok && !same_mv(b0, b1), fa0 = a0.ok && !same_mv(a0, a1);
-        int fb2 = b2.ok && !same_mv(b2, a1) && !same_mv(b2, b1) && (fa0 + fa1 + fb0 + fb1 != 4);
-        const Mv *order[5] = {&a1, &b1, &b0, &a0, &b2};
+        const bool bslice = pic_.slice_type == 0;
+        Mot a1 = nb(x, y, x - 1, y + n - 1), b1 = nb(x, y, x + n - 1, y - 1), b0 = nb(x, y, x + n, y - 1);
+        Mot a0 = nb(x, y, x - 1, y + n), b2 = nb(x, y, x - 1, y - 1);
+        int fa1 = a1.ok, fb1 = b1.ok && !same_mot(b1, a1), fb0 = b0.ok && !same_mot(b0, b1), fa0 = a0.ok && !same_mot(a0, a1);
+        int fb2 = b2.ok && !same_mot(b2, a1) && !same_mot(b2, b1) && (fa0 + fa1 + fb0 + fb1 != 4);
+        const Mot *order[5] = {&a1, &b1, &b0, &a0, &b2};
         const int flag[5] = {fa1, fb1, fb0, fa0, fb2};
         int k = 0;
         for (int i = 0; i < 5 && k < kMaxMergeCand; i++) if (flag[i]) out[k++] = *order[i];
-        while (k < kMaxMergeCand) out[k++] = Mv{1, 0, 0};
+        if (bslice && k > 1 && k < kMaxMergeCand) {       // 8.5.3.2.4: list-0 motion of one candidate with list-1 motion of another
+            static const uint8_t l0c[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1c[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+            const int orig = k;
+            for (int c = 0; c < orig * (orig - 1) && k < kMaxMergeCand; c++) {
+                const Mot &p = out[l0c[c]], &q = out[l1c[c]];
+                // (the two lists hold different pictures, so DiffPicOrderCnt(RefPicList0[0], RefPicList1[0]) != 0 and the vectors need not differ)
+                if (p.f0 && q.f1) out[k++] = Mot{1, 1, 1, p.x0, p.y0, q.x1, q.y1};
+            }
+        }
+        while (k < kMaxMergeCand) out[k++] = Mot{1, 1, bslice ? 1 : 0, 0, 0, 0, 0};      // 8.5.3.2.5 (numRefIdx = 1: every zero candidate has reference index 0)
     }
-    // 8.5.3.2.6 - 8.5.3.2.7
-    void amvp_list(int x, int y, int n, Mv out[2]) const
+    // 8.5.3.2.6 - 8.5.3.2.7 for list X: spatial candidates; a neighbour's vector into the OTHER list's picture is scaled by the ratio of the picture order
+    // count distances (8.5.3.2.7 equations for tx / distScaleFactor), here always -1: the two lists' pictures sit one picture before and after this one
+    Mv amvp_pick(const Mot &m, int lx, bool scaled_pass) const
     {
-        Mv a0 = nb(x, y, x - 1, y + n), a1 = nb(x, y, x - 1, y + n - 1);
-        Mv b0 = nb(x, y, x + n, y - 1), b1 = nb(x, y, x + n - 1, y - 1), b2 = nb(x, y, x - 1, y - 1);
-        bool scaled = a0.ok || a1.ok;
-        Mv a = a0.ok ? a0 : a1, b = b0.ok ? b0 : b1.ok ? b1 : b2;
+        if (!m.ok) return Mv{0, 0, 0};
+        const int fx = lx ? m.f1 : m.f0, fy = lx ? m.f0 : m.f1;
+        if (!scaled_pass) return fx ? Mv{1, lx ? m.x1 : m.x0, lx ? m.y1 : m.y0} : Mv{0, 0, 0};      // same picture: only the same list's vector qualifies
+        if (fx) return Mv{1, lx ? m.x1 : m.x0, lx ? m.y1 : m.y0};
+        if (fy) return Mv{1, scale_mv(lx ? m.x0 : m.x1), scale_mv(lx ? m.y0 : m.y1)};
+        return Mv{0, 0, 0};
+    }
+    static int scale_mv(int v)      // td = -tb = +-1: tx = (16384 + (|td| >> 1)) / td, distScaleFactor = clip3(-4096, 4095, (tb * tx + 32) >> 6) = -256
+    {
+        const int dsf = -256, p = dsf * v;
+        const int r = (std::abs(p) + 127) >> 8;
+        return std::min(32767, std::max(-32768, p < 0 ? -r : r));
+    }
+    void amvp_list(int x, int y, int n, int lx, Mv out[2]) const
+    {
+        const Mot a0 = nb(x, y, x - 1, y + n), a1 = nb(x, y, x - 1, y + n - 1);
+        const Mot b0 = nb(x, y, x + n, y - 1), b1 = nb(x, y, x + n - 1, y - 1), b2 = nb(x, y, x - 1, y - 1);
+        const bool scaled = a0.ok || a1.ok;      // isScaledFlagLX (6.4.2 availability already excludes intra neighbours)
+        Mv a{0, 0, 0}, b{0, 0, 0};
+        for (const Mot *m : {&a0, &a1}) if (!a.ok) a = amvp_pick(*m, lx, false);
+        for (const Mot *m : {&a0, &a1}) if (!a.ok) a = amvp_pick(*m, lx, true);
+        for (const Mot *m : {&b0, &b1, &b2}) if (!b.ok) b = amvp_pick(*m, lx, false);
         if (!scaled && b.ok) a = b;
+        if (!scaled) {
+            b = Mv{0, 0, 0};
+            for (const Mot *m : {&b0, &b1, &b2}) if (!b.ok) b = amvp_pick(*m, lx, true);
+        }
         int k = 0;
         if (a.ok) out[k++] = a;
-        if (b.ok && !same_mv(a, b)) out[k++] = b;
+        if (b.ok && !(a.ok && a.x == b.x && a.y == b.y)) out[k++] = b;
         while (k < 2) out[k++] = Mv{1, 0, 0};
     }
     static int mvd_bits(int d)
@@ -838,12 +904,13 @@ private:
         bool inter = r.flags & F_INTER, nxn = r.flags & F_NXN;
         int cbf_any = r.flags & (F_CBF_Y | F_CBF_CB | F_CBF_CR);
         if (pic_.slice_type != 2) {
-            Mv ml[kMaxMergeCand];
+            Mot ml[kMaxMergeCand];
             int merge_idx = -1;
+            const Mot mine = inter ? motion_of(r) : Mot{0, 0, 0, 0, 0, 0, 0};
             if (inter) {
                 merge_list(x0, y0, n, ml);
                 for (int i = 0; i < kMaxMergeCand; i++)
-                    if (ml[i].x == r.mvx && ml[i].y == r.mvy) { merge_idx = i; break; }
+                    if (ml[i].same(mine)) { merge_idx = i; break; }
             }
             bool skip = inter && merge_idx >= 0 && !cbf_any;
             int l = avail(x0, y0, x0 - 1, y0) && skip_[(y0 >> 3) * w8_ + ((x0 - 1) >> 3)];
@@ -859,13 +926,22 @@ private:
                 if (merge_idx >= 0) {
                     code_merge_idx(merge_idx);                   // rqt_root_cbf inferred 1 (cbf_any is set, else skip)
                 } else {
-                    Mv al[2];
-                    amvp_list(x0, y0, n, al);
-                    int c0 = mvd_bits(r.mvx - al[0].x) + mvd_bits(r.mvy - al[0].y);
-                    int c1 = mvd_bits(r.mvx - al[1].x) + mvd_bits(r.mvy - al[1].y);
-                    int f = c1 < c0;
-                    code_mvd(r.mvx - al[f].x, r.mvy - al[f].y);
-                    cabac_.bin(kMvp, f);
+                    if (pic_.slice_type == 0) {                  // inter_pred_idc (9.3.4.2.2: first bin by CtDepth, nPbW + nPbH != 12 here)
+                        const bool bi = mine.f0 && mine.f1;
+                        cabac_.bin(kInterDir + (kCtuLog2 - log2n), bi);
+                        if (!bi) cabac_.bin(kInterDir + 4, mine.f1);
+                    }
+                    for (int lx = 0; lx < 2; lx++) {             // ref_idx_lX absent (one picture per list), mvd_coding, mvp_lX_flag
+                        if (!(lx ? mine.f1 : mine.f0)) continue;
+                        const int mx = lx ? mine.x1 : mine.x0, my = lx ? mine.y1 : mine.y0;
+                        Mv al[2];
+                        amvp_list(x0, y0, n, lx, al);
+                        int c0 = mvd_bits(mx - al[0].x) + mvd_bits(my - al[0].y);
+                        int c1 = mvd_bits(mx - al[1].x) + mvd_bits(my - al[1].y);
+                        int f = c1 < c0;
+                        code_mvd(mx - al[f].x, my - al[f].y);
+                        cabac_.bin(kMvp, f);
+                    }
                     cabac_.bin(kRqtRoot, cbf_any != 0);
                 }
                 if (cbf_any) transform_tree(x0, y0, x0, y0, log2n, 0, 0, r, 0, 0);
@@ -1117,10 +1193,13 @@ void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const st
         while ((1 << nb) < wc * hc) nb++;
         w.put((uint32_t)(slice_first_row(cfg, cfg.slice_index) * wc), nb);
     }
-    w.ue((uint32_t)pic.slice_type);  // 2 = I, 1 = P
+    w.ue((uint32_t)pic.slice_type);  // 2 = I, 1 = P, 0 = B
     if (!idr) {
         w.put((uint32_t)pic.poc & 0xff, 8);   // slice_pic_order_cnt_lsb
-        w.put1(1);                   // short_term_ref_pic_set_sps_flag (one set: no index bits)
+        w.put1(1);                   // short_term_ref_pic_set_sps_flag
+        // short_term_ref_pic_set_idx, Ceil(Log2(num_short_term_ref_pic_sets)) bits: none with one set; with B pictures (three sets) the set follows from the
+        // picture's place in its GOP: B pictures sit at odd positions between two anchors, an anchor at an odd position follows its predecessor directly
+        if (cfg.bframes > 0) w.put(pic.slice_type == 0 ? 2u : (pic.poc & 1) ? 0u : 1u, 2);
     }
     if (cfg.sao != 0) {
         w.put1(pic.sao != nullptr);  // slice_sao_luma_flag
@@ -1128,6 +1207,7 @@ void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const st
     }
     if (!idr) {
         w.put1(0);                   // num_ref_idx_active_override_flag
+        if (pic.slice_type == 0) w.put1(0);   // mvd_l1_zero_flag
         w.ue(5 - kMaxMergeCand);     // five_minus_max_num_merge_cand
     }
     w.se(pic.qp - 26);               // slice_qp_delta
@@ -1164,7 +1244,7 @@ void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const st
     for (const auto &v : sub) total += v.size();
     rbsp.reserve(total);
     for (const auto &v : sub) rbsp.insert(rbsp.end(), v.begin(), v.end());
-    append_nal(out, idr ? 19 : 1, rbsp);
+    append_nal(out, idr ? 19 : pic.slice_type == 0 ? 0 : 1, rbsp);      // IDR_W_RADL, TRAIL_N (a B picture is never a reference), TRAIL_R
 }
 
 size_t encode_picture(const mihevc_config &cfg, const PictureSyms &pic, std::vector<uint8_t> &out, bool with_aud)

@@ -16,7 +16,7 @@ constexpr int kCtuLog2 = 5;
 constexpr int kCtu = 32;
 constexpr int kMaxMergeCand = 5;
 
-enum : uint8_t { F_INTER = 1, F_CBF_Y = 2, F_CBF_CB = 4, F_CBF_CR = 8, F_NXN = 16 };
+enum : uint8_t { F_INTER = 1, F_CBF_Y = 2, F_CBF_CB = 4, F_CBF_CR = 8, F_NXN = 16, F_L1 = 32, F_NOL0 = 64 };      // F_L1 / F_NOL0: inter CUs of B pictures, see mihevc_cu_rec
 
 struct CodedSize {
     int w, h;          // multiples of 8
@@ -85,13 +85,13 @@ struct HrdInfo {
 };
 HrdInfo hrd_info(const mihevc_config &cfg);
 void write_sei_buffering_period(const mihevc_config &cfg, std::vector<uint8_t> &out);
-void write_sei_pic_timing(const mihevc_config &cfg, uint32_t au_cpb_removal_delay_minus1, std::vector<uint8_t> &out);
+void write_sei_pic_timing(const mihevc_config &cfg, uint32_t au_cpb_removal_delay_minus1, std::vector<uint8_t> &out, uint32_t pic_dpb_output_delay = 0);
 void write_parameter_sets(const mihevc_config &cfg, std::vector<uint8_t> &out);
 
 // One picture's symbols (pointers into pinned host copies of the device outputs).
 struct PictureSyms {
-    int slice_type;      // 2 = I (coded as IDR_W_RADL), 1 = P (TRAIL_R)
-    int poc;             // position in the closed GOP (0 for the IDR)
+    int slice_type;      // 2 = I (coded as IDR_W_RADL), 1 = P (TRAIL_R), 0 = B (TRAIL_N: between two anchors, cfg.bframes)
+    int poc;             // position in the closed GOP in DISPLAY order (0 for the IDR)
     int qp;              // slice QP
     const mihevc_cu_rec *cu;      // (h/8) x (w/8)
     const int16_t *coef[3];       // TU-local raster at picture coordinates; strides w, w/2, w/2

@@ -24,7 +24,10 @@ template <typename T> void free_plane(DevPlane<T> &d);
 
 // Per-picture argument blocks live in device memory (one per picture in flight); launches take an array of them
 // and index it with blockIdx.y, so one launch covers every picture of a lock-step batch.
-template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
+// list 0 / 1: against InterArgs::ref / ref1 (B pictures: the anchor after the picture)
+template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range, int list = 0);
+// B pictures: list-0 tree and refinement, list-1 refinement, bi-prediction trial, residual
+template <typename T> hipError_t launch_inter_ctu_b(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
 template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
 // all anti-diagonals of an I picture batch; h_args is the host copy (geometry only), d_args the device array
 // after_plan (optional): recorded between stage A (k_intra_plan, throughput-bound) and the anti-diagonal chain of stage B (latency-bound: other streams' work fits beside it)

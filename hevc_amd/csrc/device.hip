@@ -17,16 +17,19 @@ __device__ __forceinline__ int xcd_remap(int b, int n)
     return (b & 7) * chunk + (b >> 3);
 }
 
-template <typename T> __global__ __launch_bounds__(NT, 5) void k_me_search(const InterArgs<T> *args, int n_ctu)
+// list 1: the search of a B picture against the anchor after it (InterArgs::ref1 / centers1 / me1)
+template <typename T> __global__ __launch_bounds__(NT, 5) void k_me_search(const InterArgs<T> *args, int n_ctu, int list)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ctu = xcd_remap(blockIdx.x, n_ctu);
     if (ctu >= n_ctu) return;
-    const InterArgs<T> &a = args[blockIdx.y];
     MeShared<T> &s = *reinterpret_cast<MeShared<T> *>(smem);
     uint8_t *win = smem + round16(sizeof(MeShared<T>));
     GpuExec ex;
-    me_search_program<T>(ex, s, win, a, ctu);
+    if (list) {
+        const InterArgs<T> a = list1_view(args[blockIdx.y]);
+        me_search_program<T>(ex, s, win, a, ctu);
+    } else me_search_program<T>(ex, s, win, args[blockIdx.y], ctu);
 }
 
 // 4 workgroups per CU (97 / 116 VGPRs for 8 / 10 bit and no scratch since the fractional search runs two lanes per tile; LDS allows 4 at
@@ -47,6 +50,27 @@ template <typename T> __global__ __launch_bounds__(NT, 4) void k_inter_ctu(const
     T *wv = reinterpret_cast<T *>(smem + off);
     GpuExec ex;
     inter_ctu_program<T>(ex, s, wy, wu, wv, a, ctu);
+}
+
+// B pictures: the same CTU program with the list-1 refinement and the bi-prediction trial (BiShared sits behind the windows); 3 workgroups per CU
+template <typename T> __global__ __launch_bounds__(NT, 3) void k_inter_ctu_b(const InterArgs<T> *args, int n_ctu)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int ctu = xcd_remap(blockIdx.x, n_ctu);
+    if (ctu >= n_ctu) return;
+    const InterArgs<T> &a = args[blockIdx.y];
+    const int R = a.prm.me_range;
+    InterShared<T> &s = *reinterpret_cast<InterShared<T> *>(smem);
+    size_t off = round16(sizeof(InterShared<T>));
+    T *wy = reinterpret_cast<T *>(smem + off);
+    off += round16(((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16) * sizeof(T));
+    T *wu = reinterpret_cast<T *>(smem + off);
+    off += round16(((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16) * sizeof(T));
+    T *wv = reinterpret_cast<T *>(smem + off);
+    off += round16(((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16) * sizeof(T));
+    BiShared *b = reinterpret_cast<BiShared *>(smem + off);
+    GpuExec ex;
+    inter_ctu_program<T, GpuExec, true>(ex, s, wy, wu, wv, a, ctu, b);
 }
 
 // stage A of the intra pictures: every CTU of every picture in flight plans its quadtree and modes on the source picture (kernels/intra.h);
@@ -290,13 +314,13 @@ template <typename K> static hipError_t ensure_smem(K kernel, size_t bytes)
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
+template <typename T> hipError_t launch_me_search(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R, int list)
 {
     size_t smem = round16(sizeof(MeShared<T>)) + round16((size_t)me_win_elems(R));      // the window holds 8-bit samples for every T
     hipError_t e = ensure_smem(k_me_search<T>, smem);
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);
-    hipLaunchKernelGGL(k_me_search<T>, grid, dim3(NT), smem, st, d_args, n_ctu);
+    hipLaunchKernelGGL(k_me_search<T>, grid, dim3(NT), smem, st, d_args, n_ctu, list);
     return hipGetLastError();
 }
 
@@ -308,6 +332,17 @@ template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArg
     if (e != hipSuccess) return e;
     dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);
     hipLaunchKernelGGL(k_inter_ctu<T>, grid, dim3(NT), smem, st, d_args, n_ctu);
+    return hipGetLastError();
+}
+
+template <typename T> hipError_t launch_inter_ctu_b(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int R)
+{
+    size_t smem = round16(sizeof(InterShared<T>)) + round16(((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16) * sizeof(T)) +
+                  2 * round16(((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16) * sizeof(T)) + round16(sizeof(BiShared));
+    hipError_t e = ensure_smem(k_inter_ctu_b<T>, smem);
+    if (e != hipSuccess) return e;
+    dim3 grid((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch);
+    hipLaunchKernelGGL(k_inter_ctu_b<T>, grid, dim3(NT), smem, st, d_args, n_ctu);
     return hipGetLastError();
 }
 
@@ -432,7 +467,8 @@ int gfx950_device_count()
 }
 
 #define INSTANTIATE(T)                                                                                                   \
-    template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
+    template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int, int);                     \
+    template hipError_t launch_inter_ctu_b<T>(hipStream_t, const InterArgs<T> *, int, int, int);                        \
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
     template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int, hipEvent_t);     \
     template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                                       \
@@ -639,6 +675,8 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.centers = centers ? dcen.as<int16_t>() : nullptr; a.me = dme.as<int32_t>();
     a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>();
     a.est = dest.as<unsigned long long>(); a.sparse_coef = 0;
+    for (int i = 0; i < 3; i++) a.ref1[i] = {nullptr, 0};
+    a.centers1 = nullptr; a.me1 = nullptr;
     DevBuf dip, diargs;
     a.ip = nullptr;
     if (a.prm.intra_in_p) { CK(dip.alloc((size_t)n_ctu * sizeof(IpInfo))); CK(hipMemset(dip.p, 0, (size_t)n_ctu * sizeof(IpInfo))); a.ip = dip.as<IpInfo>(); }
@@ -653,7 +691,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
         a.centers = dcen.as<int16_t>();
     }
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
-    CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
+    CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range, 0));
     CK(launch_inter_ctu<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
     if (a.prm.intra_in_p) {       // intra second pass on the same reconstruction / records / levels
         IntraArgs<T> ia;

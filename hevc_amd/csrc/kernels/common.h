@@ -35,7 +35,7 @@ constexpr int PAD_C = 40;
 constexpr int NT = 256;       // threads per CTU workgroup
 constexpr int MAX_RANGE = 64;
 
-enum : uint8_t { CU_INTER = 1, CU_CBF_Y = 2, CU_CBF_CB = 4, CU_CBF_CR = 8, CU_NXN = 16 };
+enum : uint8_t { CU_INTER = 1, CU_CBF_Y = 2, CU_CBF_CB = 4, CU_CBF_CR = 8, CU_NXN = 16, CU_L1 = 32, CU_NOL0 = 64 };      // CU_L1 / CU_NOL0: inter CUs of B pictures (include/mihevc.h)
 
 template <typename T> struct PixTraits;
 template <> struct PixTraits<uint8_t> { static constexpr int kBitDepth = 8; };

@@ -30,7 +30,20 @@ template <typename T> struct InterArgs {
     int sparse_coef;             // 1: store levels only for TUs that have a non-zero one (the host coder never reads the others);
                                  //    lets `coef` point at pinned host memory so no 6 MB/picture D2H blit is needed
     IpInfo *ip;                  // per CTU, or nullptr: hand-over to the intra second pass (prm.intra_in_p)
+    // B pictures (cfg.bframes): the anchor AFTER this picture in display order is list 1 (ref is list 0: the anchor before it); its search centres and
+    // integer-search table.  ref1[0].p == nullptr: a P picture
+    Plane<const T> ref1[3];
+    const int16_t *centers1;
+    int32_t *me1;
 };
+// the arguments of the integer search against list 1: the same block with the list-1 planes, centres and table in the list-0 places
+template <typename T> DEV InterArgs<T> list1_view(const InterArgs<T> &a)
+{
+    InterArgs<T> b = a;
+    for (int i = 0; i < 3; i++) b.ref[i] = a.ref1[i];
+    b.centers = a.centers1; b.me = a.me1;
+    return b;
+}
 
 // candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
 DEVCONST int8_t kOff[9][2] = {{0, 0}, {-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
@@ -737,8 +750,55 @@ DEV int chroma_sample(const T *p00, int ws, int fx, int fy, int bit_depth)
     return clip3(0, maxv, ((acc >> 6) + (1 << (shift3 - 1))) >> shift3);
 }
 
-template <typename T, class Ex>
-DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win_v, const InterArgs<T> &a, int ctu)
+// ---- B pictures: the 14-bit intermediate predictions of 8.5.3.3.3 (before the rounding of 8.5.3.3.4.2), four luma samples / one chroma sample
+template <typename T> DEV void luma_quad14(const T *win, int i00, int ws, int fx, int fy, int bit_depth, int (&out)[4])
+{
+    const int8_t *tx = g_tab.luma_tap[fx], *ty = g_tab.luma_tap[fy];
+    const int shift1 = bit_depth - 8;
+    int acc[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        int px[15];
+        load_row15(win, i00 + (r - 3) * ws - 3, px);
+        const int t = ty[r];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v += tx[k] * px[i + k];
+            acc[i] += t * (v >> shift1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) out[i] = acc[i] >> 6;
+}
+template <typename T> DEV int chroma_sample14(const T *p00, int ws, int fx, int fy, int bit_depth)
+{
+    const int8_t *tx = g_tab.chroma_tap[fx], *ty = g_tab.chroma_tap[fy];
+    const int shift1 = bit_depth - 8;
+    int acc = 0;
+    for (int r = 0; r < 4; r++) {
+        const T *row = p00 + (r - 1) * ws - 1;
+        int v = tx[0] * row[0] + tx[1] * row[1] + tx[2] * row[2] + tx[3] * row[3];
+        acc += ty[r] * (v >> shift1);
+    }
+    return acc >> 6;
+}
+// 8.5.3.3.4.2 default weighted sample prediction: one list, or the average of both
+DEV int weighted_uni(int p, int bit_depth) { const int sh = 14 - bit_depth; return clip3(0, (1 << bit_depth) - 1, (p + (1 << (sh - 1))) >> sh); }
+DEV int weighted_bi(int p0, int p1, int bit_depth) { const int sh = 15 - bit_depth; return clip3(0, (1 << bit_depth) - 1, (p0 + p1 + (1 << (sh - 1))) >> sh); }
+// per-CTU state of the list-1 / bi-prediction part of a B picture's CTU program (behind the windows in LDS; P pictures do not carry it)
+struct BiShared {
+    int mx0[21], my0[21];        // refined list-0 vectors (InterShared::mvx / mvy go on to hold list 1)
+    unsigned c0[21], cb[21];     // list-0 cost, bi-prediction SATD sum
+    uint8_t mode[21];            // 0: list 0, 1: list 1, 2: both
+    uint8_t tile_mode[16];
+    int tile_mv1x[16], tile_mv1y[16];
+    alignas(16) int16_t p0[1536];    // the 14-bit list-0 prediction of the CTU (Y, U, V as InterShared::pred), kept while the windows hold list 1
+};
+
+template <typename T, class Ex, bool BI = false>
+DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win_v, const InterArgs<T> &a, int ctu, BiShared *bsh = nullptr)
 {
     const int R0 = a.prm.me_range, R = R0 + 3, bd = a.prm.bit_depth, lam = a.prm.lambda_sad_q4;
     const int x0 = (ctu % a.ctus_w) * CTU, y0 = (ctu / a.ctus_w) * CTU;
@@ -819,7 +879,9 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         s.rs.tu_log2[t] = inside ? (uint8_t)(node == 0 ? 5 : node < 5 ? 4 : 3) : 0;
         s.rs.tu_intra[t] = 0;
     });
-    // fractional refinement of the chosen CUs: half-pel ring, then quarter-pel ring (the centre's cost is known)
+    // fractional refinement of the chosen CUs: half-pel ring, then quarter-pel ring (the centre's cost is known).  csx / csy: the search centre the
+    // vectors are priced against, wox / woy: origin of the luma window in LDS (a B picture refines list 1 with the same code after list 0)
+    auto refine = [&](const int csx, const int csy, const int wox, const int woy) {
     for (int round = 0; round < 2; round++) {
         const int step = round == 0 ? 2 : 1;
         // 16 tiles x 8 ring positions x 2 column halves = the whole workgroup.  Wave-local steps: both lanes of a pair sit in one wave.
@@ -828,7 +890,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             if (!s.rs.tu_log2[t]) return;
             const int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
             const int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
-            const int px = x0 + txp * 8 + 4 * half + (mx >> 2) - oy_x, py = y0 + typ * 8 + (my >> 2) - oy_y;
+            const int px = x0 + txp * 8 + 4 * half + (mx >> 2) - wox, py = y0 + typ * 8 + (my >> 2) - woy;
             int m[8][4];
             luma_half_diff((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8 + 4 * half), 32, m);
             hadamard_half(m);
@@ -875,7 +937,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                     node_geom(tid, nx, ny, nl);
                     if (!mv_rows_ok(y0 + ny, 1 << nl, my, a.h, mct, mcb)) continue;
                 }
-                unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * sx) + mvd_bits(my - 4 * sy)));
+                unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * csx) + mvd_bits(my - 4 * csy)));
                 unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
                 if (key < best) best = key;
             }
@@ -884,6 +946,130 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.cost[tid] = (unsigned)(best >> 4);
         });
     }
+    };
+    refine(sx, sy, oy_x, oy_y);
+    if constexpr (BI) {
+        // ---- B picture (oracle: orc_analyze_b_frame).  The tree and the list-0 vectors stand; every CU of the tree now refines its list-1 vector
+        // (from its own node's integer search against the anchor AFTER this picture), tries the bi-prediction of the two refined vectors and takes the
+        // cheapest of SATD << 4 + lambda * (mvd bits + inter_pred_idc bins): list 0 (2), list 1 (2), both (1); ties in that order.
+        BiShared &b = *bsh;
+        const int sx1 = a.centers1 ? a.centers1[2 * ctu] : 0, sy1 = a.centers1 ? a.centers1[2 * ctu + 1] : 0;
+        const int o1_x = x0 + sx1 - R - 4, o1_y = y0 + sy1 - R - 4;
+        const int oc1_x = (x0 >> 1) + ((4 * sx1 - 4 * R - 3) >> 3) - 1, oc1_y = (y0 >> 1) + ((4 * sy1 - 4 * R - 3) >> 3) - 1;
+        // the 14-bit list-0 prediction of every tile while the list-0 windows are still in LDS (rs.res cannot hold it: it shares its LDS with the
+        // fractional search's scratch area)
+        ex.phase([&](int tid) {
+            if (tid < 21) { b.mx0[tid] = s.mvx[tid]; b.my0[tid] = s.mvy[tid]; b.c0[tid] = s.cost[tid]; b.cb[tid] = 0; }
+            {
+                const int t = tid >> 4, j = (tid >> 1) & 7, hx = (tid & 1) * 4, txp = t & 3, typ = t >> 2;
+                if (s.rs.tu_log2[t]) {
+                    const int node = s.tile_node[t], mx = s.mvx[node], my = s.mvy[node];
+                    const int px = x0 + txp * 8 + hx + (mx >> 2) - oy_x, py = y0 + typ * 8 + j + (my >> 2) - oy_y;
+                    int v[4];
+                    luma_quad14<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, v);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) b.p0[(typ * 8 + j) * 32 + txp * 8 + hx + i] = (int16_t)v[i];
+                }
+            }
+            for (int i = tid; i < 512; i += NT) {
+                const int pl = i >> 8, k = i & 255, x = k & 15, y = k >> 4, t = (y >> 2) * 4 + (x >> 2);
+                if (!s.rs.tu_log2[t]) continue;
+                const int node = s.tile_node[t], mx = s.mvx[node], my = s.mvy[node];
+                const int px = (x0 >> 1) + x + (mx >> 3) - oc_x, py = (y0 >> 1) + y + (my >> 3) - oc_y;
+                b.p0[1024 + i] = (int16_t)chroma_sample14<T>((pl ? win_v : win_u) + py * wcs + px, wcs, mx & 7, my & 7, bd);
+            }
+        });
+        // list-1 windows and integer vectors
+        ex.phase([&](int tid) {
+            copy_window<T>(win_y, wys, a.ref1[0].p, a.ref1[0].stride, o1_x, o1_y, wy, wy, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, tid);
+            copy_window<T>(win_u, wcs, a.ref1[1].p, a.ref1[1].stride, oc1_x, oc1_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
+            copy_window<T>(win_v, wcs, a.ref1[2].p, a.ref1[2].stride, oc1_x, oc1_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
+            if (tid < 21) {
+                const int32_t *m = a.me1 + ((size_t)ctu * 21 + tid) * 3;
+                s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.nsum[tid] = 0;
+            }
+        });
+        ex.phase([&](int tid) {          // SATD of the tree's CUs at their list-1 integer vectors
+            if (tid >= 16 || !s.rs.tu_log2[tid]) return;
+            const int t = tid, txp = t & 3, typ = t >> 2, node = s.tile_node[t];
+            const int px = x0 + txp * 8 + (s.mvx[node] >> 2) - o1_x, py = y0 + typ * 8 + (s.mvy[node] >> 2) - o1_y;
+            ex.atomic_add(&s.nsum[node], (unsigned)luma_tile_int<T>(win_y, py * wys + px, wys, s.src + typ * 8 * 32 + txp * 8, 32));
+        });
+        ex.phase([&](int tid) {
+            if (tid < 21 && s.valid[tid] && s.chosen[tid])
+                s.cost[tid] = (s.nsum[tid] << 4) + (unsigned)(lam * (mvd_bits(s.mvx[tid] - 4 * sx1) + mvd_bits(s.mvy[tid] - 4 * sy1)));
+        });
+        refine(sx1, sy1, o1_x, o1_y);
+        // bi-prediction of the two refined vectors: difference to the source per sample, then one lane per tile takes the 8x8 Hadamard sum
+        ex.phase([&](int tid) {
+            const int t = tid >> 4, j = (tid >> 1) & 7, hx = (tid & 1) * 4, txp = t & 3, typ = t >> 2;
+            if (!s.rs.tu_log2[t]) return;
+            const int node = s.tile_node[t], mx = s.mvx[node], my = s.mvy[node];
+            const int px = x0 + txp * 8 + hx + (mx >> 2) - o1_x, py = y0 + typ * 8 + j + (my >> 2) - o1_y;
+            int v[4];
+            luma_quad14<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, v);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int at = (typ * 8 + j) * 32 + txp * 8 + hx + i;
+                s.rs.scratch[t * 64 + j * 8 + hx + i] = (uint32_t)((int)s.src[at] - weighted_bi((int)b.p0[at], v[i], bd));
+            }
+        });
+        ex.phase([&](int tid) {
+            if (tid >= 16 || !s.rs.tu_log2[tid]) return;
+            int m[8][8];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+#pragma unroll
+                for (int i = 0; i < 8; i++) m[j][i] = (int)s.rs.scratch[tid * 64 + j * 8 + i];
+            ex.atomic_add(&b.cb[s.tile_node[tid]], (unsigned)hadamard8_satd(m));
+        });
+        ex.phase([&](int tid) {
+            if (tid >= 21 || !s.valid[tid] || !s.chosen[tid]) return;
+            const unsigned bits0 = (unsigned)(mvd_bits(b.mx0[tid] - 4 * sx) + mvd_bits(b.my0[tid] - 4 * sy)), bits1 = (unsigned)(mvd_bits(s.mvx[tid] - 4 * sx1) + mvd_bits(s.mvy[tid] - 4 * sy1));
+            const unsigned cbi = (b.cb[tid] << 4) + (unsigned)lam * (bits0 + bits1);
+            const unsigned long long k0 = (((unsigned long long)b.c0[tid] + (unsigned long long)(lam * 2)) << 2) | 0, k1 = (((unsigned long long)s.cost[tid] + (unsigned long long)(lam * 2)) << 2) | 1,
+                                     k2 = (((unsigned long long)cbi + (unsigned long long)lam) << 2) | 2;
+            const unsigned long long kb = k0 <= k1 ? (k0 <= k2 ? k0 : k2) : (k1 <= k2 ? k1 : k2);
+            b.mode[tid] = (uint8_t)(kb & 3);
+        });
+        // final prediction of every CU by its mode: list 0 from the 14-bit samples kept in BiShared::p0, list 1 from the windows, or their average
+        ex.phase([&](int tid) {
+            if (tid < 16) {
+                const int node = s.tile_node[tid], mode = b.mode[node];
+                b.tile_mode[tid] = (uint8_t)mode;
+                s.tile_mvx[tid] = mode != 1 ? b.mx0[node] : 0; s.tile_mvy[tid] = mode != 1 ? b.my0[node] : 0;
+                b.tile_mv1x[tid] = mode != 0 ? s.mvx[node] : 0; b.tile_mv1y[tid] = mode != 0 ? s.mvy[node] : 0;
+            }
+            {
+                const int t = tid >> 4, j = (tid >> 1) & 7, hx = (tid & 1) * 4, txp = t & 3, typ = t >> 2;
+                if (s.rs.tu_log2[t]) {
+                    const int node = s.tile_node[t], mode = b.mode[node], mx = s.mvx[node], my = s.mvy[node];
+                    int v[4] = {0, 0, 0, 0};
+                    if (mode != 0) {
+                        const int px = x0 + txp * 8 + hx + (mx >> 2) - o1_x, py = y0 + typ * 8 + j + (my >> 2) - o1_y;
+                        luma_quad14<T>(win_y, py * wys + px, wys, mx & 3, my & 3, bd, v);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const int at = (typ * 8 + j) * 32 + txp * 8 + hx + i, p0 = (int)b.p0[at];
+                        s.pred[at] = (T)(mode == 0 ? weighted_uni(p0, bd) : mode == 1 ? weighted_uni(v[i], bd) : weighted_bi(p0, v[i], bd));
+                    }
+                }
+            }
+            for (int i = tid; i < 512; i += NT) {
+                const int pl = i >> 8, k = i & 255, x = k & 15, y = k >> 4, t = (y >> 2) * 4 + (x >> 2);
+                if (!s.rs.tu_log2[t]) continue;
+                const int node = s.tile_node[t], mode = b.mode[node], mx = s.mvx[node], my = s.mvy[node], p0 = (int)b.p0[1024 + i];
+                int p1 = 0;
+                if (mode != 0) {
+                    const int px = (x0 >> 1) + x + (mx >> 3) - oc1_x, py = (y0 >> 1) + y + (my >> 3) - oc1_y;
+                    p1 = chroma_sample14<T>((pl ? win_v : win_u) + py * wcs + px, wcs, mx & 7, my & 7, bd);
+                }
+                s.pred[1024 + i] = (T)(mode == 0 ? weighted_uni(p0, bd) : mode == 1 ? weighted_uni(p1, bd) : weighted_bi(p0, p1, bd));
+            }
+        });
+    }
+    if constexpr (!BI)
     ex.phase([&](int tid) {
         if (tid < 16) { s.tile_mvx[tid] = s.mvx[s.tile_node[tid]]; s.tile_mvy[tid] = s.mvy[s.tile_node[tid]]; }
         if (a.ip) {
@@ -893,7 +1079,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     });
     // intra second-pass candidate (oracle: orc_analyze_inter_frame): the inter cost is above 4 per sample AND above the source's
     // own AC activity (8x8 Hadamard without the DC term).  The activity is only computed when the first test passes.
-    if (a.ip && s.ip_cost >= ((4u * 64u * s.ip_tiles) << 4)) {
+    if (!BI && a.ip && s.ip_cost >= ((4u * 64u * s.ip_tiles) << 4)) {
         ex.phase([&](int tid) {
             if (tid >= 16 || !s.rs.tu_log2[tid]) return;
             const T *sp = s.src + (tid >> 2) * 8 * 32 + (tid & 3) * 8;
@@ -906,6 +1092,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         });
     }
     // motion compensation of the chosen CUs: every lane predicts 4 luma samples and 2 chroma samples
+    if constexpr (!BI)
     ex.phase([&](int tid) {
         {
             const int t = tid >> 4, j = (tid >> 1) & 7, hx = (tid & 1) * 4, txp = t & 3, typ = t >> 2;
@@ -1018,6 +1205,11 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             r.chroma_mode = 1; r.qp = (uint8_t)a.prm.qp;
             r.intra_mode[0] = 1; r.intra_mode[1] = r.intra_mode[2] = r.intra_mode[3] = 0;
             r.mvx = (int16_t)s.tile_mvx[t]; r.mvy = (int16_t)s.tile_mvy[t];
+            if constexpr (BI) {        // which lists the CU predicts from; the list-1 vector lives in the bytes inter CUs do not use (include/mihevc.h)
+                const int mode = bsh->tile_mode[t], x1 = bsh->tile_mv1x[t], y1 = bsh->tile_mv1y[t];
+                r.flags |= (uint8_t)((mode != 0 ? CU_L1 : 0) | (mode == 1 ? CU_NOL0 : 0));
+                r.intra_mode[0] = (uint8_t)(x1 & 255); r.intra_mode[1] = (uint8_t)((x1 >> 8) & 255); r.intra_mode[2] = (uint8_t)(y1 & 255); r.intra_mode[3] = (uint8_t)((y1 >> 8) & 255);
+            }
             r.cbf_y4 = 0; r.pad[0] = r.pad[1] = r.pad[2] = 0;
             a.cu[(size_t)((y0 >> 3) + typ) * (a.w >> 3) + (x0 >> 3) + txp] = r;
         }

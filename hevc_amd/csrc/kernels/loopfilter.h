@@ -26,7 +26,16 @@ DEV int edge_bs(const mihevc_cu_rec &p, const mihevc_cu_rec &q)      // 8.7.2.4 
 {
     if (!(p.flags & CU_INTER) || !(q.flags & CU_INTER)) return 2;
     if ((p.flags & CU_CBF_Y) || (q.flags & CU_CBF_Y)) return 1;
-    if (iabs(p.mvx - q.mvx) >= 4 || iabs(p.mvy - q.mvy) >= 4) return 1;
+    // motion: every list holds ONE picture and the two lists' pictures differ, so "the same reference pictures and number of vectors" means "the same
+    // lists", and the vectors to compare are those of the same list (oracle edge_bs)
+    const int pu = p.flags & (CU_L1 | CU_NOL0), qu = q.flags & (CU_L1 | CU_NOL0);
+    if (pu != qu) return 1;
+    if (!(pu & CU_NOL0) && (iabs(p.mvx - q.mvx) >= 4 || iabs(p.mvy - q.mvy) >= 4)) return 1;
+    if (pu & CU_L1) {
+        const int px = (int16_t)(p.intra_mode[0] | (p.intra_mode[1] << 8)), py = (int16_t)(p.intra_mode[2] | (p.intra_mode[3] << 8));
+        const int qx = (int16_t)(q.intra_mode[0] | (q.intra_mode[1] << 8)), qy = (int16_t)(q.intra_mode[2] | (q.intra_mode[3] << 8));
+        if (iabs(px - qx) >= 4 || iabs(py - qy) >= 4) return 1;
+    }
     return 0;
 }
 

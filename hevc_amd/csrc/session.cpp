@@ -721,6 +721,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.sparse_coef = A.inter.sparse_coef = 1;
             A.intra.diagonal = 0;
             A.inter.centers = nullptr; A.inter.me = L.me;
+            for (int i = 0; i < 3; i++) A.inter.ref1[i] = Plane<const T>{nullptr, 0};
+            A.inter.centers1 = nullptr; A.inter.me1 = nullptr;
             if (s->cfg.pre_search) {       // search centres: the chunk's pre-search fills them for every picture (below)
                 const size_t idx = (size_t)(gstart[(size_t)g] + t);
                 PreArgs<T> &P4 = ((PreArgs<T> *)(ha + flat_off))[idx];

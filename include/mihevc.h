@@ -102,6 +102,10 @@ typedef struct mihevc_config {
                                        * under `-threads 0`, core/transcoder.py:410-411).  -1 (default): one tile per 1920x1080 of picture (4320p 4x4, 2160p 2x2, up to
                                        * 1080p-class none: tiles that large cost ~0.2 % bits); 0: off; 1: as -1 but at least 2x2 when the level allows.  Motion
                                        * compensation, deblocking and SAO cross tile boundaries; merge / AMVP candidates and CABAC contexts do not */
+    int32_t bframes;                  /* 0 (default) / 1: every second picture of a closed GOP is a B picture between two anchors (x265 bframes; the reference's
+                                       * preset=slow runs 4 with b-adapt, core/transcoder.py:399): coding order I0 P2 b1 P4 b3 ..., a B picture predicts from the anchor
+                                       * before it (list 0), the one after it (list 1) or both (8.5.3.3.4.2), is never a reference itself (TRAIL_N) and takes QP + 2.
+                                       * Packets come out in DECODING order with pts < dts differences (mihevc_receive_packet), the MP4 writer adds the ctts box */
     int32_t slice_halo;               /* slice_count > 1 only.  1: the sessions of one picture's slices EXCHANGE rows (they find each other through slice_group and must
                                        * live in one process): the PAD rows of the final reconstruction either side of every seam, so motion vectors cross seams as in a
                                        * whole picture, and 8 rows of the pre-deblock reconstruction + one row of CU records, so deblocking and SAO run across the seams
@@ -198,7 +202,8 @@ int  mihevc_p_tile_grid(const mihevc_config *cfg, int *cols, int *rows);
 /* per-8x8-block record produced by the analysis kernels and consumed by deblocking and the host entropy coder */
 typedef struct mihevc_cu_rec {
     uint8_t log2_size;     /* CU size 3..5 (CU = PU = TU except intra NxN) */
-    uint8_t flags;         /* bit0 inter, bit1 cbf_y, bit2 cbf_cb, bit3 cbf_cr, bit4 intra NxN */
+    uint8_t flags;         /* bit0 inter, bit1 cbf_y, bit2 cbf_cb, bit3 cbf_cr, bit4 intra NxN; inter CUs of B pictures: bit5 list 1 is used (its vector: two
+                            * little-endian int16 in intra_mode[0..3], which inter CUs do not use), bit6 list 0 is NOT used; neither: list 0 only (P pictures) */
     uint8_t chroma_mode;   /* chroma intra prediction mode 0..34 */
     uint8_t qp;
     uint8_t intra_mode[4];
@@ -245,7 +250,7 @@ int mihevc_k_sao(int device, const void *src_y, const void *src_u, const void *s
 /* VPS+SPS+PPS (+SEI when hdr10) as Annex-B into buf; returns size or negative error */
 int mihevc_write_parameter_sets(const mihevc_config *cfg, uint8_t *buf, size_t cap);
 /* CABAC-code one picture from its symbols into one slice NAL (+AUD when cfg->aud); returns size or negative error.
- * slice_type 2 = I (IDR), 1 = P; poc = position inside the closed GOP. */
+ * slice_type 2 = I (IDR), 1 = P, 0 = B (cfg->bframes); poc = position inside the closed GOP in display order. */
 int mihevc_encode_picture_host(const mihevc_config *cfg, int slice_type, int poc, int qp,
                                const mihevc_cu_rec *cu, const int16_t *coef_y, const int16_t *coef_u, const int16_t *coef_v,
                                const mihevc_sao_ctu *sao, uint8_t *buf, size_t cap);

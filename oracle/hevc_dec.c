@@ -69,7 +69,7 @@ enum {
     CX_SAO_MERGE = 0, CX_SAO_TYPE = 1, CX_SPLIT_CU = 2, CX_SKIP = 5, CX_PRED_MODE = 8, CX_PART_MODE = 9, CX_PREV_INTRA = 13,
     CX_CHROMA_MODE = 14, CX_RQT_ROOT = 15, CX_MERGE_FLAG = 16, CX_MERGE_IDX = 17, CX_MVP = 18, CX_SPLIT_TU = 19, CX_CBF_LUMA = 22,
     CX_CBF_CHROMA = 24, CX_MVD0 = 29, CX_MVD1 = 30, CX_LAST_X = 31, CX_LAST_Y = 49, CX_CSBF = 67, CX_SIG = 71, CX_G1 = 115,
-    CX_G2 = 139, CX_QP_DELTA = 145, CX_COUNT = 147
+    CX_G2 = 139, CX_QP_DELTA = 145, CX_INTER_DIR = 147, CX_COUNT = 152
 };
 #define CNU 154
 static const uint8_t kInit[3][CX_COUNT] = {
@@ -81,7 +81,7 @@ static const uint8_t kInit[3][CX_COUNT] = {
       111, 111, 125, 110, 110, 94, 124, 108, 124, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125, 107, 125, 141, 179, 153, 125,
       140, 139, 182, 182, 152, 136, 152, 136, 153, 136, 139, 111, 136, 139, 111, 141, 111,
       140, 92, 137, 138, 140, 152, 138, 139, 153, 74, 149, 92, 139, 107, 122, 152, 140, 179, 166, 182, 140, 227, 122, 197,
-      138, 153, 136, 167, 152, 152, 154, 154},
+      138, 153, 136, 167, 152, 152, 154, 154, CNU, CNU, CNU, CNU, CNU},
     { /* P */ 153, 185, 107, 139, 126, 197, 185, 201, 149, 154, 139, 154, 154, 154, 152, 79, 110, 122, 168, 124, 138, 94, 153, 111,
       149, 107, 167, 154, 154, 140, 198,
       125, 110, 94, 110, 95, 79, 125, 111, 110, 78, 110, 111, 111, 95, 94, 108, 123, 108,
@@ -90,7 +90,7 @@ static const uint8_t kInit[3][CX_COUNT] = {
       155, 154, 139, 153, 139, 123, 123, 63, 153, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
       170, 153, 123, 123, 107, 121, 107, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
       154, 196, 196, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 137, 169, 194, 166, 167, 154, 167, 137, 182,
-      107, 167, 91, 122, 107, 167, 154, 154},
+      107, 167, 91, 122, 107, 167, 154, 154, 95, 79, 63, 31, 31},
     { /* B */ 153, 160, 107, 139, 126, 197, 185, 201, 134, 154, 139, 154, 154, 183, 152, 79, 154, 137, 168, 224, 167, 122, 153, 111,
       149, 92, 167, 154, 154, 169, 198,
       125, 110, 124, 110, 95, 94, 125, 111, 111, 79, 125, 126, 111, 111, 79, 108, 123, 93,
@@ -99,7 +99,7 @@ static const uint8_t kInit[3][CX_COUNT] = {
       170, 154, 139, 153, 139, 123, 123, 63, 124, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154, 166, 183, 140, 136, 153, 154,
       170, 153, 138, 138, 122, 121, 122, 121, 167, 151, 183, 140, 151, 183, 140, 140, 140,
       154, 196, 167, 167, 154, 152, 167, 182, 182, 134, 149, 136, 153, 121, 136, 122, 169, 208, 166, 167, 154, 152, 167, 182,
-      107, 167, 91, 107, 107, 167, 154, 154}};
+      107, 167, 91, 107, 107, 167, 154, 154, 95, 79, 63, 31, 31}};
 
 typedef struct {
     const uint8_t *p; size_t n, pos;   /* byte position in the slice data */
@@ -164,7 +164,7 @@ static int cb_terminate(cabac *c)
 }
 
 /* ------------------------------------------------------------------ decoder state */
-typedef struct { pix *base[3]; pix *pl[3]; int stride[3]; int poc; } picture;
+typedef struct { pix *base[3]; pix *pl[3]; int stride[3]; int poc; int seq, in_dpb; } picture;      /* seq: coded video sequence (counts IDR pictures); in_dpb: still a possible reference */
 
 typedef struct { char name[40]; long long val; } kv;
 
@@ -173,6 +173,7 @@ struct orc_decoder {
     int have_sps, have_pps, have_vps;
     int w, h, bit_depth, conf[4], log2_ctb, log2_min_cb, log2_min_tb, log2_max_tb, th_inter, th_intra;
     int sao_on, strong_intra, poc_bits, num_strps, strps_neg[64], strps_delta[64][4], strps_used[64][4], amp, tmvp;
+    int strps_pos[64], strps_pdelta[64][4], strps_pused[64][4];      /* the positive (later in output order) pictures of every short-term RPS */
     /* PPS (the active one; parse_pps files a copy under its id, decode_slice activates it) */
     int init_qp, sign_hiding, cu_qp_delta, cb_off, cr_off, lf_across, dbk_control, dbk_override_en, pps_dbk_disabled,
         cabac_init_present, par_mrg_level, transform_skip;
@@ -189,7 +190,10 @@ struct orc_decoder {
     int n_bands, band_row0[24], slice_y0, pic_sao, pic_lf_across;
     unsigned char band_lf_across[24];     /* per slice: slice_loop_filter_across_slices_enabled_flag (inferred from the PPS flag when absent) */
     size_t *epb; int n_epb, cap_epb;   /* positions (escaped payload offsets after the NAL header) of the removed 0x03 bytes */
-    int poc;
+    int poc, seq, prev_tid0_poc, cur_nal;       /* prev_tid0_poc: POC of the previous picture that is not a sub-layer non-reference picture (8.3.1) */
+    const picture *ref[2];             /* RefPicList0[0], RefPicList1[0] of the current slice */
+    int ref_poc[2], mvd_l1_zero;
+    int *out_order; int n_out_order;   /* decode index of every picture in output order (coded video sequence, then POC) */
     cabac cb;
     char err[256];
     kv kvs[160]; int n_kv;
@@ -218,7 +222,7 @@ void orc_dec_close(orc_decoder *d)
 {
     if (!d) return;
     for (int i = 0; i < d->n_pics; i++) free_pic(&d->pics[i]);
-    free(d->pics); free(d->cu); free(d->depth8); free(d->skip8); free(d->sao); free(d->epb);
+    free(d->pics); free(d->cu); free(d->depth8); free(d->skip8); free(d->sao); free(d->epb); free(d->out_order);
     if (d->cur_valid) free_pic(&d->cur);
     free(d);
 }
@@ -229,10 +233,23 @@ int orc_dec_info(const orc_decoder *d, int *w, int *h, int *bd, int *cw, int *ch
     *cw = d->w - 2 * (d->conf[0] + d->conf[1]); *ch = d->h - 2 * (d->conf[2] + d->conf[3]);
     return 0;
 }
-int orc_dec_get_frame(const orc_decoder *d, int idx, pix *y, pix *u, pix *v)
+/* pictures come back in OUTPUT order (C.5.2: by coded video sequence, then by picture order count); without B pictures that is the decoding order */
+int orc_dec_get_frame(const orc_decoder *d0, int idx, pix *y, pix *u, pix *v)
 {
+    orc_decoder *d = (orc_decoder *)d0;
     if (idx < 0 || idx >= d->n_pics) return -1;
-    const picture *p = &d->pics[idx];
+    if (d->n_out_order != d->n_pics) {
+        d->out_order = (int *)realloc(d->out_order, sizeof(int) * (size_t)d->n_pics);
+        for (int i = 0; i < d->n_pics; i++) d->out_order[i] = i;
+        for (int i = 1; i < d->n_pics; i++) {          /* insertion sort: the disorder is local (one picture) */
+            int k = d->out_order[i], j = i - 1;
+            while (j >= 0 && (d->pics[d->out_order[j]].seq > d->pics[k].seq ||
+                              (d->pics[d->out_order[j]].seq == d->pics[k].seq && d->pics[d->out_order[j]].poc > d->pics[k].poc))) { d->out_order[j + 1] = d->out_order[j]; j--; }
+            d->out_order[j + 1] = k;
+        }
+        d->n_out_order = d->n_pics;
+    }
+    const picture *p = &d->pics[d->out_order[idx]];
     pix *dst[3] = {y, u, v};
     for (int c = 0; c < 3; c++) {
         int w = c ? d->w / 2 : d->w, h = c ? d->h / 2 : d->h;
@@ -358,10 +375,12 @@ static int parse_sps(orc_decoder *d, bitrd *b)
     for (int i = 0; i < d->num_strps; i++) {
         if (i && br_bit(b)) { set_err(d, "sps: inter RPS prediction"); return -1; }
         int neg = (int)br_ue(b), posn = (int)br_ue(b);
-        if (posn || neg > 4) { set_err(d, "sps: rps shape"); return -1; }
-        d->strps_neg[i] = neg;
+        if (posn > 4 || neg > 4) { set_err(d, "sps: rps shape"); return -1; }
+        d->strps_neg[i] = neg; d->strps_pos[i] = posn;
         int acc = 0;
         for (int k = 0; k < neg; k++) { acc -= (int)br_ue(b) + 1; d->strps_delta[i][k] = acc; d->strps_used[i][k] = br_bit(b); }
+        acc = 0;
+        for (int k = 0; k < posn; k++) { acc += (int)br_ue(b) + 1; d->strps_pdelta[i][k] = acc; d->strps_pused[i][k] = br_bit(b); }
     }
     if (br_bit(b)) { set_err(d, "sps: long-term refs"); return -1; }
     d->tmvp = br_bit(b);
@@ -815,15 +834,15 @@ static int transform_tree(orc_decoder *d, int x0, int y0, int xb, int yb, int lo
 /* spec-literal motion compensation with coordinate clamping — 8.5.3.3.3.1 */
 static const int8_t kLT[4][8] = {{0, 0, 0, 64, 0, 0, 0, 0}, {-1, 4, -10, 58, 17, -5, 1, 0}, {-1, 4, -11, 40, 40, -11, 4, -1}, {0, 1, -5, 17, 58, -10, 4, -1}};
 static const int8_t kCT[8][4] = {{0, 64, 0, 0}, {-2, 58, 10, -2}, {-4, 54, 16, -2}, {-6, 46, 28, -4}, {-4, 36, 36, -4}, {-4, 28, 46, -6}, {-2, 16, 54, -4}, {-2, 10, 58, -2}};
-static void mc_block(orc_decoder *d, const picture *ref, int c_idx, int x, int y, int n, int mvx, int mvy)
+/* predSamplesLX of one block: the 14-bit intermediate samples of 8.5.3.3.3.1 / .2 with reference coordinates clamped to the picture (8.5.3.3.3.1 xInt / yInt) */
+static void mc_block14(orc_decoder *d, const picture *ref, int c_idx, int x, int y, int n, int mvx, int mvy, int16_t *out)
 {
     int chroma = c_idx != 0, taps = chroma ? 4 : 8, half = chroma ? 1 : 3;
     int w = chroma ? d->w / 2 : d->w, h = chroma ? d->h / 2 : d->h;
     int fx = chroma ? mvx & 7 : mvx & 3, fy = chroma ? mvy & 7 : mvy & 3;
     int xi = x + (chroma ? mvx >> 3 : mvx >> 2), yi = y + (chroma ? mvy >> 3 : mvy >> 2);
-    int shift1 = d->bit_depth - 8 < 4 ? d->bit_depth - 8 : 4, shift3 = 14 - d->bit_depth, maxv = (1 << d->bit_depth) - 1;
+    int shift1 = d->bit_depth - 8 < 4 ? d->bit_depth - 8 : 4, shift3 = 14 - d->bit_depth;
     const pix *rp = ref->pl[c_idx]; int rs = ref->stride[c_idx];
-    pix *dp = d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x;
     for (int j = 0; j < n; j++)
         for (int i = 0; i < n; i++) {
             int v;
@@ -843,45 +862,119 @@ static void mc_block(orc_decoder *d, const picture *ref, int c_idx, int x, int y
             }
 #undef RS
 #undef TAP
-            v = (v + (1 << (shift3 - 1))) >> shift3;
+            out[j * n + i] = (int16_t)v;
+        }
+}
+/* 8.5.3.3.4.2 default weighted sample prediction into the current picture: one list ((p + offset1) >> shift1) or the average of both */
+static void mc_predict(orc_decoder *d, int c_idx, int x, int y, int n, int use0, int mv0x, int mv0y, int use1, int mv1x, int mv1y)
+{
+    int16_t p0[32 * 32], p1[32 * 32];
+    const int maxv = (1 << d->bit_depth) - 1, shift1 = 14 - d->bit_depth, shift2 = 15 - d->bit_depth;
+    if (use0) mc_block14(d, d->ref[0], c_idx, x, y, n, mv0x, mv0y, p0);
+    if (use1) mc_block14(d, d->ref[1], c_idx, x, y, n, mv1x, mv1y, p1);
+    pix *dp = d->cur.pl[c_idx] + (size_t)y * d->cur.stride[c_idx] + x;
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            int v;
+            if (use0 && use1) v = (p0[j * n + i] + p1[j * n + i] + (1 << (shift2 - 1))) >> shift2;
+            else v = ((use0 ? p0 : p1)[j * n + i] + (1 << (shift1 - 1))) >> shift1;
             dp[j * d->cur.stride[c_idx] + i] = (pix)CLIP3(0, maxv, v);
         }
 }
 
+/* motion of a prediction block: prediction list utilization flags and the two vectors (reference indices are 0: one picture per list) */
+typedef struct { int ok, f[2], mv[2][2]; } motion;
 typedef struct { int ok, mvx, mvy; } mvcand;
-static mvcand nb_motion(orc_decoder *d, int xc, int yc, int xn, int yn)
+static motion rec_motion(const orc_cu_rec *r)
 {
-    mvcand m = {0, 0, 0};
+    motion m;
+    memset(&m, 0, sizeof m);
+    m.ok = 1; m.f[0] = !(r->flags & ORC_F_NOL0); m.f[1] = (r->flags & ORC_F_L1) != 0;
+    if (m.f[0]) { m.mv[0][0] = r->mvx; m.mv[0][1] = r->mvy; }
+    if (m.f[1]) { m.mv[1][0] = orc_mv1x(r); m.mv[1][1] = orc_mv1y(r); }
+    return m;
+}
+static motion nb_motion(orc_decoder *d, int xc, int yc, int xn, int yn)
+{
+    motion m;
+    memset(&m, 0, sizeof m);
     if (!avail_z(d, xc, yc, xn, yn)) return m;
     const orc_cu_rec *r = cu_at(d, xn, yn);
     if (!(r->flags & ORC_F_INTER)) return m;
-    m.ok = 1; m.mvx = r->mvx; m.mvy = r->mvy;
-    return m;
+    return rec_motion(r);
 }
-/* 8.5.3.2.2-.5 merge candidates (spatial + zero; P slices, one reference) */
-static void merge_list(orc_decoder *d, int x, int y, int n, mvcand out[5])
+static int same_motion(const motion *a, const motion *b)
 {
-    mvcand a1 = nb_motion(d, x, y, x - 1, y + n - 1), b1 = nb_motion(d, x, y, x + n - 1, y - 1);
-    mvcand b0 = nb_motion(d, x, y, x + n, y - 1), a0 = nb_motion(d, x, y, x - 1, y + n), b2 = nb_motion(d, x, y, x - 1, y - 1);
+    if (!a->ok || !b->ok || a->f[0] != b->f[0] || a->f[1] != b->f[1]) return 0;
+    for (int l = 0; l < 2; l++) if (a->f[l] && (a->mv[l][0] != b->mv[l][0] || a->mv[l][1] != b->mv[l][1])) return 0;
+    return 1;
+}
+/* 8.5.3.2.2 - 8.5.3.2.5 merge candidates: spatial, combined bi-predictive (B slices), zero; no temporal candidate (the SPS switches it off) */
+static void merge_list(orc_decoder *d, int x, int y, int n, motion out[5])
+{
+    motion a1 = nb_motion(d, x, y, x - 1, y + n - 1), b1 = nb_motion(d, x, y, x + n - 1, y - 1);
+    motion b0 = nb_motion(d, x, y, x + n, y - 1), a0 = nb_motion(d, x, y, x - 1, y + n), b2 = nb_motion(d, x, y, x - 1, y - 1);
     /* pruning compares against the neighbour's raw availability, not its post-pruning flag (8.5.3.2.3) */
-#define SAME(p, q) ((p).ok && (q).ok && (p).mvx == (q).mvx && (p).mvy == (q).mvy)
-    int fa1 = a1.ok, fb1 = b1.ok && !SAME(b1, a1), fb0 = b0.ok && !SAME(b0, b1), fa0 = a0.ok && !SAME(a0, a1);
-    int fb2 = b2.ok && !SAME(b2, a1) && !SAME(b2, b1) && (fa0 + fa1 + fb0 + fb1 != 4);
-#undef SAME
+    int fa1 = a1.ok, fb1 = b1.ok && !same_motion(&b1, &a1), fb0 = b0.ok && !same_motion(&b0, &b1), fa0 = a0.ok && !same_motion(&a0, &a1);
+    int fb2 = b2.ok && !same_motion(&b2, &a1) && !same_motion(&b2, &b1) && (fa0 + fa1 + fb0 + fb1 != 4);
     a1.ok = fa1; b1.ok = fb1; b0.ok = fb0; a0.ok = fa0; b2.ok = fb2;
     int k = 0;
-    mvcand order[5] = {a1, b1, b0, a0, b2};
+    motion order[5] = {a1, b1, b0, a0, b2};
     for (int i = 0; i < 5 && k < d->max_merge; i++) if (order[i].ok) out[k++] = order[i];
-    while (k < 5) { out[k].ok = 1; out[k].mvx = 0; out[k].mvy = 0; k++; }
+    if (d->slice_type == 0 && k > 1 && k < d->max_merge) {          /* 8.5.3.2.4, Table 8-6 */
+        static const uint8_t l0c[12] = {0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3}, l1c[12] = {1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2};
+        const int orig = k;
+        for (int c = 0; c < orig * (orig - 1) && k < d->max_merge; c++) {
+            const motion *p = &out[l0c[c]], *q = &out[l1c[c]];
+            if (!p->f[0] || !q->f[1]) continue;
+            /* DiffPicOrderCnt(RefPicList0[refIdxL0], RefPicList1[refIdxL1]) != 0 || mvL0 != mvL1 */
+            if (d->ref_poc[0] == d->ref_poc[1] && p->mv[0][0] == q->mv[1][0] && p->mv[0][1] == q->mv[1][1]) continue;
+            motion m;
+            memset(&m, 0, sizeof m);
+            m.ok = 1; m.f[0] = m.f[1] = 1; m.mv[0][0] = p->mv[0][0]; m.mv[0][1] = p->mv[0][1]; m.mv[1][0] = q->mv[1][0]; m.mv[1][1] = q->mv[1][1];
+            out[k++] = m;
+        }
+    }
+    while (k < 5) { memset(&out[k], 0, sizeof out[k]); out[k].ok = 1; out[k].f[0] = 1; out[k].f[1] = d->slice_type == 0; k++; }      /* 8.5.3.2.5 */
 }
-/* 8.5.3.2.6-.7 AMVP candidates (spatial; one reference so no scaling) */
-static void amvp_list(orc_decoder *d, int x, int y, int n, mvcand out[2])
+/* 8.5.3.2.7, one neighbour for list X: first the vector that refers to the SAME picture as RefPicListX[0] (its list-X vector, else its list-Y vector),
+ * in the second pass any vector, scaled by the ratio of the POC distances (equations 8-179 .. 8-183) */
+static mvcand amvp_from(const orc_decoder *d, const motion *m, int lx, int scaled_pass)
 {
-    mvcand a0 = nb_motion(d, x, y, x - 1, y + n), a1 = nb_motion(d, x, y, x - 1, y + n - 1);
-    mvcand b0 = nb_motion(d, x, y, x + n, y - 1), b1 = nb_motion(d, x, y, x + n - 1, y - 1), b2 = nb_motion(d, x, y, x - 1, y - 1);
-    int scaled = a0.ok || a1.ok;   /* 6.4.2 availability already excludes intra neighbours */
-    mvcand a = a0.ok ? a0 : a1, b = b0.ok ? b0 : b1.ok ? b1 : b2;
+    mvcand c = {0, 0, 0};
+    if (!m->ok) return c;
+    for (int t = 0; t < 2; t++) {
+        const int l = t ? !lx : lx;
+        if (!m->f[l]) continue;
+        if (d->ref_poc[l] == d->ref_poc[lx]) { c.ok = 1; c.mvx = m->mv[l][0]; c.mvy = m->mv[l][1]; return c; }
+        if (!scaled_pass) continue;
+        const int td = CLIP3(-128, 127, d->poc - d->ref_poc[l]), tb = CLIP3(-128, 127, d->poc - d->ref_poc[lx]);
+        const int tx = (16384 + (iabs(td) >> 1)) / td, dsf = CLIP3(-4096, 4095, (tb * tx + 32) >> 6);
+        for (int k = 0; k < 2; k++) {
+            const int p = dsf * m->mv[l][k], r = (iabs(p) + 127) >> 8, v = CLIP3(-32768, 32767, p < 0 ? -r : r);
+            if (k) c.mvy = v; else c.mvx = v;
+        }
+        c.ok = 1;
+        return c;
+    }
+    return c;
+}
+/* 8.5.3.2.6 - 8.5.3.2.7 AMVP candidates of list X (spatial; the SPS switches the temporal one off) */
+static void amvp_list(orc_decoder *d, int x, int y, int n, int lx, mvcand out[2])
+{
+    motion a0 = nb_motion(d, x, y, x - 1, y + n), a1 = nb_motion(d, x, y, x - 1, y + n - 1);
+    motion b0 = nb_motion(d, x, y, x + n, y - 1), b1 = nb_motion(d, x, y, x + n - 1, y - 1), b2 = nb_motion(d, x, y, x - 1, y - 1);
+    const int scaled = a0.ok || a1.ok;   /* isScaledFlagLX; 6.4.2 availability already excludes intra neighbours */
+    const motion *as[2] = {&a0, &a1}, *bs[3] = {&b0, &b1, &b2};
+    mvcand a = {0, 0, 0}, b = {0, 0, 0};
+    for (int k = 0; k < 2 && !a.ok; k++) a = amvp_from(d, as[k], lx, 0);
+    for (int k = 0; k < 2 && !a.ok; k++) a = amvp_from(d, as[k], lx, 1);
+    for (int k = 0; k < 3 && !b.ok; k++) b = amvp_from(d, bs[k], lx, 0);
     if (!scaled && b.ok) a = b;
+    if (!scaled) {
+        b.ok = 0;
+        for (int k = 0; k < 3 && !b.ok; k++) b = amvp_from(d, bs[k], lx, 1);
+    }
     int k = 0;
     if (a.ok) out[k++] = a;
     if (b.ok && !(a.ok && a.mvx == b.mvx && a.mvy == b.mvy)) out[k++] = b;
@@ -916,11 +1009,6 @@ static int coding_unit(orc_decoder *d, int x0, int y0, int log2n)
         int l = avail_z(d, x0, y0, x0 - 1, y0) && d->skip8[(y0 >> 3) * w8 + ((x0 - 1) >> 3)];
         int a = avail_z(d, x0, y0, x0, y0 - 1) && d->skip8[((y0 - 1) >> 3) * w8 + (x0 >> 3)];
         skip = cb_decision(c, CX_SKIP + l + a);
-    }
-    const picture *ref = NULL;
-    if (d->slice_type != 2) {
-        for (int i = 0; i < d->n_pics; i++) if (d->pics[i].poc == d->poc - 1) ref = &d->pics[i];
-        if (!ref) { set_err(d, "P slice without its reference picture (poc %d)", d->poc - 1); return -1; }
     }
     uint8_t lmodes[4] = {1, 1, 1, 1};
     int chroma_mode = 1;
@@ -985,19 +1073,32 @@ static int coding_unit(orc_decoder *d, int x0, int y0, int log2n)
     rec.flags = (uint8_t)((intra ? 0 : ORC_F_INTER) | (nxn ? ORC_F_NXN : 0));
     memcpy(rec.intra_mode, lmodes, 4); rec.chroma_mode = (uint8_t)chroma_mode;
     if (!intra) {
-        int mvx, mvy;
-        if (merge) { mvcand l[5]; merge_list(d, x0, y0, n, l); mvx = l[merge_idx].mvx; mvy = l[merge_idx].mvy; }
+        motion m;
+        memset(&m, 0, sizeof m);
+        if (merge) { motion l[5]; merge_list(d, x0, y0, n, l); m = l[merge_idx]; }
         else {
-            int dx, dy;
-            if (read_mvd(c, &dx, &dy)) { set_err(d, "mvd escape too long"); return -1; }
-            int flag = cb_decision(c, CX_MVP);
-            mvcand l[2]; amvp_list(d, x0, y0, n, l);
-            mvx = l[flag].mvx + dx; mvy = l[flag].mvy + dy;
+            /* 7.3.8.6 prediction_unit: inter_pred_idc (B slices; 9.3.4.2.2: first bin by CtDepth since nPbW + nPbH != 12), then per list mvd_coding and
+             * mvp_lX_flag (ref_idx_lX is absent: one active picture per list) */
+            m.ok = 1; m.f[0] = 1; m.f[1] = 0;
+            if (d->slice_type == 0) {
+                if (cb_decision(c, CX_INTER_DIR + (d->log2_ctb - log2n))) m.f[1] = 1;               /* PRED_BI */
+                else if (cb_decision(c, CX_INTER_DIR + 4)) { m.f[0] = 0; m.f[1] = 1; }             /* PRED_L1 */
+            }
+            for (int lx = 0; lx < 2; lx++) {
+                if (!m.f[lx]) continue;
+                int dx = 0, dy = 0;
+                if (!(lx == 1 && d->mvd_l1_zero && m.f[0]) && read_mvd(c, &dx, &dy)) { set_err(d, "mvd escape too long"); return -1; }
+                int flag = cb_decision(c, CX_MVP);
+                mvcand l[2]; amvp_list(d, x0, y0, n, lx, l);
+                m.mv[lx][0] = l[flag].mvx + dx; m.mv[lx][1] = l[flag].mvy + dy;
+            }
         }
-        rec.mvx = (int16_t)mvx; rec.mvy = (int16_t)mvy;
-        mc_block(d, ref, 0, x0, y0, n, mvx, mvy);
-        mc_block(d, ref, 1, x0 >> 1, y0 >> 1, n >> 1, mvx, mvy);
-        mc_block(d, ref, 2, x0 >> 1, y0 >> 1, n >> 1, mvx, mvy);
+        if (m.f[0]) { rec.mvx = (int16_t)m.mv[0][0]; rec.mvy = (int16_t)m.mv[0][1]; } else rec.flags |= ORC_F_NOL0;
+        if (m.f[1]) { rec.flags |= ORC_F_L1; orc_set_mv1(&rec, m.mv[1][0], m.mv[1][1]); }
+        if ((m.f[0] && !d->ref[0]) || (m.f[1] && !d->ref[1])) { set_err(d, "inter block without its reference picture"); return -1; }
+        mc_predict(d, 0, x0, y0, n, m.f[0], m.mv[0][0], m.mv[0][1], m.f[1], m.mv[1][0], m.mv[1][1]);
+        mc_predict(d, 1, x0 >> 1, y0 >> 1, n >> 1, m.f[0], m.mv[0][0], m.mv[0][1], m.f[1], m.mv[1][0], m.mv[1][1]);
+        mc_predict(d, 2, x0 >> 1, y0 >> 1, n >> 1, m.f[0], m.mv[0][0], m.mv[0][1], m.f[1], m.mv[1][0], m.mv[1][1]);
     }
     for (int yy = 0; yy < n; yy += 8)
         for (int xx = 0; xx < n; xx += 8) { *cu_at(d, x0 + xx, y0 + yy) = rec; d->skip8[((y0 + yy) >> 3) * w8 + ((x0 + xx) >> 3)] = (uint8_t)skip; }
@@ -1081,7 +1182,7 @@ static void finish_picture(orc_decoder *d)
 {
     if (!d->cur_valid) return;
     picture out; memset(&out, 0, sizeof out);
-    if (d->pic_sao) { alloc_pic(d, &out); out.poc = d->poc; }
+    if (d->pic_sao) { alloc_pic(d, &out); out.poc = d->cur.poc; out.seq = d->cur.seq; out.in_dpb = d->cur.in_dpb; }
     {   /* in-loop filters over the whole picture with the slice / tile boundary rules of 8.7.2 / 8.7.3 (hevc_dec_recon.c: the decoder's own) */
         d2_picture_info pi;
         memset(&pi, 0, sizeof pi);
@@ -1105,6 +1206,7 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
     if (!d->have_sps || !d->have_pps) { set_err(d, "slice before parameter sets"); return -1; }
     bitrd b = {rbsp, n, 0, 0};
     const int first = br_bit(&b);        /* first_slice_segment_in_pic_flag */
+    d->cur_nal = nal_type;
     int irap = nal_type >= 16 && nal_type <= 23, idr = nal_type == 19 || nal_type == 20;
     if (irap) br_bit(&b);
     if (activate_pps(d, (int)br_ue(&b))) { set_err(d, "slice: pps id"); return -1; }
@@ -1118,11 +1220,13 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
         if (addr % wc || addr / wc != d->band_row0[d->n_bands]) { set_err(d, "slice at CTB %d: only consecutive slices of whole CTB rows are decoded", addr); return -1; }
     } else finish_picture(d);
     d->slice_type = (int)br_ue(&b);
-    if (d->slice_type == 0) { set_err(d, "B slices unsupported"); return -1; }
+    if (d->slice_type < 0 || d->slice_type > 2) { set_err(d, "slice_type %d", d->slice_type); return -1; }
+    if (irap && d->slice_type != 2) { set_err(d, "IRAP picture with a P / B slice"); return -1; }
     int poc = 0;
     if (!idr) {
+        /* 8.3.1: POC from the previous picture at TemporalId 0 that is not a sub-layer non-reference picture (TRAIL_N is one) */
         int lsb = (int)br_u(&b, d->poc_bits);
-        int prev = d->n_pics ? d->pics[d->n_pics - 1].poc : 0;   /* all pictures are reference pictures at TemporalId 0 */
+        int prev = d->prev_tid0_poc;
         int maxl = 1 << d->poc_bits, prev_lsb = prev & (maxl - 1), prev_msb = prev - prev_lsb, msb;
         if (lsb < prev_lsb && prev_lsb - lsb >= maxl / 2) msb = prev_msb + maxl;
         else if (lsb > prev_lsb && lsb - prev_lsb > maxl / 2) msb = prev_msb - maxl;
@@ -1130,16 +1234,55 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
         poc = msb + lsb;
         if (!br_bit(&b)) { set_err(d, "slice: explicit RPS unsupported"); return -1; }
         if (d->num_strps > 1) { int nb = 0; while ((1 << nb) < d->num_strps) nb++; d->ref_idx = (int)br_u(&b, nb); } else d->ref_idx = 0;
-        if (d->strps_neg[d->ref_idx] != 1 || d->strps_delta[d->ref_idx][0] != -1) { set_err(d, "slice: RPS is not {-1}"); return -1; }
+        if (d->ref_idx >= d->num_strps) { set_err(d, "slice: short_term_ref_pic_set_idx"); return -1; }
     }
     if (!first && poc != d->poc) { set_err(d, "slices of one picture disagree on the picture order count"); return -1; }
     d->poc = poc;
+    if (first) {
+        if (idr) d->seq++;
+        /* 8.3.2 reference picture set: pictures of this coded video sequence outside the set can never be referenced again; the set's pictures must
+         * all be present (no picture is ever missing in these streams: a missing one is an error).  8.3.4 reference picture lists with one active entry
+         * each: RefPicList0 = StCurrBefore then StCurrAfter, RefPicList1 = StCurrAfter then StCurrBefore */
+        const picture *before = NULL, *after = NULL;
+        int before_poc = 0, after_poc = 0;
+        for (int i = 0; i < d->n_pics; i++) {
+            picture *p = &d->pics[i];
+            if (!p->in_dpb) continue;
+            int keep = 0;
+            if (!idr && p->seq == d->seq) {
+                for (int k = 0; k < d->strps_neg[d->ref_idx]; k++)
+                    if (p->poc == poc + d->strps_delta[d->ref_idx][k]) { keep = 1; if (d->strps_used[d->ref_idx][k] && !before) { before = p; before_poc = p->poc; } }
+                for (int k = 0; k < d->strps_pos[d->ref_idx]; k++)
+                    if (p->poc == poc + d->strps_pdelta[d->ref_idx][k]) { keep = 1; if (d->strps_pused[d->ref_idx][k] && !after) { after = p; after_poc = p->poc; } }
+            }
+            p->in_dpb = keep;
+        }
+        /* the nearest picture first: negative deltas are listed closest first, so "first match in DPB order" is not enough when a set holds several */
+        if (!idr) {
+            for (int k = 0; k < d->strps_neg[d->ref_idx] && d->strps_used[d->ref_idx][k]; k++) {
+                int found = 0;
+                for (int i = 0; i < d->n_pics; i++) if (d->pics[i].in_dpb && d->pics[i].seq == d->seq && d->pics[i].poc == poc + d->strps_delta[d->ref_idx][k]) { if (k == 0) { before = &d->pics[i]; before_poc = d->pics[i].poc; } found = 1; }
+                if (!found) { set_err(d, "reference picture poc %d of picture %d is not in the DPB", poc + d->strps_delta[d->ref_idx][k], poc); return -1; }
+            }
+            for (int k = 0; k < d->strps_pos[d->ref_idx] && d->strps_pused[d->ref_idx][k]; k++) {
+                int found = 0;
+                for (int i = 0; i < d->n_pics; i++) if (d->pics[i].in_dpb && d->pics[i].seq == d->seq && d->pics[i].poc == poc + d->strps_pdelta[d->ref_idx][k]) { if (k == 0) { after = &d->pics[i]; after_poc = d->pics[i].poc; } found = 1; }
+                if (!found) { set_err(d, "reference picture poc %d of picture %d is not in the DPB", poc + d->strps_pdelta[d->ref_idx][k], poc); return -1; }
+            }
+        }
+        d->ref[0] = before ? before : after; d->ref_poc[0] = before ? before_poc : after_poc;
+        d->ref[1] = after ? after : before; d->ref_poc[1] = after ? after_poc : before_poc;
+        if (nal_type != 0) d->prev_tid0_poc = poc;          /* TRAIL_N (0) is a sub-layer non-reference picture: it does not anchor later POCs */
+    }
     d->sao_luma = d->sao_chroma = 0;
     if (d->sao_on) { d->sao_luma = br_bit(&b); d->sao_chroma = br_bit(&b); }
     d->max_merge = 5;
+    d->mvd_l1_zero = 0;
     if (d->slice_type != 2) {
         if (br_bit(&b)) { set_err(d, "slice: num_ref_idx override"); return -1; }
+        if (d->slice_type == 0) d->mvd_l1_zero = br_bit(&b);      /* (lists_modification / cabac_init / collocated / pred_weight_table: absent by PPS and SPS) */
         d->max_merge = 5 - (int)br_ue(&b);
+        if (!d->ref[0] || (d->slice_type == 0 && !d->ref[1])) { set_err(d, "slice: empty reference picture list"); return -1; }
     }
     d->slice_qp = d->init_qp + br_se(&b);
     int slice_lf_across = d->lf_across;      /* 7.4.7.1: when absent, inferred equal to pps_loop_filter_across_slices_enabled_flag */
@@ -1162,7 +1305,6 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
 
     int w8 = d->w >> 3, h8 = d->h >> 3;
     if (first) {
-        if (idr) { for (int i = 0; i < d->n_pics; i++) d->pics[i].poc = -1000000 - i; }  /* IDR: earlier pictures leave the DPB */
         if (!d->cu) {
             d->cu = (orc_cu_rec *)calloc((size_t)w8 * h8, sizeof(orc_cu_rec));
             d->depth8 = (uint8_t *)calloc((size_t)w8 * h8, 1); d->skip8 = (uint8_t *)calloc((size_t)w8 * h8, 1);
@@ -1170,7 +1312,7 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
         }
         memset(d->cu, 0, sizeof(orc_cu_rec) * w8 * h8); memset(d->depth8, 0, (size_t)w8 * h8); memset(d->skip8, 0, (size_t)w8 * h8);
         memset(d->sao, 0, sizeof(orc_sao_ctu) * wc * hc);
-        alloc_pic(d, &d->cur); d->cur_valid = 1; d->cur.poc = d->poc;
+        alloc_pic(d, &d->cur); d->cur_valid = 1; d->cur.poc = d->poc; d->cur.seq = d->seq; d->cur.in_dpb = d->cur_nal != 0;
         d->n_bands = 0; d->band_row0[0] = 0;
         d->pic_sao = d->sao_luma || d->sao_chroma; d->pic_lf_across = d->lf_across;
     } else if ((d->sao_luma || d->sao_chroma) != d->pic_sao) { set_err(d, "slices of one picture disagree on SAO"); return -1; }
@@ -1202,7 +1344,7 @@ static int decode_slice(orc_decoder *d, const uint8_t *rbsp, size_t n, int nal_t
             sub_end = e;
             if (sub_end > n || sub_end <= sub_start) { set_err(d, "slice: entry point %d out of range", ti); goto done; }
         }
-        cb_init(&d->cb, rbsp + sub_start, sub_end - sub_start, d->slice_type == 2 ? 0 : 1, d->slice_qp);
+        cb_init(&d->cb, rbsp + sub_start, sub_end - sub_start, d->slice_type == 2 ? 0 : d->slice_type == 1 ? 1 : 2, d->slice_qp);      /* 9.3.2.2: initType with cabac_init_flag 0 */
         /* one tile (no tiles in the PPS): CTB rows from row0 until end_of_slice_segment_flag */
         const int ry0 = d->tiles ? d->row_bd[ty] : row0, ry1 = d->tiles ? d->row_bd[ty + 1] : hc;
         int ended = 0;
@@ -1280,14 +1422,14 @@ int orc_dec_decode(orc_decoder *d, const uint8_t *data, size_t size)
         int rc = 0;
         /* 7.4.2.4.4: an access unit delimiter, when present, is the first NAL unit of its access unit (one slice per picture here) */
         if (type == 35 && au_open) { set_err(d, "access unit delimiter is not the first NAL unit of its access unit"); break; }
-        au_open = !(type == 1 || type == 19 || type == 20);
+        au_open = !(type == 0 || type == 1 || type == 19 || type == 20);
         if (au_open) finish_picture(d);          /* a non-VCL NAL unit after the slices: the picture before it is complete */
         if (type == 32) rc = parse_vps(d, &b);
         else if (type == 33) rc = parse_sps(d, &b);
         else if (type == 34) rc = parse_pps(d, &b);
         else if (type == 35) { n_aud++; put_kv(d, "aud.last_pic_type", br_u(&b, 3)); if (!br_trailing_ok(&b)) { set_err(d, "aud trailing"); rc = -1; } }
         else if (type == 39 || type == 40) rc = parse_sei(d, &b);
-        else if (type == 1 || type == 19 || type == 20) { rc = decode_slice(d, rbsp, m, type); n_slices++; }
+        else if (type == 0 || type == 1 || type == 19 || type == 20) { rc = decode_slice(d, rbsp, m, type); n_slices++; }
         else { set_err(d, "unsupported NAL type %d", type); rc = -1; }
         if (rc) break;
         i = e;

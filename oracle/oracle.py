@@ -228,6 +228,34 @@ def analyze_inter(src: Frame, ref: Frame, prm: Params, centers=None, dump_me=Fal
     return a
 
 
+def _padded_bases(ref: Frame):
+    rp = ref.padded()
+    sy, sc = rp.y.shape[1], rp.u.shape[1]
+    return rp, sy, sc, (rp.y.ctypes.data + 2 * (PAD * sy + PAD), rp.u.ctypes.data + 2 * (PAD // 2 * sc + PAD // 2), rp.v.ctypes.data + 2 * (PAD // 2 * sc + PAD // 2))
+
+
+def analyze_b(src: Frame, ref0: Frame, ref1: Frame, prm: Params, centers0=None, centers1=None, dump_me=False) -> Analysis:
+    """B picture between two anchors (orc_analyze_b_frame): ref0 = the anchor before it in display order (list 0), ref1 = the one after it (list 1), both
+    UNPADDED final reconstructions.  a.me = (list-0 dump, list-1 dump) when dump_me.  CU records of inter CUs: flags & 32 = list 1 used (vector in the
+    intra_mode bytes), flags & 64 = list 0 not used."""
+    h, w = src.shape
+    a = Analysis(h, w)
+    keep0, sy, sc, b0 = _padded_bases(ref0)
+    keep1, _, _, b1 = _padded_bases(ref1)
+    n_ctu = ((w + CTU - 1) // CTU) * ((h + CTU - 1) // CTU)
+    cen = [np.ascontiguousarray(c, dtype=np.int16).reshape(n_ctu, 2) if c is not None else None for c in (centers0, centers1)]
+    me = [np.zeros((n_ctu, 21, 3), np.int32) if dump_me else None for _ in range(2)]
+    est = C.c_uint64(0)
+    lib().orc_analyze_b_frame(_p(src.y), _p(src.u), _p(src.v), w, w // 2, *[C.c_void_p(x) for x in b0], *[C.c_void_p(x) for x in b1], sy, sc, w, h, C.byref(prm),
+                              _p(cen[0]) if cen[0] is not None else None, _p(cen[1]) if cen[1] is not None else None,
+                              _p(a.rec.y), _p(a.rec.u), _p(a.rec.v), w, w // 2, _p(a.cu), _p(a.coef_y), _p(a.coef_u), _p(a.coef_v),
+                              _p(me[0]) if dump_me else None, _p(me[1]) if dump_me else None, C.byref(est))
+    del keep0, keep1
+    a.me = tuple(me) if dump_me else None
+    a.est = est.value
+    return a
+
+
 def search_centres(src: Frame, prev: Frame, bit_depth=8) -> np.ndarray:
     """Per-CTU search centres of picture `src` from the 1/4-size pictures of `src` and `prev` (orc_lowres + orc_pre_search).  A session feeds its
     integer search with the centres of the SOURCE picture against the SOURCE picture before it (the whole chunk at once, before any reconstruction
@@ -305,7 +333,7 @@ def decode(stream: bytes):
                   "sei.mdcv.max_lum", "sei.mdcv.min_lum", "sei.cll.max_cll", "sei.cll.max_fall", "pps.init_qp", "pps.tile_cols", "pps.tile_rows", "vui.hrd_present", "hrd.bit_rate_value_minus1", "hrd.cpb_size_value_minus1", "hrd.cbr_flag",
                   "sei.bp.initial_delay", "sei.bp.initial_offset", "count.sei_bp", "count.sei_pt", "sei.pt.au_cpb_removal_delay_minus1", "slice.last_qp",
                   "slice.max_merge", "sps.conf_right", "sps.conf_bottom", "sps.sao", "sps.amp", "sps.strong_intra", "sps.poc_bits",
-                  "vps.level_idc", "hrd.bit_rate_value_minus1", "hrd.cpb_size_value_minus1", "hrd.bit_rate_scale", "hrd.cpb_size_scale"):
+                  "vps.level_idc", "sps.max_num_reorder", "sps.max_dec_pic_buffering_minus1", "hrd.bit_rate_value_minus1", "hrd.cpb_size_value_minus1", "hrd.bit_rate_scale", "hrd.cpb_size_scale"):
             info[k] = q(k)
         del info["query"]
         return frames, info

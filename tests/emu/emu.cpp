@@ -139,6 +139,8 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU;
     a.prm = to_prm(prm); a.centers = centers; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0;
+    for (int i = 0; i < 3; i++) a.ref1[i] = {nullptr, 0};
+    a.centers1 = nullptr; a.me1 = nullptr;
     if (est) *est = 0;
     std::vector<IpInfo> ipv;
     a.ip = nullptr;
@@ -197,6 +199,55 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
                 free(is);
                 if (!ok) return -2;
             }
+    }
+    return 0;
+}
+
+// B picture between two anchors: integer search against both (list 0: r0*, list 1: r1*), then the B form of the CTU program
+template <typename T>
+static int b_frame(const T *sy, const T *su, const T *sv, const T *r0y, const T *r0u, const T *r0v, const T *r1y, const T *r1u, const T *r1v, int w, int h,
+                   const mihevc_cost_params *prm, const int16_t *centers0, const int16_t *centers1, T *oy, T *ou, T *ov, mihevc_cu_rec *cu,
+                   int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump0, int32_t *me_dump1, unsigned long long *est)
+{
+    Padded<T> p00(w, h, PAD_Y), p01(w / 2, h / 2, PAD_C), p02(w / 2, h / 2, PAD_C), p10(w, h, PAD_Y), p11(w / 2, h / 2, PAD_C), p12(w / 2, h / 2, PAD_C);
+    p00.load(r0y, w, h); p01.load(r0u, w / 2, h / 2); p02.load(r0v, w / 2, h / 2);
+    p10.load(r1y, w, h); p11.load(r1u, w / 2, h / 2); p12.load(r1v, w / 2, h / 2);
+    InterArgs<T> a;
+    a.src[0] = {sy, w}; a.src[1] = {su, w / 2}; a.src[2] = {sv, w / 2};
+    a.ref[0] = {p00.plane.p, p00.stride}; a.ref[1] = {p01.plane.p, p01.stride}; a.ref[2] = {p02.plane.p, p02.stride};
+    a.ref1[0] = {p10.plane.p, p10.stride}; a.ref1[1] = {p11.plane.p, p11.stride}; a.ref1[2] = {p12.plane.p, p12.stride};
+    a.rec[0] = {oy, w}; a.rec[1] = {ou, w / 2}; a.rec[2] = {ov, w / 2};
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU;
+    a.prm = to_prm(prm); a.centers = centers0; a.centers1 = centers1; a.cu = cu; a.coef[0] = cy; a.coef[1] = cu_; a.coef[2] = cv; a.est = est; a.sparse_coef = 0; a.ip = nullptr;
+    if (est) *est = 0;
+    const int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU), R = a.prm.me_range;
+    std::vector<int32_t> me0((size_t)n_ctu * 63), me1((size_t)n_ctu * 63);
+    a.me = me0.data(); a.me1 = me1.data();
+    SeqExec ex; ex.order = emu_order();
+    const char *waves = getenv("EMU_WAVES");
+    std::vector<uint8_t> win((size_t)me_win_elems(R) + 8);
+    std::vector<T> wy((size_t)mc_win_y(R) * mc_win_y_stride(R) + 16), wu((size_t)mc_win_c(R) * mc_win_c_stride(R) + 16), wv(wu.size());
+    for (int list = 0; list < 2; list++) {
+        const InterArgs<T> al = list ? list1_view(a) : a;
+        for (int c = 0; c < n_ctu; c++) {
+            MeShared<T> *ms = fresh_shared<MeShared<T>>();
+            bool ok = true;
+            if (waves) ok = run_waves((unsigned long long)atoll(waves) + (unsigned)c + 1000u * list, [&](WaveExec &wx) { me_search_program<T>(wx, *ms, win.data(), al, c); });
+            else me_search_program<T>(ex, *ms, win.data(), al, c);
+            free(ms);
+            if (!ok) return -2;
+        }
+    }
+    if (me_dump0) memcpy(me_dump0, me0.data(), me0.size() * sizeof(int32_t));
+    if (me_dump1) memcpy(me_dump1, me1.data(), me1.size() * sizeof(int32_t));
+    for (int c = 0; c < n_ctu; c++) {
+        InterShared<T> *is = fresh_shared<InterShared<T>>();
+        BiShared *bs = fresh_shared<BiShared>();
+        bool ok = true;
+        if (waves) ok = run_waves((unsigned long long)atoll(waves) + 7919u * (unsigned)c, [&](WaveExec &wx) { inter_ctu_program<T, WaveExec, true>(wx, *is, wy.data(), wu.data(), wv.data(), a, c, bs); });
+        else inter_ctu_program<T, SeqExec, true>(ex, *is, wy.data(), wu.data(), wv.data(), a, c, bs);
+        free(is); free(bs);
+        if (!ok) return -2;
     }
     return 0;
 }
@@ -279,6 +330,18 @@ int emu_inter_frame(const void *sy, const void *su, const void *sv, const void *
                                     (const uint8_t *)rv, w, h, prm, centers, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, cu, cy, cu_, cv, me_dump, est);
     return inter_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)ry, (const uint16_t *)ru,
                                  (const uint16_t *)rv, w, h, prm, centers, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, cu, cy, cu_, cv, me_dump, est);
+}
+int emu_b_frame(const void *sy, const void *su, const void *sv, const void *r0y, const void *r0u, const void *r0v, const void *r1y, const void *r1u, const void *r1v,
+                int w, int h, const mihevc_cost_params *prm, const int16_t *centers0, const int16_t *centers1, void *oy, void *ou, void *ov, mihevc_cu_rec *cu,
+                int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump0, int32_t *me_dump1, unsigned long long *est)
+{
+    if (prm->bit_depth == 8)
+        return b_frame<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (const uint8_t *)r0y, (const uint8_t *)r0u, (const uint8_t *)r0v,
+                                (const uint8_t *)r1y, (const uint8_t *)r1u, (const uint8_t *)r1v, w, h, prm, centers0, centers1, (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov,
+                                cu, cy, cu_, cv, me_dump0, me_dump1, est);
+    return b_frame<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)r0y, (const uint16_t *)r0u, (const uint16_t *)r0v,
+                             (const uint16_t *)r1y, (const uint16_t *)r1u, (const uint16_t *)r1v, w, h, prm, centers0, centers1, (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov,
+                             cu, cy, cu_, cv, me_dump0, me_dump1, est);
 }
 int emu_intra_frame(const void *sy, const void *su, const void *sv, int w, int h, const mihevc_cost_params *prm, void *oy, void *ou, void *ov,
                     mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv, unsigned long long *est)

@@ -320,3 +320,75 @@ def test_default_p_tile_grid_is_one_tile_per_1080p_area():
         assert _lib.p_tile_grid(make_cfg(w, h, level_idc=level)) == want, (w, h)
     sl = make_cfg(7680, 544, 10, level_idc=180, pic_height=4320, slice_count=8, slice_index=0)
     assert _lib.p_tile_grid(sl) == (1, 1)              # a sliced picture's slices already are one host job each
+
+
+def coding_order(n):
+    """cfg.bframes = 1: display positions of a closed GOP of n pictures in DECODING order with their slice types: I0 P2 b1 P4 b3 ...; the last picture is
+    always an anchor (an even GOP ends ... P(n-2) b(n-3) P(n-1))"""
+    anchors = list(range(0, n, 2)) + ([n - 1] if n > 1 and (n - 1) % 2 else [])
+    out = [(0, 2)]
+    for prev, cur in zip(anchors, anchors[1:]):
+        out.append((cur, 1))
+        if cur - prev == 2:
+            out.append((prev + 1, 0))
+    return out
+
+
+def encode_gop_with_b(cfg, srcs, qp, bd, me_range=8):
+    """oracle analysis -> product host coder for ONE closed GOP with a B picture between every two anchors; returns (stream in decoding order,
+    reconstructions by display position, slice types by display position)"""
+    lib = _lib.load()
+    buf = (C.c_uint8 * (4 << 20))()
+    n = lib.mihevc_write_parameter_sets(C.byref(cfg), buf, len(buf))
+    stream = bytes(buf[:n]) if not cfg.aud else b""
+    headers = bytes(buf[:n])
+    prm_i, prm_p, prm_b = O.default_params(max(0, qp - 3), bd, me_range), O.default_params(qp, bd, me_range), O.default_params(qp + 2, bd, me_range)
+    prm_i.tile_cols, prm_i.tile_rows = _lib.tile_grid(cfg)
+    for prm in (prm_p, prm_b):
+        prm.rdo_zero = 1
+    recs, types, cus = {}, {}, {}
+    last_anchor = None
+    for k, (pos, st) in enumerate(coding_order(len(srcs))):
+        src = srcs[pos]
+        if st == 2:
+            a, prm = O.analyze_intra(src, prm_i), prm_i
+        elif st == 1:
+            a, prm = O.analyze_inter(src, recs[last_anchor], prm_p), prm_p
+        else:
+            a, prm = O.analyze_b(src, recs[pos - 1], recs[pos + 1], prm_b), prm_b
+        dbk = O.deblock(a.rec, a.cu, bd)
+        rec, sao = O.sao(src, dbk, prm) if cfg.sao else (dbk, None)
+        recs[pos], types[pos], cus[pos] = rec, st, a.cu
+        if st != 0:
+            last_anchor = pos
+        m = lib.mihevc_encode_picture_host(C.byref(cfg), st, pos, prm.qp, util.ptr(a.cu), util.ptr(a.coef_y), util.ptr(a.coef_u), util.ptr(a.coef_v),
+                                           util.ptr(sao) if cfg.sao else None, buf, len(buf))
+        assert m > 0, (m, pos, st)
+        pkt = bytes(buf[:m])
+        if k == 0 and cfg.aud:
+            cut = pkt.index(b"\0\0\0\1", 4)
+            pkt = pkt[:cut] + headers + pkt[cut:]
+        stream += pkt
+    return stream, [recs[i] for i in range(len(srcs))], [types[i] for i in range(len(srcs))], [cus[i] for i in range(len(srcs))]
+
+
+@pytest.mark.parametrize("w,h,qp,bd,n,aud", [(96, 80, 26, 8, 7, 1), (136, 72, 32, 8, 6, 0), (72, 104, 24, 10, 5, 1), (160, 96, 20, 8, 9, 1)])
+def test_b_pictures_decode_to_the_oracle_reconstruction(w, h, qp, bd, n, aud):
+    """cfg.bframes: I0 P2 b1 P4 b3 ... in decoding order; B slices (TRAIL_N) with one picture per list, merge candidates with the combined bi-predictive
+    ones, AMVP with the vector of the other list's picture scaled (x -1), inter_pred_idc, bi-prediction by the default weighted average.  The decoder
+    returns pictures in output order: they must equal the oracle's reconstructions by display position, and all three prediction kinds must occur."""
+    cfg = make_cfg(w, h, bd, aud=aud, bframes=1)
+    srcs = [util.synth_frame(h, w, seed=17, shift=(3 * i, 2 * i), bit_depth=bd) for i in range(n)]
+    stream, recs, types, cus = encode_gop_with_b(cfg, srcs, qp, bd)
+    assert types[0] == 2 and types[n - 1] != 0 and all(t == 0 for t in types[1:n - 1:2])
+    frames, info = O.decode(stream)
+    assert len(frames) == n
+    for i, (f, r) in enumerate(zip(frames, recs)):
+        assert f.same(r), f"display picture {i} (slice type {types[i]}) differs after decode"
+    kinds = set()
+    for cu, t in zip(cus, types):
+        if t == 0:
+            fl = cu["flags"][(cu["flags"] & 1) == 1]
+            kinds |= {int(x) & 96 for x in np.unique(fl)}
+    assert kinds == {0, 32, 96}, kinds          # list 0 only, both lists, list 1 only
+    assert info["sps.max_num_reorder"] == 1 and info["sps.max_dec_pic_buffering_minus1"] == 2

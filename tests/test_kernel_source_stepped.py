@@ -168,3 +168,30 @@ def test_waves_as_threads_with_real_barriers(emu, monkeypatch):
     want, got = O.analyze_inter(srcs[1], ref, prm, dump_me=True), emu.inter(srcs[1], ref, prm)
     assert ((want.cu["flags"] & 1) == 0).any()
     assert util.same_analysis(want, got), util.describe_diff(want, got)
+
+
+@pytest.mark.parametrize("w,h,qp,bd,rng,pre", [(96, 80, 26, 8, 8, 0), (136, 72, 32, 8, 12, 1), (72, 104, 24, 10, 8, 1), (160, 96, 20, 8, 12, 0)])
+def test_stepped_b_picture_kernels_equal_oracle(emu, w, h, qp, bd, rng, pre):
+    """cfg.bframes: the B form of the CTU program (list-0 tree + refinement, list-1 refinement from its own integer search, bi-prediction trial by the
+    default weighted average of the 14-bit predictions, cheapest of three) against orc_analyze_b_frame: both integer-search dumps, records (incl. which
+    lists and the list-1 vector), levels, reconstruction, estimate; then deblocking with the two-list boundary strength and SAO."""
+    prm_i, prm_p, prm_b = O.default_params(max(0, qp - 3), bd, rng), O.default_params(qp, bd, rng), O.default_params(qp + 2, bd, rng)
+    prm_p.rdo_zero = prm_b.rdo_zero = 1
+    f = [util.synth_frame(h, w, seed=23, shift=(3 * i, 2 * i), bit_depth=bd) for i in range(3)]
+    a0 = O.analyze_intra(f[0], prm_i)
+    r0, _ = O.sao(f[0], O.deblock(a0.rec, a0.cu, bd), prm_i)
+    a2 = O.analyze_inter(f[2], r0, prm_p)
+    r2, _ = O.sao(f[2], O.deblock(a2.rec, a2.cu, bd), prm_p)
+    c0 = O.search_centres(f[1], f[0], bd) if pre else None
+    c1 = O.search_centres(f[1], f[2], bd) if pre else None
+    want = O.analyze_b(f[1], r0, r2, prm_b, c0, c1, dump_me=True)
+    got = emu.b(f[1], r0, r2, prm_b, c0, c1)
+    assert np.array_equal(want.me[0], got.me[0]) and np.array_equal(want.me[1], got.me[1]), "integer searches differ"
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+    kinds = {int(x) & 96 for x in np.unique(want.cu["flags"])}
+    assert len(kinds) >= 2, kinds
+    d = O.deblock(want.rec, want.cu, bd)
+    assert emu.deblock(want.rec, want.cu, bd).same(d)
+    gf, gsp = emu.sao(f[1], d, prm_b)
+    wf, wsp = O.sao(f[1], d, prm_b)
+    assert np.array_equal(gsp, wsp) and gf.same(wf)

@@ -98,6 +98,22 @@ class StageApi:
         a.rec, a.me, a.est = to_frame(o), me, est.value
         return a
 
+    def b(self, src: O.Frame, ref0: O.Frame, ref1: O.Frame, prm, centers0=None, centers1=None):
+        """B picture between two anchors (mihevc_k_b_frame / emu_b_frame): a.me = (list-0 dump, list-1 dump)"""
+        bd = prm.bit_depth
+        h, w = src.shape
+        s, r0, r1 = planes(src, bd), planes(ref0, bd), planes(ref1, bd)
+        o = [np.zeros_like(p) for p in s]
+        a = O.Analysis(h, w)
+        me = [np.zeros((n_ctus(w, h), 21, 3), np.int32) for _ in range(2)]
+        est = C.c_uint64(0)
+        cen = [np.ascontiguousarray(c, dtype=np.int16) if c is not None else None for c in (centers0, centers1)]
+        self._call("b_frame", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(r0[0]), ptr(r0[1]), ptr(r0[2]), ptr(r1[0]), ptr(r1[1]), ptr(r1[2]), w, h, C.byref(prm),
+                   ptr(cen[0]) if cen[0] is not None else None, ptr(cen[1]) if cen[1] is not None else None, ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(a.cu), ptr(a.coef_y),
+                   ptr(a.coef_u), ptr(a.coef_v), ptr(me[0]), ptr(me[1]), C.byref(est))
+        a.rec, a.me, a.est = to_frame(o), tuple(me), est.value
+        return a
+
     def deblock(self, rec: O.Frame, cu, bd):
         r = planes(rec, bd)
         h, w = rec.shape

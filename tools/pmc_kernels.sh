@@ -13,7 +13,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_LDS_ADDR_CONFLICT" \
            "SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VALU_MFMA_I8 SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM SQ_WAIT_INST_ANY"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp -d $out/p$i -o p --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras > $out/run$i.log 2>&1 || { tail -5 $out/run$i.log; exit 1; }
+  rocprofv3 --pmc $grp -d $out/p$i -o p --output-format csv -- python3 $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras --profile-stages 1 > $out/run$i.log 2>&1 || { tail -5 $out/run$i.log; exit 1; }
 done
 cd $root
 { echo "# mean per dispatch of the SQ counters rocprofv3 wrote for each kernel (three separate --pmc passes of: python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extras)."
