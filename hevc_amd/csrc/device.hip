@@ -712,6 +712,56 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
     return MIHEVC_OK;
 }
 
+// B picture between two anchors: both integer searches, then the B form of the CTU program
+template <typename T>
+int stage_b(const void *sy, const void *su, const void *sv, const void *f0y, const void *f0u, const void *f0v, const void *f1y, const void *f1u, const void *f1v, int w, int h,
+            const mihevc_cost_params *prm, const int16_t *centers0, const int16_t *centers1, void *ry, void *ru, void *rv, mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_,
+            int16_t *cv, int32_t *me_dump0, int32_t *me_dump1, uint64_t *est)
+{
+    Planes3<T> src, ref0, ref1, rec;
+    if (src.alloc(w, h, false) || ref0.alloc(w, h, true) || ref1.alloc(w, h, true) || rec.alloc(w, h, false)) return MIHEVC_ENOMEM;
+    if (int e = src.upload(sy, su, sv)) return e;
+    if (int e = ref0.upload(f0y, f0u, f0v)) return e;
+    if (int e = ref1.upload(f1y, f1u, f1v)) return e;
+    const int ctus_w = (w + CTU - 1) / CTU, n_ctu = ctus_w * ((h + CTU - 1) / CTU);
+    const size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h;
+    DevBuf dcu, dc0, dc1, dc2, dargs, dme0, dme1, dcen0, dcen1, dpad, dest;
+    CK(dest.alloc(8)); CK(hipMemset(dest.p, 0, 8));
+    CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec))); CK(dc0.alloc(ny * 2)); CK(dc1.alloc(ny / 2)); CK(dc2.alloc(ny / 2));
+    CK(dargs.alloc(sizeof(InterArgs<T>))); CK(dme0.alloc((size_t)n_ctu * 63 * 4)); CK(dme1.alloc((size_t)n_ctu * 63 * 4)); CK(dcen0.alloc((size_t)n_ctu * 4)); CK(dcen1.alloc((size_t)n_ctu * 4));
+    CK(dpad.alloc(2 * sizeof(SaoArgs<T>)));
+    CK(hipMemset(dcu.p, 0, n8 * sizeof(mihevc_cu_rec)));
+    if (centers0) CK(hipMemcpy(dcen0.p, centers0, (size_t)n_ctu * 4, hipMemcpyHostToDevice));
+    if (centers1) CK(hipMemcpy(dcen1.p, centers1, (size_t)n_ctu * 4, hipMemcpyHostToDevice));
+    SaoArgs<T> pa[2];
+    memset(pa, 0, sizeof pa);
+    for (int i = 0; i < 3; i++) { pa[0].out[i] = ref0.p[i].pl; pa[1].out[i] = ref1.p[i].pl; }
+    pa[0].w = pa[1].w = w; pa[0].h = pa[1].h = h;
+    CK(hipMemcpy(dpad.p, pa, sizeof pa, hipMemcpyHostToDevice));
+    CK(launch_pad<T>(0, dpad.as<SaoArgs<T>>(), w, h, 2));
+    InterArgs<T> a;
+    for (int i = 0; i < 3; i++) {
+        a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.ref[i] = {ref0.p[i].pl.p, ref0.p[i].pl.stride}; a.ref1[i] = {ref1.p[i].pl.p, ref1.p[i].pl.stride}; a.rec[i] = rec.p[i].pl;
+    }
+    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm);
+    a.centers = centers0 ? dcen0.as<int16_t>() : nullptr; a.centers1 = centers1 ? dcen1.as<int16_t>() : nullptr;
+    a.me = dme0.as<int32_t>(); a.me1 = dme1.as<int32_t>();
+    a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>();
+    a.est = dest.as<unsigned long long>(); a.sparse_coef = 0; a.ip = nullptr;
+    CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
+    CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range, 0));
+    CK(launch_me_search<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range, 1));
+    CK(launch_inter_ctu_b<T>(0, dargs.as<InterArgs<T>>(), n_ctu, 1, a.prm.me_range));
+    CK(hipDeviceSynchronize());
+    if (int e = rec.download(ry, ru, rv)) return e;
+    CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(cy, dc0.p, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cu_, dc1.p, ny / 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cv, dc2.p, ny / 2, hipMemcpyDeviceToHost));
+    if (me_dump0) CK(hipMemcpy(me_dump0, dme0.p, (size_t)n_ctu * 63 * 4, hipMemcpyDeviceToHost));
+    if (me_dump1) CK(hipMemcpy(me_dump1, dme1.p, (size_t)n_ctu * 63 * 4, hipMemcpyDeviceToHost));
+    if (est) CK(hipMemcpy(est, dest.p, 8, hipMemcpyDeviceToHost));
+    return MIHEVC_OK;
+}
+
 template <typename T> int stage_deblock(void *ry, void *ru, void *rv, int w, int h, const mihevc_cu_rec *cu, int bit_depth)
 {
     Planes3<T> rec;
@@ -831,6 +881,18 @@ int mihevc_k_inter_frame(int device, const void *sy, const void *su, const void 
     if (int e = select_device(device)) return e;
     if (prm->bit_depth == 8) return stage_inter<uint8_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump, est);
     if (prm->bit_depth == 10) return stage_inter<uint16_t>(sy, su, sv, fy, fu, fv, w, h, prm, centers, ry, ru, rv, cu, cy, cu_, cv, me_dump, est);
+    return MIHEVC_EINVAL;
+}
+
+int mihevc_k_b_frame(int device, const void *sy, const void *su, const void *sv, const void *f0y, const void *f0u, const void *f0v, const void *f1y, const void *f1u,
+                     const void *f1v, int w, int h, const mihevc_cost_params *prm, const int16_t *centers0, const int16_t *centers1, void *ry, void *ru, void *rv,
+                     mihevc_cu_rec *cu, int16_t *cy, int16_t *cu_, int16_t *cv, int32_t *me_dump0, int32_t *me_dump1, uint64_t *est)
+{
+    if (!sy || !su || !sv || !f0y || !f0u || !f0v || !f1y || !f1u || !f1v || !prm || !ry || !ru || !rv || !cu || !cy || !cu_ || !cv || !geometry_ok(w, h)) return MIHEVC_EINVAL;
+    if (prm->me_range < 1 || prm->me_range > MAX_RANGE) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    if (prm->bit_depth == 8) return stage_b<uint8_t>(sy, su, sv, f0y, f0u, f0v, f1y, f1u, f1v, w, h, prm, centers0, centers1, ry, ru, rv, cu, cy, cu_, cv, me_dump0, me_dump1, est);
+    if (prm->bit_depth == 10) return stage_b<uint16_t>(sy, su, sv, f0y, f0u, f0v, f1y, f1u, f1v, w, h, prm, centers0, centers1, ry, ru, rv, cu, cy, cu_, cv, me_dump0, me_dump1, est);
     return MIHEVC_EINVAL;
 }
 

@@ -238,6 +238,12 @@ int mihevc_k_inter_frame(int device, const void *src_y, const void *src_u, const
                          const mihevc_cost_params *prm, const int16_t *centers, void *rec_y, void *rec_u, void *rec_v,
                          mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump,
                          uint64_t *est_bits_q4);
+/* K1+K3 for a B picture (cfg.bframes) between two anchors: ref0 = the (unpadded) reconstruction of the anchor before it in display order (list 0), ref1 = the
+ * anchor after it (list 1); both integer searches, list-0 tree, list-1 refinement, bi-prediction trial.  centers0 / centers1, me_dump0 / me_dump1: per list */
+int mihevc_k_b_frame(int device, const void *src_y, const void *src_u, const void *src_v,
+                     const void *ref0_y, const void *ref0_u, const void *ref0_v, const void *ref1_y, const void *ref1_u, const void *ref1_v, int width, int height,
+                     const mihevc_cost_params *prm, const int16_t *centers0, const int16_t *centers1, void *rec_y, void *rec_u, void *rec_v,
+                     mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump0, int32_t *me_dump1, uint64_t *est_bits_q4);
 /* K4a: deblocking in place */
 int mihevc_k_deblock(int device, void *rec_y, void *rec_u, void *rec_v, int width, int height,
                      const mihevc_cu_rec *cu, int bit_depth);

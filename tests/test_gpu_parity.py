@@ -449,3 +449,27 @@ def test_concurrent_sessions_from_several_threads(lib):
     for t in threads:
         t.join()
     assert failed == []
+
+
+@pytest.mark.parametrize("w,h,qp,bd,rng,pre", [(96, 80, 26, 8, 8, 0), (136, 72, 32, 8, 12, 1), (200, 104, 24, 10, 15, 1), (544, 320, 22, 8, 15, 1)])
+def test_b_picture_stage_equals_oracle(api, w, h, qp, bd, rng, pre):
+    """cfg.bframes on the device (mihevc_k_b_frame: k_me_search against both anchors + k_inter_ctu_b) against orc_analyze_b_frame, bit for bit: both
+    integer-search dumps, records incl. which lists and the list-1 vector, levels, reconstruction, estimate; then the deblocking kernel with the
+    two-list boundary strength."""
+    from hevc_amd import _lib
+    cp_i, cp_p, cp_b = _lib.cost_params(max(0, qp - 3), bd, rng), _lib.cost_params(qp, bd, rng), _lib.cost_params(qp + 2, bd, rng)
+    cp_p.rdo_zero = cp_b.rdo_zero = 1
+    to_prm = lambda cp: O.Params(cp.qp, cp.qp_c, cp.bit_depth, cp.lambda_sad_q4, cp.lambda_q4, cp.me_range, 1, 1, 0, 0, 0, cp.rdo_zero, 0)      # noqa: E731
+    f = [util.synth_frame(h, w, seed=23, shift=(3 * i, 2 * i), bit_depth=bd) for i in range(3)]
+    a0 = O.analyze_intra(f[0], to_prm(cp_i))
+    r0, _ = O.sao(f[0], O.deblock(a0.rec, a0.cu, bd), to_prm(cp_i))
+    a2 = O.analyze_inter(f[2], r0, to_prm(cp_p))
+    r2, _ = O.sao(f[2], O.deblock(a2.rec, a2.cu, bd), to_prm(cp_p))
+    c0 = O.search_centres(f[1], f[0], bd) if pre else None
+    c1 = O.search_centres(f[1], f[2], bd) if pre else None
+    want = O.analyze_b(f[1], r0, r2, to_prm(cp_b), c0, c1, dump_me=True)
+    got = api.b(f[1], r0, r2, cp_b, c0, c1)
+    assert np.array_equal(want.me[0], got.me[0]) and np.array_equal(want.me[1], got.me[1]), "integer searches differ"
+    assert util.same_analysis(want, got), util.describe_diff(want, got)
+    assert len({int(x) & 96 for x in np.unique(want.cu["flags"])}) >= 2
+    assert api.deblock(want.rec, want.cu, bd).same(O.deblock(want.rec, want.cu, bd))
