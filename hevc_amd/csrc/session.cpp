@@ -150,7 +150,7 @@ private:
 
 struct Packet {
     std::vector<uint8_t> data;
-    int64_t pts = 0;
+    int64_t pts = 0, dts = 0;
     bool key = false, ready = false;
 };
 
@@ -198,9 +198,9 @@ struct mihevc_session {
     std::vector<Src> free_src;
     // per lane
     struct Lane {
-        void *rec_base[2][3], *rec_p[2][3]; int rec_stride[3];       // padded final reconstructions (ping-pong)
+        void *rec_base[3][3], *rec_p[3][3]; int rec_stride[3];       // padded final reconstructions: the anchors ping-pong between 0 and 1; 2 = B pictures (cfg.bframes; never a reference)
         void *work_base[3], *work_p[3]; int work_stride[3];           // pre-deblock / deblocked picture (unpadded)
-        int32_t *me = nullptr;
+        int32_t *me = nullptr, *me1 = nullptr;      // integer-search tables (me1: list 1 of B pictures)
         IpInfo *ip = nullptr;      // per CTU: inter pass -> intra second pass of P pictures
         IntraPlan *plan = nullptr; // per CTU: k_intra_plan -> k_intra_diag (IDR pictures)
         uint8_t *sym_dev[kRing] = {nullptr}, *sym_host[kRing] = {nullptr};
@@ -230,6 +230,8 @@ struct mihevc_session {
     double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
     bool rho_measured = false;                // the session's first chunk measures rho with a trial analysis of the GOPs' first P picture
     double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
+    double beta_bp = 0.45;                    // cfg.bframes: learned (B bits at QP + 2) / (P bits at QP): what a B picture takes of the GOP budget beside a P picture
+    int64_t pts_step = 1, first_pts = 0;      // pts distance of the first two frames: with B pictures dts = (pts of the frame at the packet's place in decoding order) - pts_step
     int idr_qp_hint = -1;                     // mean IDR QP the last chunk settled on: where the next chunk's IDR analysis starts
     int last_gop_len = 0;                     // length of the stream's previous GOP (picture timing SEI at the next IDR)
     double scene_avg = 0;                     // running mean of the picture-to-picture difference over ordinary pictures (scene-cut detector)
@@ -292,10 +294,11 @@ int ensure_lanes(mihevc_session *s, int n)
     while ((int)s->lane.size() < n) {
         mihevc_session::Lane L;
         memset(&L, 0, sizeof L);
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < (s->cfg.bframes > 0 ? 3 : 2); k++)
             if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, 1)) return e;
         if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, 2)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
+        if (s->cfg.bframes > 0) HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me1));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, (void **)&L.plan));
         for (int k = 0; k < s->ring; k++) {
@@ -340,8 +343,8 @@ template <typename T> Plane<const T> mkc(void *p, int stride) { return Plane<con
 // puts the access unit together and publishes the packet.  One part = the whole picture in one job, as before round 3.
 struct PictureJob {
     mihevc_session *s;
-    int slot, lane_i, slice_type, poc, qp, prev_gop_len, parts, n_tiles;
-    int64_t index, pts;
+    int slot, lane_i, slice_type, poc, qp, prev_gop_len, parts, n_tiles, dec_pos;      // poc: place in the GOP in display order, dec_pos: in decoding order
+    int64_t index, pts, dts, dec_index;      // index: display order (frame records, reconstructions); dec_index: decoding order (packets)
     bool first_of_stream;
     PictureSyms pic;
     std::vector<std::vector<uint8_t>> sub;
@@ -366,7 +369,7 @@ void publish_picture(PictureJob *j)
     SymLayout sl(s->w, s->h);
     const uint8_t *b = s->lane[j->lane_i].sym_host[j->slot];
     Packet pk;
-    pk.pts = j->pts; pk.key = j->slice_type == 2;
+    pk.pts = j->pts; pk.dts = j->dts; pk.key = j->slice_type == 2;
     // a picture's later slices (sessions on other devices, cfg.slice_index > 0) contribute their slice NAL unit only: the access unit's
     // delimiter, parameter sets and SEI come with slice 0
     const bool au_head = s->cfg.slice_count <= 1 || s->cfg.slice_index == 0;
@@ -375,7 +378,9 @@ void publish_picture(PictureJob *j)
     if (s->cfg.hrd && au_head) {
         if (j->slice_type == 2) write_sei_buffering_period(s->cfg, pk.data);
         // clock ticks since the previous buffering period: position in the GOP, or the previous GOP's length at an IDR
-        write_sei_pic_timing(s->cfg, (uint32_t)(j->poc > 0 ? j->poc - 1 : (j->index > 0 ? j->prev_gop_len - 1 : 0)), pk.data);
+        // (cfg.bframes: removal happens in decoding order; a picture is shown one tick after the picture at its display place was removed)
+        write_sei_pic_timing(s->cfg, (uint32_t)(j->dec_pos > 0 ? j->dec_pos - 1 : (j->dec_index > 0 ? j->prev_gop_len - 1 : 0)), pk.data,
+                             s->cfg.bframes > 0 ? (uint32_t)(j->poc + 1 - j->dec_pos) : 0u);
     }
     assemble_picture(s->cfg, j->pic, j->sub, pk.data, false);
     const unsigned long long *sse = (const unsigned long long *)(b + sl.sse);
@@ -398,7 +403,7 @@ void publish_picture(PictureJob *j)
                 fr.est_known = true;
             }
         }
-        s->packets[index] = std::move(pk);
+        s->packets[j->dec_index] = std::move(pk);
         s->frames_done++;
         delete j;
         s->jobs_open[slot]--;
@@ -475,6 +480,12 @@ static int group_sum(mihevc_session *s, std::vector<double> &v)
     if (!s->group->allreduce(v)) { s->failed = true; s->err = "another slice of the picture failed"; return MIHEVC_EDEVICE; }
     return 0;
 }
+
+// cfg.bframes: a closed GOP of `len` pictures is coded I0 P2 b1 P4 b3 ...: step 0 the IDR picture, odd steps the anchors (P), even steps the B picture between the
+// last two anchors; the GOP's last picture is always an anchor.  Display position / slice type (2 I, 1 P, 0 B) of step t; without B pictures step = position.
+static inline int pos_of_step(bool bf, int t, int len) { return !bf || t == 0 ? t : (t & 1) ? std::min(t + 1, len - 1) : t - 1; }
+static inline int type_of_step(bool bf, int t) { return t == 0 ? 2 : (bf && !(t & 1)) ? 0 : 1; }
+constexpr int kQpB = 2;      // a B picture takes the QP of the anchors around it + 2 (x265 pbratio 1.3): nothing predicts from it
 
 template <typename T> int encode_chunk(mihevc_session *s)
 {
@@ -592,7 +603,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
     const size_t flat_off = (size_t)(steps + 1) * lay.total;  // + one block for the rho trial (below)
-    const size_t need = flat_off + (size_t)n * sizeof(PreArgs<T>);          // + one pre-search block per picture of the chunk (stream order)
+    const bool bf = s->cfg.bframes > 0;
+    const int n_pre = bf ? 2 * n : n;       // pre-search blocks: one per picture of the chunk (stream order); with B pictures a second one per picture for list 1
+    const size_t need = flat_off + (size_t)n_pre * sizeof(PreArgs<T>);
     if (need > s->args_cap) {
         BufferCache &bc = BufferCache::get();
         bc.release(s->device, s->args_cap, false, s->d_args); bc.release(s->device, s->args_cap, true, s->h_args);
@@ -604,9 +617,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
     }
     uint8_t *ha = s->h_args, *da = (uint8_t *)s->d_args;
     // the chunk's 1/4-size source pictures and search centres (cfg.pre_search): [n pictures of (w/4)(h/4) bytes | n x n_ctu x 2 int16]
-    const size_t low_pic = (size_t)(s->w >> 2) * (s->h >> 2), low_bytes = ((size_t)n * low_pic + 255) & ~(size_t)255;
+    const size_t low_pic = (size_t)(s->w >> 2) * (s->h >> 2), low_bytes = ((size_t)n_pre * low_pic + 255) & ~(size_t)255;
     if (s->cfg.pre_search) {
-        const size_t want = low_bytes + (size_t)n * s->n_ctu * 2 * sizeof(int16_t);
+        const size_t want = low_bytes + (size_t)n_pre * s->n_ctu * 2 * sizeof(int16_t);
         if (want > s->low_cap) {
             BufferCache &bc = BufferCache::get();
             bc.release(s->device, s->low_cap, false, s->d_low);
@@ -633,7 +646,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
     for (int t = 0; t < steps; t++)
         for (int g = 0; g < gops; g++) {
             if (t >= glen[(size_t)g]) continue;
-            int fi = gstart[(size_t)g] + t;
+            const int pos = pos_of_step(bf, t, glen[(size_t)g]), ptype = type_of_step(bf, t);
+            int fi = gstart[(size_t)g] + pos;
             // lanes with a picture at step t are a prefix [0, batch): they are sorted by GOP length
             batch[t] = g + 1;
             mihevc_session::Lane &L = s->lane[g];
@@ -641,7 +655,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
             StepView<T> hv(ha, lay, t);
             struct { IntraArgs<T> &intra; InterArgs<T> &inter; DeblockArgs<T> &dbk_v, &dbk_h; SaoArgs<T> &sao; } A{hv.intra[g], hv.inter[g], hv.dbk_v[g], hv.dbk_h[g], hv.sao[g]};
             uint8_t *sym = L.sym_dev[slot_of(t)];
-            const int cur = t & 1, prev = cur ^ 1;
+            // reconstruction buffers: anchor number k (the IDR picture is 0) goes to buffer k & 1 and predicts from the other one; the B picture between
+            // anchors k - 1 and k reads both and goes to buffer 2
+            const int anchor = !bf ? t : (t + 1) / 2;
+            const int cur = ptype == 0 ? 2 : anchor & 1, prev = ptype == 0 ? (t / 2 - 1) & 1 : (anchor & 1) ^ 1, nxt = ptype == 0 ? (t / 2) & 1 : 0;
+            const int ref_pos = ptype == 0 ? pos - 1 : !bf ? pos - 1 : pos_of_step(bf, std::max(0, t - 2), glen[(size_t)g]) * (t > 1) ;      // display position of the list-0 reference
             const CostParams P = prm_for(t == 0 ? s->qp_i : s->qp_p);      // provisional; the controller patches it per step
             for (int i = 0; i < 3; i++) {
                 A.intra.src[i] = mkc<T>(src.p[i], src.stride[i]); A.intra.rec[i] = mk<T>(L.work_p[i], L.work_stride[i]);
@@ -721,19 +739,25 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.sparse_coef = A.inter.sparse_coef = 1;
             A.intra.diagonal = 0;
             A.inter.centers = nullptr; A.inter.me = L.me;
-            for (int i = 0; i < 3; i++) A.inter.ref1[i] = Plane<const T>{nullptr, 0};
-            A.inter.centers1 = nullptr; A.inter.me1 = nullptr;
+            for (int i = 0; i < 3; i++) A.inter.ref1[i] = ptype == 0 ? mkc<T>(L.rec_p[nxt][i], L.rec_stride[i]) : Plane<const T>{nullptr, 0};
+            A.inter.centers1 = nullptr; A.inter.me1 = ptype == 0 ? L.me1 : nullptr;
             if (s->cfg.pre_search) {       // search centres: the chunk's pre-search fills them for every picture (below)
-                const size_t idx = (size_t)(gstart[(size_t)g] + t);
+                const size_t idx = (size_t)fi, ridx = (size_t)(gstart[(size_t)g] + std::max(0, ref_pos));
                 PreArgs<T> &P4 = ((PreArgs<T> *)(ha + flat_off))[idx];
                 P4.src = A.inter.src[0]; P4.ref = A.inter.src[0];
-                P4.lsrc = low + idx * low_pic; P4.lref = low + (t > 0 ? idx - 1 : idx) * low_pic;      // an IDR picture's centres are never read
+                P4.lsrc = low + idx * low_pic; P4.lref = low + (t > 0 ? ridx : idx) * low_pic;      // against the SOURCE of the picture it will predict from; an IDR picture's centres are never read
                 P4.w = s->w; P4.h = s->h; P4.bit_depth = s->cfg.bit_depth; P4.centers = cen + idx * (size_t)s->n_ctu * 2;
                 if (t > 0) A.inter.centers = P4.centers;
+                if (bf) {                  // the second block: a B picture against the source of the anchor AFTER it (other pictures: a copy of the first, never read)
+                    PreArgs<T> &P5 = ((PreArgs<T> *)(ha + flat_off))[(size_t)n + idx];
+                    P5 = P4;
+                    P5.lsrc = low + ((size_t)n + idx) * low_pic; P5.centers = cen + ((size_t)n + idx) * (size_t)s->n_ctu * 2;
+                    if (ptype == 0) { P5.lref = low + (idx + 1) * low_pic; A.inter.centers1 = P5.centers; }
+                }
             }
             // P pictures: the inter pass leaves per-CTU costs for the intra second pass, which runs on the same work picture,
             // records and levels with the one-tile PPS 0 geometry
-            const bool ipass = t > 0 && s->cfg.intra_in_p;
+            const bool ipass = ptype == 1 && s->cfg.intra_in_p;
             A.inter.ip = ipass ? L.ip : nullptr;
             A.intra.ip = ipass ? L.ip : nullptr;
             A.intra.plan = t == 0 ? L.plan : nullptr;      // P pictures' second pass plans and codes a CTU inside one workgroup
@@ -767,27 +791,31 @@ template <typename T> int encode_chunk(mihevc_session *s)
     }
     const double cpb_idr_cap = s->cfg.vbv_bufsize_kbits > 0 ? kIdrCpbShare * kCpbStart * share * s->cfg.vbv_bufsize_kbits * 1000.0 : 1e30;
     const int p_slots = s->ring - 1;          // a P step's CABAC job is complete once its slot has been handed out again
+    // output (display) index of the picture lane g codes at step j (cfg.bframes: steps are in decoding order)
+    auto fidx = [&](int g, int j) { return (size_t)(first_index + gstart[(size_t)g] + pos_of_step(bf, j, glen[(size_t)g])); };
     // P-picture QP of lane g at step t.  Every input is deterministic: CABAC sizes only of pictures whose ring slot has been
     // reused (steps <= t - p_slots), device estimates of steps <= t - 2 (the step loop waits for that copy), a model for the
     // picture in flight.  The controller solves for the constant QP that spends the rest of the GOP budget and walks towards
     // it (+3 / -1 per picture, dead band 0.75): a constant QP is what the budget buys the most PSNR with.
     auto decide_p = [&](int g, int t) -> int {
         std::lock_guard<std::mutex> l(s->m);
-        auto frame = [&](int j) -> mihevc_session::FrameRec & { return s->frames[(size_t)(first_index + gstart[(size_t)g] + j)]; };
-        // CABAC / estimate ratio of this GOP's finished P pictures, seeded with two pictures' worth of the session ratio
+        auto frame = [&](int j) -> mihevc_session::FrameRec & { return s->frames[fidx(g, j)]; };
+        auto is_p = [&](int j) { return type_of_step(bf, j) == 1; };
+        // CABAC / estimate ratio of this GOP's finished P / B pictures, seeded with two pictures' worth of the session ratio
         double sum_b = 0, sum_e = 0, seed = 0;
         for (int j = 1; j <= t - p_slots; j++)
             if (frame(j).bits >= 0 && frame(j).est_q4 > 0) { sum_b += (double)frame(j).bits; sum_e += (double)frame(j).est_q4 / 16.0; }
         for (int j = t - 2; j >= 1 && seed == 0; j--) if (frame(j).est_known) seed = 2.0 * (double)frame(j).est_q4 / 16.0;
         const double rp = (sum_e + seed) > 0 ? (sum_b + s->ratio_p * seed) / (sum_e + seed) : s->ratio_p;
         // reference point (q_ref, b_ref) of the rate model b(q) = b_ref * 2^((q_ref - q) / 6): the last two P estimates, or the
-        // IDR picture scaled by the learned P/I ratio before any P estimate exists
+        // IDR picture scaled by the learned P/I ratio before any P estimate exists.  (cfg.bframes: P pictures only; a B picture is modelled as
+        // beta_bp x a P picture at its QP - kQpB.)
         const auto &idr = frame(0);
         const double idr_bits = (double)idr.est_q4 / 16.0 * s->ratio_i;
         double b_ref = idr_bits * s->rho_pi, lg = 0;
         int q_ref = idr.qp, have = 0;
         for (int j = t - 2; j >= 1 && have < 2; j--) {
-            if (!frame(j).est_known) continue;
+            if (!is_p(j) || !frame(j).est_known) continue;
             const double b = std::max(1.0, (double)frame(j).est_q4 / 16.0 * rp);
             if (!have) q_ref = frame(j).qp;
             lg += std::log2(b) + (frame(j).qp - q_ref) / 6.0;
@@ -799,10 +827,12 @@ template <typename T> int encode_chunk(mihevc_session *s)
             const auto &fr = frame(j);
             if (j <= t - p_slots && fr.bits >= 0) spent += (double)fr.bits;
             else if (j <= t - 2 && fr.est_known) spent += (double)fr.est_q4 / 16.0 * rp;
-            else spent += b_ref * std::exp2((q_ref - fr.qp) / 6.0);
+            else spent += (is_p(j) ? 1.0 : s->beta_bp) * b_ref * std::exp2((q_ref - (fr.qp - (is_p(j) ? 0 : kQpB))) / 6.0);
         }
-        const int left = gop_len[g] - t;
-        double target = (budget[g] - spent) / std::max(1, left);
+        // what is left of the budget, shared by the pictures still to come in units of a P picture (a B picture counts beta_bp)
+        double units = 0;
+        for (int j = t; j < gop_len[g]; j++) units += is_p(j) ? 1.0 : s->beta_bp;
+        double target = (budget[g] - spent) / std::max(0.5, units);
         target = std::max(target, 0.25 * budget[g] / gop_len[g]);
         const double q_ss = q_ref + 6.0 * std::log2(b_ref / target);
         int qp;
@@ -818,8 +848,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
         hv.intra[g].prm = hv.inter[g].prm = hv.sao[g].prm = prm_for(qp);
         if (t > 0) { hv.intra[g].prm.tile_cols = s->ptiles.cols; hv.intra[g].prm.tile_rows = s->ptiles.rows; }
         std::lock_guard<std::mutex> l(s->m);
-        auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + t)];
-        fr.qp = qp; fr.type = t == 0 ? 2 : 1;
+        auto &fr = s->frames[fidx(g, t)];
+        fr.qp = qp; fr.type = type_of_step(bf, t);
     };
     // ---- lock-step over the GOPs ----
     hipEvent_t t_begin, t_end;
@@ -849,11 +879,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
             std::vector<double> v((size_t)batch[j]);
             {
                 std::lock_guard<std::mutex> l(s->m);
-                for (int g = 0; g < batch[j]; g++) v[(size_t)g] = (double)s->frames[(size_t)(first_index + gstart[(size_t)g] + j)].bits_local;
+                for (int g = 0; g < batch[j]; g++) v[(size_t)g] = (double)s->frames[fidx(g, j)].bits_local;
             }
             if (int e = group_sum(s, v)) return e;
             std::lock_guard<std::mutex> l(s->m);
-            for (int g = 0; g < batch[j]; g++) s->frames[(size_t)(first_index + gstart[(size_t)g] + j)].bits = (long long)v[(size_t)g];
+            for (int g = 0; g < batch[j]; g++) s->frames[fidx(g, j)].bits = (long long)v[(size_t)g];
         }
         if (t >= 2) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_copy[slot_of(t - 2)], 0));      // the SSE pass of step t - 2 still reads the picture buffer this step reuses
         if (s->rc_on && t >= 3) {
@@ -867,7 +897,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             {
                 std::lock_guard<std::mutex> l(s->m);
                 for (int g = 0; g < batch[j]; g++) {
-                    auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + j)];
+                    auto &fr = s->frames[fidx(g, j)];
                     if (!fr.est_known) { fr.est_q4 = (unsigned long long)v[(size_t)g]; fr.est_known = true; }
                 }
             }
@@ -875,9 +905,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
         for (int g = 0; g < B; g++) {
             // IDR pictures under rate control start where the last chunk's IDR pictures ended (first chunk: kIdrStart above the CRF's IDR QP)
             const int q_idr = !s->rc_on ? s->qp_i : std::min(51, std::max(s->qp_i, s->idr_qp_hint >= 0 ? s->idr_qp_hint : s->qp_i + kIdrStart));
-            qp_step[g] = t == 0 ? q_idr : (s->rc_on ? decide_p(g, t) : s->qp_p);
+            const int ptype = type_of_step(bf, t);
+            // a B picture: the QP of the last anchor + kQpB (nothing predicts from it); it does not move the controller's walk
+            qp_step[g] = t == 0 ? q_idr : ptype == 0 ? std::min(51, qp_prev[g] + kQpB) : (s->rc_on ? decide_p(g, t) : s->qp_p);
             patch_qp(t, g, qp_step[g]);
-            qp_prev[g] = qp_step[g];
+            if (ptype != 0) qp_prev[g] = qp_step[g];
         }
         if (t == 0) {
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
@@ -885,7 +917,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             STAGE(0, B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B, s->tiles.cols, s->tiles.rows, s->cfg.pre_search ? s->ev_args : nullptr));
             if (s->cfg.pre_search) {       // the chunk's search centres: beside the anti-diagonal chain, not beside k_intra_plan (both want the ALUs)
                 HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_args, 0));
-                HIPCK(s, launch_pre_search_chunk<T>(s->st_pre, (const PreArgs<T> *)(da + flat_off), s->w, s->h, s->n_ctu, n));
+                HIPCK(s, launch_pre_search_chunk<T>(s->st_pre, (const PreArgs<T> *)(da + flat_off), s->w, s->h, s->n_ctu, n_pre));
                 HIPCK(s, hipEventRecord(s->ev_pre, s->st_pre));
             }
             if (s->rc_on) {
@@ -913,7 +945,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         if (gop_len[g] < 2) d = ib <= budget[g] ? -1e9 + q : 1e9 + ib;          // IDR-only GOP: finest that fits
                         else if (rest <= 0) d = 1e9 + ib;
                         else {
-                            const double q_ss = std::max((double)s->qp_p, q + 6.0 * std::log2(ib * rho / (rest / (gop_len[g] - 1))));
+                            double units = 0;              // the GOP's other pictures in units of a P picture (cfg.bframes: a B picture counts beta_bp)
+                            for (int j = 1; j < gop_len[g]; j++) units += type_of_step(bf, j) == 1 ? 1.0 : s->beta_bp;
+                            const double q_ss = std::max((double)s->qp_p, q + 6.0 * std::log2(ib * rho / (rest / std::max(0.5, units))));
                             d = std::fabs(q_ss - (q + 3));
                         }
                         if (d < best_d) { best_d = d; pick = q; }
@@ -1027,12 +1061,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 HIPCK(s, launch_prep_p_step<T>(s->st_compute, pv.sao, (const PreArgs<T> *)nullptr, dv.intra, dv.inter, dv.sao, sp, s->w, s->h, B));
                 if (t == 1 && s->cfg.pre_search) HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_pre, 0));      // the chunk's search centres (st_pre, under the IDR step)
             }
-            // stage 1 = the integer search around the chunk's search centres
+            // stage 1 = the integer search around the chunk's search centres (a B picture: against both anchors)
+            const bool bstep = type_of_step(bf, t) == 0;
             if (int e_ = mark(1, B, true)) return e_;
-            HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range, 0));
+            if (bstep) HIPCK(s, launch_me_search<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range, 1));
             if (int e_ = mark(1, B, false)) return e_;
-            STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
-            if (s->cfg.intra_in_p) STAGE(7, B, launch_intra_p<T>(s->st_compute, dv.intra, s->n_ctu, B));
+            if (bstep) STAGE(2, B, launch_inter_ctu_b<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            else STAGE(2, B, launch_inter_ctu<T>(s->st_compute, dv.inter, s->n_ctu, B, s->me_range));
+            if (s->cfg.intra_in_p && !bstep) STAGE(7, B, launch_intra_p<T>(s->st_compute, dv.intra, s->n_ctu, B));
         }
         if (grp) {
             // X1: kSeamRows rows of the pre-deblock reconstruction + one row of CU records either side of every seam.  Every band puts its own first and last
@@ -1069,15 +1106,15 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         if (s->keep_recon) {
             for (int g = 0; g < B; g++) {
-                int fi = gstart[(size_t)g] + t;
-                std::vector<uint16_t> &dst = s->recon[s->frames_in - n + fi];
+                std::vector<uint16_t> &dst = s->recon[(int64_t)fidx(g, t)];
+                const int rbuf = !bf ? (t & 1) : type_of_step(bf, t) == 0 ? 2 : ((t + 1) / 2) & 1;
                 dst.assign((size_t)s->w * s->h * 3 / 2, 0);
                 std::vector<uint8_t> tmp((size_t)s->w * s->h * 3 / 2 * esize(s));
                 size_t off = 0;
                 HIPCK(s, hipStreamSynchronize(s->st_compute));
                 for (int i = 0; i < 3; i++) {
                     int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h;
-                    HIPCK(s, hipMemcpy2D(tmp.data() + off * esize(s), pw * esize(s), s->lane[g].rec_p[t & 1][i], s->lane[g].rec_stride[i] * esize(s),
+                    HIPCK(s, hipMemcpy2D(tmp.data() + off * esize(s), pw * esize(s), s->lane[g].rec_p[rbuf][i], s->lane[g].rec_stride[i] * esize(s),
                                          pw * esize(s), ph, hipMemcpyDeviceToHost));
                     off += (size_t)pw * ph;
                 }
@@ -1092,12 +1129,17 @@ template <typename T> int encode_chunk(mihevc_session *s)
         // host jobs per picture: the pool's threads shared by the pictures of this step (their tiles, when the picture has several: cfg.p_tiles / IDR grid)
         const int parts_wanted = std::max(1, s->host_threads / std::max(1, B));
         for (int g = 0; g < B; g++) {
-            int fi = gstart[(size_t)g] + t;
+            const int pos = pos_of_step(bf, t, glen[(size_t)g]);
             PictureJob *j = new PictureJob();
-            j->s = s; j->slot = lane_slot[g]; j->lane_i = g; j->index = s->frames_in - n + fi; j->pts = s->pending[fi].pts;
+            j->s = s; j->slot = lane_slot[g]; j->lane_i = g; j->index = (int64_t)fidx(g, t); j->pts = s->pending[gstart[(size_t)g] + pos].pts;
+            // packets leave in DECODING order: place t of the GOP; dts = the pts of the frame at that place in display order, one frame earlier when
+            // B pictures reorder (an anchor is decoded one picture before the B picture in front of it is shown)
+            j->dec_index = first_index + gstart[(size_t)g] + t;
+            j->dts = s->pending[gstart[(size_t)g] + t].pts - (bf ? s->pts_step : 0);
+            j->dec_pos = t;
             j->prev_gop_len = prev_len[(size_t)g];
-            j->slice_type = t == 0 ? 2 : 1; j->poc = t; j->qp = qp_step[g]; j->first_of_stream = j->index == 0;
-            j->pic.slice_type = j->slice_type; j->pic.poc = t; j->pic.qp = j->qp;
+            j->slice_type = type_of_step(bf, t); j->poc = pos; j->qp = qp_step[g]; j->first_of_stream = j->dec_index == 0;
+            j->pic.slice_type = j->slice_type; j->pic.poc = pos; j->pic.qp = j->qp;
             picture_symbols(s, j->slot, g, j->pic);
             j->n_tiles = picture_tiles(s->cfg, j->pic);
             j->parts = std::min(j->n_tiles, parts_wanted);
@@ -1150,23 +1192,25 @@ template <typename T> int encode_chunk(mihevc_session *s)
         // learn from the finished chunk (all CABAC sizes are known now, so this is deterministic): CABAC bits per estimated
         // bit for I and P pictures, and the P/I size ratio at equal QP
         std::lock_guard<std::mutex> l(s->m);
-        double bi = 0, ei = 0, bp = 0, ep = 0, lg = 0;
-        int np = 0;
+        double bi = 0, ei = 0, bp = 0, ep = 0, lg = 0, lgb = 0;
+        int np = 0, nb = 0;
         for (int g = 0; g < gops; g++) {
             const auto &idr = s->frames[(size_t)(first_index + gstart[(size_t)g])];
             if (idr.bits < 0 || !idr.est_q4) continue;
             bi += (double)idr.bits; ei += (double)idr.est_q4 / 16.0;
-            for (int j = 1; j < gop_len[g]; j++) {
-                const auto &fr = s->frames[(size_t)(first_index + gstart[(size_t)g] + j)];
+            for (int j = 1; j < gop_len[g]; j++) {          // steps: decoding order
+                const auto &fr = s->frames[fidx(g, j)];
                 if (fr.bits <= 0 || !fr.est_q4) continue;
                 bp += (double)fr.bits; ep += (double)fr.est_q4 / 16.0;
-                lg += std::log2((double)fr.bits / (double)idr.bits) + (fr.qp - idr.qp) / 6.0;
-                np++;
+                if (type_of_step(bf, j) == 1) { lg += std::log2((double)fr.bits / (double)idr.bits) + (fr.qp - idr.qp) / 6.0; np++; }
+                else { lgb += std::log2((double)fr.bits / (double)idr.bits) + (fr.qp - kQpB - idr.qp) / 6.0; nb++; }
             }
         }
         if (ei > 0) s->ratio_i = 0.5 * s->ratio_i + 0.5 * bi / ei;
         if (ep > 0) s->ratio_p = 0.5 * s->ratio_p + 0.5 * bp / ep;
         if (np) s->rho_pi = std::min(1.0, std::max(1.0 / 256, 0.5 * s->rho_pi + 0.5 * std::exp2(lg / np)));
+        // a B picture at QP + kQpB against a P picture at QP (both brought to the IDR picture's QP through the 2^(-dQP/6) rule)
+        if (np && nb) s->beta_bp = std::min(1.5, std::max(0.05, 0.5 * s->beta_bp + 0.5 * std::exp2(lgb / nb - lg / np)));
     }
     for (auto &src : s->pending) if (!src.borrowed) s->free_src.push_back(src);
     s->pending.clear();
@@ -1196,6 +1240,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 1) || (cfg->height & 1) || cfg->width > 8192 || cfg->height > 4352) return MIHEVC_EINVAL;
     if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return MIHEVC_EINVAL;
     if (cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->keyint < 1 || cfg->keyint > 240) return MIHEVC_EINVAL;
+    if (cfg->bframes < 0 || cfg->bframes > 1 || (cfg->bframes && cfg->slice_count > 1)) return MIHEVC_EINVAL;      // B pictures: whole pictures only (for now)
     if (cfg->slice_count > 1) {        // one slice of a picture: a band of whole CTU rows (the last band takes the picture's remainder)
         if (cfg->slice_count > 16 || cfg->slice_index < 0 || cfg->slice_index >= cfg->slice_count || cfg->pic_height < cfg->height) return MIHEVC_EINVAL;
         int rows = 0;
@@ -1292,6 +1337,7 @@ static int ingest(mihevc_session *s, const void *y, const void *u, const void *v
         ((uintptr_t)y & 3) == 0 && ((uintptr_t)u & 3) == 0 && ((uintptr_t)v & 3) == 0 && (pitch_y * es) % 4 == 0 && (pitch_c * es) % 4 == 0) {
         for (int i = 0; i < 3; i++) { src.base[i] = nullptr; src.p[i] = const_cast<void *>(in[i]); src.stride[i] = i ? pitch_c : pitch_y; }
         src.pts = pts; src.borrowed = true;
+        if (s->frames_in == 0) s->first_pts = pts; else if (s->frames_in == 1) s->pts_step = std::max<int64_t>(1, pts - s->first_pts);
         s->pending.push_back(src);
         s->frames_in++;
         s->stats.frames_in = s->frames_in;
@@ -1315,6 +1361,7 @@ static int ingest(mihevc_session *s, const void *y, const void *u, const void *v
     }
     if (!device_src && !async) HIPCK(s, hipStreamSynchronize(s->st_up));     // caller's buffers may be reused on return
     else s->up_pending = true;
+    if (s->frames_in == 0) s->first_pts = pts; else if (s->frames_in == 1) s->pts_step = std::max<int64_t>(1, pts - s->first_pts);
     s->pending.push_back(src);
     s->frames_in++;
     s->stats.frames_in = s->frames_in;
@@ -1372,7 +1419,7 @@ int mihevc_receive_packet(mihevc_session *s, const uint8_t **data, size_t *size,
     if (it == s->packets.end() || !it->second.ready) return (s->flushed && s->next_out >= s->frames_in) ? MIHEVC_EOF : MIHEVC_EAGAIN;
     s->cur_packet = std::move(it->second.data);
     if (pts) *pts = it->second.pts;
-    if (dts) *dts = it->second.pts;        // no reordering: decode order == display order
+    if (dts) *dts = it->second.dts;        // packets come in decoding order; dts < pts only with B pictures (cfg.bframes)
     if (keyframe) *keyframe = it->second.key;
     s->packets.erase(it);
     s->next_out++;
@@ -1458,7 +1505,9 @@ void mihevc_close(mihevc_session *s)
     for (auto &x : s->free_src) free3(x.base, 0);
     for (auto &L : s->lane) {
         free3(L.rec_base[0], 1); free3(L.rec_base[1], 1); free3(L.work_base, 2);
+        if (L.rec_base[2][0]) free3(L.rec_base[2], 1);
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me);
+        bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me1);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, L.plan);
         for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }

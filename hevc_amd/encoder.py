@@ -174,6 +174,18 @@ class Encoder:
             self._check(rc, "receive_packet")
             yield C.string_at(data, size.value), pts.value, bool(key.value)
 
+    def packets_dts(self) -> Iterator[Tuple[bytes, int, bool, int]]:
+        """The same with the decoding time stamp: (annexb bytes, pts, keyframe, dts).  Packets always come in DECODING order; dts differs from pts only
+        when the session codes B pictures (cfg.bframes)."""
+        data, size = C.POINTER(C.c_uint8)(), C.c_size_t()
+        pts, dts, key = C.c_int64(), C.c_int64(), C.c_int()
+        while True:
+            rc = self._lib.mihevc_receive_packet(self._s, C.byref(data), C.byref(size), C.byref(pts), C.byref(dts), C.byref(key))
+            if rc in (_lib.EAGAIN, _lib.EOF):
+                return
+            self._check(rc, "receive_packet")
+            yield C.string_at(data, size.value), pts.value, bool(key.value), dts.value
+
     def headers(self) -> bytes:
         data, size = C.POINTER(C.c_uint8)(), C.c_size_t()
         self._check(self._lib.mihevc_get_headers(self._s, C.byref(data), C.byref(size)), "get_headers")
@@ -529,13 +541,13 @@ def encode_file(file_path: Path, out_path: Path, info: VideoInfo, progress_callb
                     if stop_event is not None and stop_event.is_set():
                         return 1
                     enc.send(y, u, v, pts=i)
-                    for data, pts, key in enc.packets():
-                        mux.add_sample(data, pts, key)
+                    for data, pts, key, dts in enc.packets_dts():
+                        mux.add_sample(data, pts, key, dts)
                         n_out += 1
                     progress()
                 enc.flush()
-                for data, pts, key in enc.packets():
-                    mux.add_sample(data, pts, key)
+                for data, pts, key, dts in enc.packets_dts():
+                    mux.add_sample(data, pts, key, dts)
                     n_out += 1
                 progress()
                 headers = enc.headers()

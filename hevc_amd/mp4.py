@@ -84,9 +84,11 @@ class Mp4Writer:
         self._sizes: List[int] = []
         self._sync: List[int] = []
         self._pts: List[int] = []
+        self._cts: List[int] = []          # composition offset of every sample in frames (pts - dts): non-zero only with B pictures (cfg.bframes)
 
-    def add_sample(self, annexb: bytes, pts: int, keyframe: bool):
-        """One access unit; parameter sets are dropped (hvc1 keeps them in hvcC only), NALs get 4-byte lengths."""
+    def add_sample(self, annexb: bytes, pts: int, keyframe: bool, dts: int = None):
+        """One access unit, in DECODING order; parameter sets are dropped (hvc1 keeps them in hvcC only), NALs get 4-byte lengths.  dts (same unit as
+        pts: frames) only differs from pts when B pictures reorder: the track then gets a ctts box and an edit list that takes the first delay out."""
         size = 0
         for nal in split_annexb(annexb):
             if nal_type(nal) in (32, 33, 34):
@@ -96,6 +98,7 @@ class Mp4Writer:
             size += 4 + len(nal)
         self._sizes.append(size)
         self._pts.append(pts)
+        self._cts.append(0 if dts is None else max(0, pts - dts))
         if keyframe:
             self._sync.append(len(self._sizes))
 
@@ -137,9 +140,21 @@ class Mp4Writer:
         # 4 GiB — decided ONCE, before moov is sized (sizing moov with stco and then switching to co64 left the offset 4 bytes short)
         big = big_mdat or 4 * len(self._sizes) + (1 << 16) >= 1 << 32
 
+        # composition offsets (ctts, version 0: pts - dts >= 0 by construction) as runs, and the edit that starts the presentation at the first picture's time
+        ctts, edts = b'', b''
+        if any(self._cts):
+            runs = []
+            for v in self._cts:
+                if runs and runs[-1][1] == v:
+                    runs[-1][0] += 1
+                else:
+                    runs.append([1, v])
+            ctts = full_box(b'ctts', 0, 0, struct.pack('>I', len(runs)), b''.join(struct.pack('>II', k, v * delta) for k, v in runs))
+            edts = box(b'edts', full_box(b'elst', 0, 0, struct.pack('>I', 1), struct.pack('>IIHH', dur, min(self._cts[:1] or [0]) * delta, 1, 0)))
+
         def moov_with(chunk_offset: int) -> bytes:
             stco = full_box(b'co64' if big else b'stco', 0, 0, struct.pack('>I', 1), struct.pack('>Q' if big else '>I', chunk_offset))
-            stbl = box(b'stbl', self._stsd(headers), stts, stss, stsc, stsz, stco)
+            stbl = box(b'stbl', self._stsd(headers), stts, ctts, stss, stsc, stsz, stco)
             minf = box(b'minf', full_box(b'vmhd', 0, 1, b'\0' * 8), box(b'dinf', full_box(b'dref', 0, 0, struct.pack('>I', 1), full_box(b'url ', 0, 1))), stbl)
             mdia = box(b'mdia', full_box(b'mdhd', 0, 0, struct.pack('>IIIIHH', 0, 0, ts, dur, 0x55C4, 0)),
                        full_box(b'hdlr', 0, 0, b'\0' * 4, b'vide', b'\0' * 12, b'VideoHandler\0'), minf)
@@ -147,7 +162,7 @@ class Mp4Writer:
                             struct.pack('>II', c.width << 16, c.height << 16))
             mvhd = full_box(b'mvhd', 0, 0, struct.pack('>IIII', 0, 0, ts, dur), struct.pack('>IH', 0x10000, 0x100), b'\0' * 10, mat, b'\0' * 24,
                             struct.pack('>I', 2))
-            return box(b'moov', mvhd, box(b'trak', tkhd, mdia))
+            return box(b'moov', mvhd, box(b'trak', tkhd, edts, mdia))
 
         moov = moov_with(0)
         moov = moov_with(len(ftyp) + len(moov) + head)        # box sizes do not depend on the offset VALUE once its width is fixed

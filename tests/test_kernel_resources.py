@@ -23,5 +23,7 @@ def test_no_kernel_uses_scratch(tmp_path):
         vgpr = int(re.search(r" VGPRs: (\d+)", b).group(1))
         seen[name] = (vgpr, scratch)
         assert scratch == 0, f"{name}: {scratch} bytes of scratch per lane ({vgpr} VGPRs)"
-    inter = [v for k, v in seen.items() if "k_inter_ctu" in k]
+    inter = [v for k, v in seen.items() if "k_inter_ctu" in k and "k_inter_ctu_b" not in k]
     assert inter and all(v[0] <= 128 for v in inter)            # 4 workgroups per CU
+    inter_b = [v for k, v in seen.items() if "k_inter_ctu_b" in k]
+    assert inter_b and all(v[0] <= 168 for v in inter_b)        # the B form (list-1 refinement + bi-prediction trial): 3 workgroups per CU
