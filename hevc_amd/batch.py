@@ -80,7 +80,10 @@ class BatchRunner:
         self.queue = deque(Path(f) for f in files)
         self.out_dir = Path(out_dir)
         self.n_devices = mi355x_device_count() if n_devices is None else n_devices
-        self.max_workers = max_workers or max(1, self.n_devices) or 1
+        # default: TWO worker processes per device.  One session leaves a good part of an MI355X idle while it walks an IDR picture's anti-diagonal chain or
+        # waits for its CABAC jobs (profiles/r02: k_intra_diag keeps < 20 % of the CUs busy); two ranks sharing one GPU reached 5674 fps against ~5000 for
+        # one (gpurun_out/r2_ranks2b.json), and short clips (<= 4 GOPs: one chunk) gain the most.  Worker k still drives device k % n_devices.
+        self.max_workers = max_workers or max(1, 2 * self.n_devices) or 1
         self.kw = dict(debug=debug, skip_validator=skip_validator, force_cpu=force_cpu, force_gpu=force_gpu)
         self.csv_path = Path(csv_path) if csv_path else self.out_dir / 'transcode_log.csv'
         self.on_progress, self.on_finished, self.convert = on_progress, on_finished, convert

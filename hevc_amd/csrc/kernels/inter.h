@@ -894,22 +894,28 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             int m[8][4];
             luma_half_diff((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8 + 4 * half), 32, m);
             hadamard_half(m);
-            uint32_t *x = s.rs.scratch + tid * 16;       // |values| <= 32 x the sample range: they fit 16 bits
+            // |values| <= 32 x the sample range: they fit 16 bits.  A lane's block is 16 dwords = four 16-byte chunks; chunk c goes to place (c + (lane >> 2)) & 3
+            // of the block: with the plain order lanes i and i + 4 hit the same banks in every 128-bit store and load (16 dwords x 4 = all 64 banks: a
+            // 4-way conflict, 41 % of this kernel's LDS cycles in profiles/r02_d); rotated, any 16 consecutive lanes cover the 64 banks once
+            uint32_t *x = s.rs.scratch + tid * 16;
+            const int sw = tid >> 2;
 #pragma unroll
             for (int j = 0; j < 8; j += 2) {
                 const uint32_t o[4] = {pack_lo16(m[j][0], m[j][1]), pack_lo16(m[j][2], m[j][3]), pack_lo16(m[j + 1][0], m[j + 1][1]), pack_lo16(m[j + 1][2], m[j + 1][3])};
-                store_x4(x + 2 * j, o);
+                store_x4(x + 4 * (((j >> 1) + sw) & 3), o);
             }
         });
         ex.wave_step([&](int tid) {      // the last butterfly stage across the halves: this lane takes rows 4 half .. 4 half + 3
             const int u = tid >> 1, half = tid & 1, t = u & 15;
             if (!s.rs.tu_log2[t]) return;
-            const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16 + 8 * half, *xb = xa + 16;
+            const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16, *xb = xa + 16;      // the pair's two blocks (both lanes of a pair share lane >> 2)
+            const int sw = tid >> 2;
             unsigned sum = 0;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 uint32_t va[4], vb[4];
-                load_x4(xa + 4 * c, va); load_x4(xb + 4 * c, vb);
+                const int at = 4 * ((2 * half + c + sw) & 3);
+                load_x4(xa + at, va); load_x4(xb + at, vb);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int a0 = (int)(int16_t)(va[i] & 0xffff), a1 = (int)(int16_t)(va[i] >> 16), b0 = (int)(int16_t)(vb[i] & 0xffff), b1 = (int)(int16_t)(vb[i] >> 16);

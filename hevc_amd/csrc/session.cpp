@@ -188,7 +188,9 @@ struct mihevc_session {
     bool is16 = false, keep_recon = false, flushed = false, failed = false, flushing = false;
     std::string err;
     hipStream_t st_compute = nullptr, st_copy = nullptr, st_pre = nullptr;      // st_pre: the chunk's pre-search, beside the IDR step
-    hipStream_t st_up = nullptr;       // uploads of host frames (mihevc_send_frame / _async); the chunk's first launch waits for ev_up
+    // uploads of host frames (mihevc_send_frame / _async) go through st_pre (idle outside a chunk's IDR step; a FOURTH stream per session made two of them share a
+    // hardware queue: the copy stream's SSE pass and symbol copies then queued behind the compute stream's kernels, +10 ms of bubbles per 300-frame clip); the
+    // chunk's first launch waits for ev_up
     hipEvent_t ev_up = nullptr;
     bool up_pending = false;
     // source pictures of the current chunk (device), in display order
@@ -1221,7 +1223,7 @@ int run_chunk(mihevc_session *s)
 {
     if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
     if (s->up_pending) {       // frames still on their way up (mihevc_send_frame_async, device-to-device copies): everything the chunk launches comes behind them
-        HIPCK(s, hipEventRecord(s->ev_up, s->st_up));
+        HIPCK(s, hipEventRecord(s->ev_up, s->st_pre));
         HIPCK(s, hipStreamWaitEvent(s->st_compute, s->ev_up, 0));
         HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_up, 0));
         s->up_pending = false;
@@ -1278,7 +1280,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     s->rc_on = cfg->qp < 0 && cfg->vbv_maxrate_kbps > 0;
     write_parameter_sets(s->cfg, s->headers);
     bool ok = StreamCache::get().acquire(s->device, &s->st_compute) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_copy) == hipSuccess &&
-              StreamCache::get().acquire(s->device, &s->st_pre) == hipSuccess && StreamCache::get().acquire(s->device, &s->st_up) == hipSuccess;
+              StreamCache::get().acquire(s->device, &s->st_pre) == hipSuccess;
     for (int i = 0; ok && i < kRing; i++)
         ok = hipEventCreateWithFlags(&s->ev_compute[i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&s->ev_copy[i], hipEventDisableTiming) == hipSuccess;
@@ -1289,7 +1291,6 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
         if (s->ev_pre) (void)hipEventDestroy(s->ev_pre);
         if (s->ev_args) (void)hipEventDestroy(s->ev_args);
         if (s->ev_up) (void)hipEventDestroy(s->ev_up);
-        StreamCache::get().release(s->device, s->st_up);
         StreamCache::get().release(s->device, s->st_compute);
         StreamCache::get().release(s->device, s->st_copy);
         StreamCache::get().release(s->device, s->st_pre);
@@ -1352,14 +1353,14 @@ static int ingest(mihevc_session *s, const void *y, const void *u, const void *v
         int pw = i ? s->w / 2 : s->w, ph = i ? s->h / 2 : s->h;               // coded plane size
         int sw = i ? s->cfg.width / 2 : s->cfg.width, sh = i ? s->cfg.height / 2 : s->cfg.height, pitch = i ? pitch_c : pitch_y;
         if (pitch < sw) return MIHEVC_EINVAL;
-        HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st_up));
+        HIPCK(s, hipMemcpy2DAsync(src.p[i], src.stride[i] * es, in[i], pitch * es, sw * es, sh, device_src ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s->st_pre));
         // replicate the last column/row into the coded-size margin (the conformance window crops it again)
         if (pw > sw || ph > sh) {
-            if (s->is16) HIPCK(s, launch_extend_margin<uint16_t>(s->st_up, Plane<uint16_t>{(uint16_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
-            else HIPCK(s, launch_extend_margin<uint8_t>(s->st_up, Plane<uint8_t>{(uint8_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
+            if (s->is16) HIPCK(s, launch_extend_margin<uint16_t>(s->st_pre, Plane<uint16_t>{(uint16_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
+            else HIPCK(s, launch_extend_margin<uint8_t>(s->st_pre, Plane<uint8_t>{(uint8_t *)src.p[i], src.stride[i]}, sw, sh, pw, ph));
         }
     }
-    if (!device_src && !async) HIPCK(s, hipStreamSynchronize(s->st_up));     // caller's buffers may be reused on return
+    if (!device_src && !async) HIPCK(s, hipStreamSynchronize(s->st_pre));     // caller's buffers may be reused on return
     else s->up_pending = true;
     if (s->frames_in == 0) s->first_pts = pts; else if (s->frames_in == 1) s->pts_step = std::max<int64_t>(1, pts - s->first_pts);
     s->pending.push_back(src);
@@ -1386,7 +1387,7 @@ int mihevc_sync_uploads(mihevc_session *s)
     if (!s) return MIHEVC_EINVAL;
     if (s->failed) return MIHEVC_EDEVICE;
     if (hipSetDevice(s->device) != hipSuccess) return MIHEVC_EDEVICE;
-    HIPCK(s, hipStreamSynchronize(s->st_up));
+    HIPCK(s, hipStreamSynchronize(s->st_pre));
     s->up_pending = false;
     return MIHEVC_OK;
 }
@@ -1497,7 +1498,6 @@ void mihevc_close(mihevc_session *s)
     if (s->st_compute) (void)hipStreamSynchronize(s->st_compute);
     if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
     if (s->st_pre) (void)hipStreamSynchronize(s->st_pre);
-    if (s->st_up) (void)hipStreamSynchronize(s->st_up);
     BufferCache &bc = BufferCache::get();
     SymLayout sl(s->w, s->h);
     auto free3 = [&](void *b[3], int padded) { for (int i = 0; i < 3; i++) bc.release(s->device, s->plane_bytes[padded][i], false, b[i]); };
@@ -1530,7 +1530,6 @@ void mihevc_close(mihevc_session *s)
     StreamCache::get().release(s->device, s->st_compute);       // both idle: synchronised above
     StreamCache::get().release(s->device, s->st_copy);
     StreamCache::get().release(s->device, s->st_pre);
-    StreamCache::get().release(s->device, s->st_up);
     delete s;
 }
 
