@@ -113,7 +113,7 @@ int mihevc_encode_picture_host(const mihevc_config *cfg, int slice_type, int poc
 {
     if (!config_ok(cfg) || !cu || !coef_y || !coef_u || !coef_v || !buf) return MIHEVC_EINVAL;
     if (slice_type != 1 && slice_type != 2 && !(slice_type == 0 && cfg->bframes > 0)) return MIHEVC_EINVAL;
-    PictureSyms p{slice_type, poc, qp, cu, {coef_y, coef_u, coef_v}, cfg->sao ? sao : nullptr};
+    PictureSyms p{slice_type, poc, qp, cu, {coef_y, coef_u, coef_v}, cfg->sao ? sao : nullptr, 0};
     std::vector<uint8_t> v;
     encode_picture(*cfg, p, v);
     return copy_out(v, buf, cap);

@@ -91,8 +91,8 @@ void write_vps(const mihevc_config &c, std::vector<uint8_t> &out)
     w.put(0xffff, 16);
     profile_tier_level(w, c);
     w.put1(1);            // vps_sub_layer_ordering_info_present_flag
-    w.ue(c.bframes > 0 ? 2 : 1);   // vps_max_dec_pic_buffering_minus1: current + one reference (+ the second anchor a B picture predicts from)
-    w.ue(c.bframes > 0 ? 1 : 0);   // vps_max_num_reorder_pics: an anchor precedes the B picture in front of it in decoding order
+    w.ue(c.bframes != 0 ? 2 : 1);   // vps_max_dec_pic_buffering_minus1: current + one reference (+ the second anchor a B picture predicts from)
+    w.ue(c.bframes != 0 ? 1 : 0);   // vps_max_num_reorder_pics: an anchor precedes the B picture in front of it in decoding order
     w.ue(0);              // vps_max_latency_increase_plus1
     w.put(0, 6);          // vps_max_layer_id
     w.ue(0);              // vps_num_layer_sets_minus1
@@ -130,8 +130,8 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
     w.ue((uint32_t)c.bit_depth - 8);
     w.ue(4);              // log2_max_pic_order_cnt_lsb_minus4 -> 8 bits (keyint <= 240)
     w.put1(1);            // sps_sub_layer_ordering_info_present_flag
-    w.ue(c.bframes > 0 ? 2 : 1);   // sps_max_dec_pic_buffering_minus1
-    w.ue(c.bframes > 0 ? 1 : 0);   // sps_max_num_reorder_pics
+    w.ue(c.bframes != 0 ? 2 : 1);   // sps_max_dec_pic_buffering_minus1
+    w.ue(c.bframes != 0 ? 1 : 0);   // sps_max_num_reorder_pics
     w.ue(0);                       // sps_max_latency_increase_plus1
     w.ue(0);              // log2_min_luma_coding_block_size_minus3 -> 8
     w.ue(kCtuLog2 - 3);   // log2_diff_max_min_luma_coding_block_size -> CTB 32
@@ -143,7 +143,7 @@ void write_sps(const mihevc_config &c, std::vector<uint8_t> &out)
     w.put1(0);            // amp_enabled_flag
     w.put1(c.sao != 0);   // sample_adaptive_offset_enabled_flag
     w.put1(0);            // pcm_enabled_flag
-    if (c.bframes > 0) {
+    if (c.bframes != 0) {          // (bframes = -1: B pictures where the session's probe finds them worth it: the stream has to announce them)
         // three reference picture sets (7.3.7): 0 = {-1} (an anchor right behind its predecessor: the last picture of an even GOP), 1 = {-2} (an anchor
         // two pictures on), 2 = {-1, +1} (the B picture between two anchors)
         w.ue(3);          // num_short_term_ref_pic_sets
@@ -1199,7 +1199,8 @@ void assemble_picture(const mihevc_config &cfg, const PictureSyms &pic, const st
         w.put1(1);                   // short_term_ref_pic_set_sps_flag
         // short_term_ref_pic_set_idx, Ceil(Log2(num_short_term_ref_pic_sets)) bits: none with one set; with B pictures (three sets) the set follows from the
         // picture's place in its GOP: B pictures sit at odd positions between two anchors, an anchor at an odd position follows its predecessor directly
-        if (cfg.bframes > 0) w.put(pic.slice_type == 0 ? 2u : (pic.poc & 1) ? 0u : 1u, 2);
+        // (PictureSyms::ref_dist says it outright when a session mixes chunks with and without B pictures: bframes = -1)
+        if (cfg.bframes != 0) w.put(pic.slice_type == 0 ? 2u : pic.ref_dist ? (pic.ref_dist == 1 ? 0u : 1u) : (pic.poc & 1) ? 0u : 1u, 2);
     }
     if (cfg.sao != 0) {
         w.put1(pic.sao != nullptr);  // slice_sao_luma_flag

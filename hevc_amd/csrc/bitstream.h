@@ -96,6 +96,8 @@ struct PictureSyms {
     const mihevc_cu_rec *cu;      // (h/8) x (w/8)
     const int16_t *coef[3];       // TU-local raster at picture coordinates; strides w, w/2, w/2
     const mihevc_sao_ctu *sao;    // per CTU, or nullptr when SAO is off for the picture
+    int ref_dist = 0;             // P pictures of a stream that announces B pictures (cfg.bframes != 0): pictures between this one and its reference + 1 (1 or 2);
+                                  // 0: derive it from the place in the GOP (the fixed I0 P2 b1 P4 b3 ... layout)
 };
 
 // CABAC-code the picture into one slice-segment NAL appended to out; returns the number of bins coded (stats).

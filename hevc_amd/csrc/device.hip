@@ -685,7 +685,7 @@ int stage_inter(const void *sy, const void *su, const void *sv, const void *fy, 
         const size_t ln = (size_t)(w >> 2) * (h >> 2);
         CK(dls.alloc(ln)); CK(dlr.alloc(ln)); CK(dpre.alloc(sizeof(PreArgs<T>)));
         PreArgs<T> pa2;
-        pa2.src = a.src[0]; pa2.ref = a.ref[0]; pa2.lsrc = dls.as<uint8_t>(); pa2.lref = dlr.as<uint8_t>(); pa2.w = w; pa2.h = h; pa2.bit_depth = a.prm.bit_depth; pa2.centers = dcen.as<int16_t>();
+        pa2.src = a.src[0]; pa2.ref = a.ref[0]; pa2.lsrc = dls.as<uint8_t>(); pa2.lref = dlr.as<uint8_t>(); pa2.w = w; pa2.h = h; pa2.bit_depth = a.prm.bit_depth; pa2.centers = dcen.as<int16_t>(); pa2.cost = nullptr;
         CK(hipMemcpy(dpre.p, &pa2, sizeof pa2, hipMemcpyHostToDevice));
         CK(launch_pre_search<T>(0, dpre.as<PreArgs<T>>(), w, h, n_ctu, 1, true));
         a.centers = dcen.as<int16_t>();

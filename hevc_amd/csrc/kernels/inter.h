@@ -57,6 +57,7 @@ template <typename T> struct PreArgs {
     uint8_t *lsrc, *lref;        // (w/4) x (h/4) each, row stride w/4
     int w, h, bit_depth;         // coded size
     int16_t *centers;            // out: 2 per CTU, integer luma samples
+    unsigned *cost;              // out, optional: per CTU the smallest SAD of its 8x8 low-resolution block over the window (the B-picture probe sums them)
 };
 template <typename T> DEV void lowres_sample(const PreArgs<T> &a, int i)
 {
@@ -166,6 +167,7 @@ template <typename T, class Ex> DEV void pre_search_program(Ex &ex, PreShared &s
         if (2 * sad_best >= s.sad0) p = R * span + R;
         a.centers[2 * ctu] = (int16_t)(4 * (p % span - R));
         a.centers[2 * ctu + 1] = (int16_t)(4 * (p / span - R));
+        if (a.cost) a.cost[ctu] = sad_best;
     });
 }
 

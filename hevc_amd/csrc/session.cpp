@@ -232,6 +232,7 @@ struct mihevc_session {
     double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
     bool rho_measured = false;                // the session's first chunk measures rho with a trial analysis of the GOPs' first P picture
     double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
+    void *d_probe = nullptr; size_t probe_cap = 0;      // cfg.bframes = -1: the probe's low-resolution pictures, centres and costs
     double beta_bp = 0.45;                    // cfg.bframes: learned (B bits at QP + 2) / (P bits at QP): what a B picture takes of the GOP budget beside a P picture
     int64_t pts_step = 1, first_pts = 0;      // pts distance of the first two frames: with B pictures dts = (pts of the frame at the packet's place in decoding order) - pts_step
     int idr_qp_hint = -1;                     // mean IDR QP the last chunk settled on: where the next chunk's IDR analysis starts
@@ -296,11 +297,11 @@ int ensure_lanes(mihevc_session *s, int n)
     while ((int)s->lane.size() < n) {
         mihevc_session::Lane L;
         memset(&L, 0, sizeof L);
-        for (int k = 0; k < (s->cfg.bframes > 0 ? 3 : 2); k++)
+        for (int k = 0; k < (s->cfg.bframes != 0 ? 3 : 2); k++)
             if (int e = alloc_planes(s, L.rec_base[k], L.rec_p[k], L.rec_stride, 1)) return e;
         if (int e = alloc_planes(s, L.work_base, L.work_p, L.work_stride, 2)) return e;
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me));
-        if (s->cfg.bframes > 0) HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me1));
+        if (s->cfg.bframes != 0) HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, (void **)&L.me1));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, (void **)&L.plan));
         for (int k = 0; k < s->ring; k++) {
@@ -347,7 +348,7 @@ struct PictureJob {
     mihevc_session *s;
     int slot, lane_i, slice_type, poc, qp, prev_gop_len, parts, n_tiles, dec_pos;      // poc: place in the GOP in display order, dec_pos: in decoding order
     int64_t index, pts, dts, dec_index;      // index: display order (frame records, reconstructions); dec_index: decoding order (packets)
-    bool first_of_stream;
+    bool first_of_stream, reorder;      // reorder: the stream announces B pictures (dts one frame early, output delay in the picture timing SEI)
     PictureSyms pic;
     std::vector<std::vector<uint8_t>> sub;
     std::atomic<int> left;
@@ -382,7 +383,7 @@ void publish_picture(PictureJob *j)
         // clock ticks since the previous buffering period: position in the GOP, or the previous GOP's length at an IDR
         // (cfg.bframes: removal happens in decoding order; a picture is shown one tick after the picture at its display place was removed)
         write_sei_pic_timing(s->cfg, (uint32_t)(j->dec_pos > 0 ? j->dec_pos - 1 : (j->dec_index > 0 ? j->prev_gop_len - 1 : 0)), pk.data,
-                             s->cfg.bframes > 0 ? (uint32_t)(j->poc + 1 - j->dec_pos) : 0u);
+                             j->reorder ? (uint32_t)(j->poc + 1 - j->dec_pos) : 0u);
     }
     assemble_picture(s->cfg, j->pic, j->sub, pk.data, false);
     const unsigned long long *sse = (const unsigned long long *)(b + sl.sse);
@@ -480,6 +481,59 @@ static int group_sum(mihevc_session *s, std::vector<double> &v)
 {
     if (!s->group) return 0;
     if (!s->group->allreduce(v)) { s->failed = true; s->err = "another slice of the picture failed"; return MIHEVC_EDEVICE; }
+    return 0;
+}
+
+// cfg.bframes = -1: are B pictures worth it for this chunk?  With a B picture between every two anchors an anchor predicts from TWO pictures back; that pays when
+// motion stays trackable over two pictures (translation, static content) and costs when it does not (zoom, fades, occlusion: tools/rd_curve.py, profiles/r03).
+// The probe asks the pre-search: for up to 8 pictures spread over the chunk, the smallest low-resolution SAD of every CTU against the SOURCE one place back (c1)
+// and two places back (c2), summed.  B pictures when c2 <= 1.3 c1 + a floor of 6 grey levels per low-resolution sample block (static pictures: both near zero).
+// One launch pair + one small read-back per chunk (~0.3 ms at 1080p).  stats.reserved[0] / [1] keep the last c1 / c2 (in 1/1000 per CTU) for tests and tools.
+template <typename T> static int probe_bframes(mihevc_session *s, int n, bool &use_b)
+{
+    use_b = false;
+    if (n < 3) return 0;
+    const int K = std::min(8, (n - 2 + 7) / 8 + 1);
+    std::vector<int> at;
+    for (int k = 0; k < K; k++) { const int p = 2 + (int)((long long)(n - 3) * k / std::max(1, K - 1)); if (at.empty() || at.back() != p) at.push_back(p); }
+    const int ne = 4 * (int)at.size();
+    const size_t low_pic = (size_t)(s->w >> 2) * (s->h >> 2), o_low = ((size_t)ne * sizeof(PreArgs<T>) + 255) & ~(size_t)255, o_cen = (o_low + (size_t)ne * low_pic + 255) & ~(size_t)255;
+    const size_t o_cost = (o_cen + (size_t)ne * s->n_ctu * 2 * sizeof(int16_t) + 255) & ~(size_t)255, need = o_cost + (size_t)ne * s->n_ctu * sizeof(unsigned);
+    if (need > s->probe_cap) {
+        BufferCache &bc = BufferCache::get();
+        bc.release(s->device, s->probe_cap, false, s->d_probe);
+        s->d_probe = nullptr; s->probe_cap = 0;
+        const size_t cap = (need + 0xffff) & ~(size_t)0xffff;
+        HIPCK(s, bc.alloc(s->device, cap, false, &s->d_probe));
+        s->probe_cap = cap;
+    }
+    uint8_t *base = (uint8_t *)s->d_probe;
+    std::vector<PreArgs<T>> args((size_t)ne);
+    for (size_t k = 0; k < at.size(); k++)
+        for (int e = 0; e < 4; e++) {          // 0: picture p against p - 1 (cost c1); 1, 2: the low-resolution pictures of p - 1 and p - 2; 3: p against p - 2 (cost c2)
+            const int i = (int)k * 4 + e, pic = at[k] - (e == 1 ? 1 : e == 2 ? 2 : 0);
+            const mihevc_session::Src &src = s->pending[(size_t)pic];
+            PreArgs<T> &a = args[(size_t)i];
+            a.src = a.ref = mkc<T>(src.p[0], src.stride[0]);
+            a.lsrc = base + o_low + (size_t)i * low_pic;
+            a.lref = base + o_low + (size_t)((int)k * 4 + (e == 0 ? 1 : e == 3 ? 2 : e)) * low_pic;
+            a.w = s->w; a.h = s->h; a.bit_depth = s->cfg.bit_depth;
+            a.centers = (int16_t *)(base + o_cen) + (size_t)i * s->n_ctu * 2;
+            a.cost = (unsigned *)(base + o_cost) + (size_t)i * s->n_ctu;
+        }
+    HIPCK(s, hipMemcpyAsync(base, args.data(), (size_t)ne * sizeof(PreArgs<T>), hipMemcpyHostToDevice, s->st_compute));
+    HIPCK(s, launch_pre_search_chunk<T>(s->st_compute, (const PreArgs<T> *)base, s->w, s->h, s->n_ctu, ne));
+    std::vector<unsigned> cost((size_t)ne * s->n_ctu);
+    HIPCK(s, hipMemcpyAsync(cost.data(), base + o_cost, cost.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->st_compute));
+    HIPCK(s, hipStreamSynchronize(s->st_compute));
+    unsigned long long c1 = 0, c2 = 0;
+    for (size_t k = 0; k < at.size(); k++)
+        for (int c = 0; c < s->n_ctu; c++) { c1 += cost[(k * 4 + 0) * s->n_ctu + c]; c2 += cost[(k * 4 + 3) * s->n_ctu + c]; }
+    const unsigned long long floor_ = 6ull * 64ull * (unsigned long long)s->n_ctu * at.size();
+    use_b = 10 * c2 <= 13 * c1 + 10 * floor_;
+    s->stats.reserved[0] = (int32_t)std::min<unsigned long long>(0x7fffffff, c1 * 1000 / ((unsigned long long)s->n_ctu * at.size()));
+    s->stats.reserved[1] = (int32_t)std::min<unsigned long long>(0x7fffffff, c2 * 1000 / ((unsigned long long)s->n_ctu * at.size()));
+    s->stats.reserved[2] = use_b;
     return 0;
 }
 
@@ -605,7 +659,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
     const size_t flat_off = (size_t)(steps + 1) * lay.total;  // + one block for the rho trial (below)
-    const bool bf = s->cfg.bframes > 0;
+    bool bf_decided = s->cfg.bframes > 0;
+    if (s->cfg.bframes < 0) { if (int e = probe_bframes<T>(s, n, bf_decided)) return e; }
+    const bool bf = bf_decided;
     const int n_pre = bf ? 2 * n : n;       // pre-search blocks: one per picture of the chunk (stream order); with B pictures a second one per picture for list 1
     const size_t need = flat_off + (size_t)n_pre * sizeof(PreArgs<T>);
     if (need > s->args_cap) {
@@ -748,7 +804,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 PreArgs<T> &P4 = ((PreArgs<T> *)(ha + flat_off))[idx];
                 P4.src = A.inter.src[0]; P4.ref = A.inter.src[0];
                 P4.lsrc = low + idx * low_pic; P4.lref = low + (t > 0 ? ridx : idx) * low_pic;      // against the SOURCE of the picture it will predict from; an IDR picture's centres are never read
-                P4.w = s->w; P4.h = s->h; P4.bit_depth = s->cfg.bit_depth; P4.centers = cen + idx * (size_t)s->n_ctu * 2;
+                P4.w = s->w; P4.h = s->h; P4.bit_depth = s->cfg.bit_depth; P4.centers = cen + idx * (size_t)s->n_ctu * 2; P4.cost = nullptr;
                 if (t > 0) A.inter.centers = P4.centers;
                 if (bf) {                  // the second block: a B picture against the source of the anchor AFTER it (other pictures: a copy of the first, never read)
                     PreArgs<T> &P5 = ((PreArgs<T> *)(ha + flat_off))[(size_t)n + idx];
@@ -1137,7 +1193,9 @@ template <typename T> int encode_chunk(mihevc_session *s)
             // packets leave in DECODING order: place t of the GOP; dts = the pts of the frame at that place in display order, one frame earlier when
             // B pictures reorder (an anchor is decoded one picture before the B picture in front of it is shown)
             j->dec_index = first_index + gstart[(size_t)g] + t;
-            j->dts = s->pending[gstart[(size_t)g] + t].pts - (bf ? s->pts_step : 0);
+            j->reorder = s->cfg.bframes != 0;
+            j->dts = s->pending[gstart[(size_t)g] + t].pts - (j->reorder ? s->pts_step : 0);
+            j->pic.ref_dist = type_of_step(bf, t) == 1 ? pos - std::max(0, pos_of_step(bf, bf ? std::max(0, t - 2) * (t > 1) : t - 1, glen[(size_t)g])) : 0;
             j->dec_pos = t;
             j->prev_gop_len = prev_len[(size_t)g];
             j->slice_type = type_of_step(bf, t); j->poc = pos; j->qp = qp_step[g]; j->first_of_stream = j->dec_index == 0;
@@ -1242,7 +1300,7 @@ int mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out)
     if (cfg->width < 16 || cfg->height < 16 || (cfg->width & 1) || (cfg->height & 1) || cfg->width > 8192 || cfg->height > 4352) return MIHEVC_EINVAL;
     if (cfg->bit_depth != 8 && cfg->bit_depth != 10) return MIHEVC_EINVAL;
     if (cfg->fps_num <= 0 || cfg->fps_den <= 0 || cfg->keyint < 1 || cfg->keyint > 240) return MIHEVC_EINVAL;
-    if (cfg->bframes < 0 || cfg->bframes > 1 || (cfg->bframes && cfg->slice_count > 1)) return MIHEVC_EINVAL;      // B pictures: whole pictures only (for now)
+    if (cfg->bframes < -1 || cfg->bframes > 1 || (cfg->bframes && cfg->slice_count > 1)) return MIHEVC_EINVAL;      // B pictures: whole pictures only (for now)
     if (cfg->slice_count > 1) {        // one slice of a picture: a band of whole CTU rows (the last band takes the picture's remainder)
         if (cfg->slice_count > 16 || cfg->slice_index < 0 || cfg->slice_index >= cfg->slice_count || cfg->pic_height < cfg->height) return MIHEVC_EINVAL;
         int rows = 0;
@@ -1522,6 +1580,7 @@ void mihevc_close(mihevc_session *s)
     if (s->ev_up) (void)hipEventDestroy(s->ev_up);
     bc.release(s->device, s->low_cap, false, s->d_low);
     bc.release(s->device, s->jobs_cap, false, s->d_jobs); bc.release(s->device, s->jobs_cap, true, s->h_jobs);
+    bc.release(s->device, s->probe_cap, false, s->d_probe);
     for (int k = 0; k < 2; k++) {
         bc.release(s->device, s->x1_bytes, false, s->x1_export[k]);
         if (s->ev_x1[k]) (void)hipEventDestroy(s->ev_x1[k]);

@@ -102,10 +102,14 @@ typedef struct mihevc_config {
                                        * under `-threads 0`, core/transcoder.py:410-411).  -1 (default): one tile per 1920x1080 of picture (4320p 4x4, 2160p 2x2, up to
                                        * 1080p-class none: tiles that large cost ~0.2 % bits); 0: off; 1: as -1 but at least 2x2 when the level allows.  Motion
                                        * compensation, deblocking and SAO cross tile boundaries; merge / AMVP candidates and CABAC contexts do not */
-    int32_t bframes;                  /* 0 (default) / 1: every second picture of a closed GOP is a B picture between two anchors (x265 bframes; the reference's
+    int32_t bframes;                  /* 0 (default) / 1 / -1.  1: every second picture of a closed GOP is a B picture between two anchors (x265 bframes; the reference's
                                        * preset=slow runs 4 with b-adapt, core/transcoder.py:399): coding order I0 P2 b1 P4 b3 ..., a B picture predicts from the anchor
                                        * before it (list 0), the one after it (list 1) or both (8.5.3.3.4.2), is never a reference itself (TRAIL_N) and takes QP + 2.
-                                       * Packets come out in DECODING order with pts < dts differences (mihevc_receive_packet), the MP4 writer adds the ctts box */
+                                       * Packets come out in DECODING order with dts <= pts (mihevc_receive_packet), the MP4 writer adds the ctts box.
+                                       * -1: decided per chunk (x265 b-adapt in spirit): a probe on the 1/4-size SOURCE pictures compares how well a picture is
+                                       * matched by the picture one place and two places before it; B pictures where two places back is nearly as good (static and
+                                       * translating content), none where it is not (zoom, fades: there anchors two pictures apart cost more than B pictures save).
+                                       * mihevc_stats.reserved[0..2]: the last probe's two costs (1/1000 per CTU) and its decision */
     int32_t slice_halo;               /* slice_count > 1 only.  1: the sessions of one picture's slices EXCHANGE rows (they find each other through slice_group and must
                                        * live in one process): the PAD rows of the final reconstruction either side of every seam, so motion vectors cross seams as in a
                                        * whole picture, and 8 rows of the pre-deblock reconstruction + one row of CU records, so deblocking and SAO run across the seams

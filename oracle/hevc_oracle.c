@@ -667,7 +667,9 @@ void orc_lowres(const pix *src, int stride, int w, int h, int bit_depth, pix *ds
             dst[y * lw + x] = (pix)(s >> (4 + sh));
         }
 }
-void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers)
+void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers) { orc_pre_search_cost(lsrc, lref, lw, lh, centers, NULL); }
+/* the same, also returning per CTU the smallest SAD of its low-resolution block over the window (the session's B-picture probe sums them) */
+void orc_pre_search_cost(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers, uint32_t *costs)
 {
     int wc = (lw + 7) >> 3, hc = (lh + 7) >> 3, R = ORC_PRE_RANGE, span = 2 * R + 1;
     for (int cy = 0; cy < hc; cy++)
@@ -694,6 +696,7 @@ void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *c
             if (2 * sad_best >= sad0) p = R * span + R;
             centers[2 * (cy * wc + cx)] = (int16_t)(4 * (p % span - R));
             centers[2 * (cy * wc + cx) + 1] = (int16_t)(4 * (p / span - R));
+            if (costs) costs[cy * wc + cx] = sad_best;
         }
 }
 

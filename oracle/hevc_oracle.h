@@ -138,6 +138,7 @@ void orc_analyze_b_frame(const pix *src_y, const pix *src_u, const pix *src_v, i
 void orc_lowres(const pix *src, int stride, int w, int h, int bit_depth, pix *dst /* (w/4) x (h/4), stride w/4 */);
 /* per CTU search centre (integer luma samples, 2 per CTU) from a +-14 full search of its 8x8 low-resolution block */
 void orc_pre_search(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers);
+void orc_pre_search_cost(const pix *lsrc, const pix *lref, int lw, int lh, int16_t *centers, uint32_t *costs);
 /* K2+K3: intra (I) frame */
 void orc_analyze_intra_frame(const pix *src_y, const pix *src_u, const pix *src_v, int src_stride, int src_cstride,
                              int w, int h, const orc_params *prm,

@@ -271,6 +271,20 @@ def search_centres(src: Frame, prev: Frame, bit_depth=8) -> np.ndarray:
     return cen
 
 
+def search_cost(src: Frame, other: Frame, bit_depth=8) -> int:
+    """Sum over the CTUs of the smallest SAD of their 8x8 low-resolution block of `src` over the +-14 window in `other` (orc_pre_search_cost): what the
+    session's B-picture probe compares between the picture one place and two places before (mihevc_config.bframes = -1)."""
+    h, w = src.shape
+    lw, lh = w >> 2, h >> 2
+    ls, lr = np.empty((lh, lw), np.uint16), np.empty((lh, lw), np.uint16)
+    lib().orc_lowres(_p(src.y), w, w, h, bit_depth, _p(ls))
+    lib().orc_lowres(_p(other.y), w, w, h, bit_depth, _p(lr))
+    n_ctu = ((w + CTU - 1) // CTU) * ((h + CTU - 1) // CTU)
+    cen, cost = np.zeros((n_ctu, 2), np.int16), np.zeros(n_ctu, np.uint32)
+    lib().orc_pre_search_cost(_p(ls), _p(lr), lw, lh, _p(cen), _p(cost))
+    return int(cost.sum())
+
+
 def deblock(rec: Frame, cu: np.ndarray, bit_depth=8) -> Frame:
     out = rec.copy()
     h, w = out.shape

@@ -154,7 +154,7 @@ static int inter_frame(const T *sy, const T *su, const T *sv, const T *ry, const
     if (a.prm.pre_search && !centers) {
         PreArgs<T> pa;
         ls.assign((size_t)(w / 4) * (h / 4), 0); lr = ls; cen.assign((size_t)n_ctu * 2, 0);
-        pa.src = a.src[0]; pa.ref = a.ref[0]; pa.lsrc = ls.data(); pa.lref = lr.data(); pa.w = w; pa.h = h; pa.bit_depth = a.prm.bit_depth; pa.centers = cen.data();
+        pa.src = a.src[0]; pa.ref = a.ref[0]; pa.lsrc = ls.data(); pa.lref = lr.data(); pa.w = w; pa.h = h; pa.bit_depth = a.prm.bit_depth; pa.centers = cen.data(); pa.cost = nullptr;
         for (int i = 0; i < 2 * (w / 4) * (h / 4); i++) lowres_sample<T>(pa, i);
         for (int c = 0; c < n_ctu; c++) {
             PreShared ps;

@@ -139,3 +139,39 @@ def test_b_pictures_through_convert_video_and_the_muxer(lib, tmp_path, monkeypat
         cnt, off = int.from_bytes(c[8 + 8 * k:12 + 8 * k], "big"), int.from_bytes(c[12 + 8 * k:16 + 8 * k], "big")
         offs += [off] * cnt
     assert len(offs) == n and offs[0] == 1 and set(offs) == {0, 1, 2}      # I: one frame, anchors: two, B pictures: none (fps_den = 1)
+
+
+def probe_positions(n):
+    """pictures the session's probe looks at (hevc_amd/csrc/session.cpp probe_bframes)"""
+    K = min(8, (n - 2 + 7) // 8 + 1)
+    at = []
+    for k in range(K):
+        p = 2 + (n - 3) * k // max(1, K - 1)
+        if not at or at[-1] != p:
+            at.append(p)
+    return at
+
+
+@pytest.mark.parametrize("pattern,w,h,n", [("bars", 640, 352, 24), ("motion", 640, 352, 24), ("stress", 640, 352, 40)])
+def test_adaptive_b_decision_follows_the_probe(lib, pattern, w, h, n):
+    """cfg.bframes = -1: the session decides per chunk from the pre-search costs of the SOURCE pictures one and two places back (orc_pre_search_cost is the
+    same arithmetic): the decision it reports equals the rule applied to the oracle's sums, the picture types follow it, and the stream decodes either way."""
+    from hevc_amd import _lib
+    from hevc_amd.yuvio import SyntheticClip
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.me_range, cfg.gops_in_flight, cfg.bframes, cfg.scenecut, cfg.qp, cfg.level_idc = w, h, 12, 2, 12, 4, -1, 0, 30, 93
+    clip = SyntheticClip(pattern, 1, w, h, n)
+    frames = [O.Frame(*clip.frame(i)) for i in range(n)]
+    pk, infos, recs, st = run_b_session(cfg, frames, 8)
+    at = probe_positions(n)
+    c1 = sum(O.search_cost(frames[p], frames[p - 1]) for p in at)
+    c2 = sum(O.search_cost(frames[p], frames[p - 2]) for p in at)
+    n_ctu = util.n_ctus(w, h)
+    want = 10 * c2 <= 13 * c1 + 10 * 6 * 64 * n_ctu * len(at)
+    assert (st.reserved[0], st.reserved[1]) == (c1 * 1000 // (n_ctu * len(at)), c2 * 1000 // (n_ctu * len(at))), (st.reserved[0], st.reserved[1], c1, c2)
+    assert bool(st.reserved[2]) == want
+    assert any(t == 0 for _, t, _ in infos) == want
+    dec, info = O.decode(b"".join(p[0] for p in pk))
+    assert len(dec) == n and all(d.same(r) for d, r in zip(dec, recs))
+    replay(lib, cfg, frames, infos, recs)
+    print(pattern, "probe", st.reserved[0] / 1000, st.reserved[1] / 1000, "B" if want else "no B")
