@@ -24,7 +24,7 @@ class Config(C.Structure):
         [("md_primaries", (C.c_uint16 * 2) * 3), ("md_white", C.c_uint16 * 2), ("md_max_lum", C.c_uint32), ("md_min_lum", C.c_uint32),
          ("max_cll", C.c_uint16), ("max_fall", C.c_uint16)] +
         [(n, C.c_int32) for n in ("me_range", "gops_in_flight", "host_threads", "sao", "profile_stages", "intra_tiles", "intra_nxn", "intra_in_p", "hrd", "pre_search", "rdo_zero", "chroma_modes", "pic_height", "slice_count", "slice_index")] +
-        [("slice_ctu_rows", C.c_int32 * 16), ("rate_share_q16", C.c_int32), ("scenecut", C.c_int32), ("gop_balance", C.c_int32), ("rdo_cg", C.c_int32), ("p_tiles", C.c_int32), ("bframes", C.c_int32), ("slice_halo", C.c_int32), ("slice_group", C.c_int32)])
+        [("slice_ctu_rows", C.c_int32 * 16), ("rate_share_q16", C.c_int32), ("scenecut", C.c_int32), ("gop_balance", C.c_int32), ("rdo_cg", C.c_int32), ("p_tiles", C.c_int32), ("bframes", C.c_int32), ("b_qp_offset", C.c_int32), ("slice_halo", C.c_int32), ("slice_group", C.c_int32)])
 
 
 class Stats(C.Structure):

@@ -41,7 +41,7 @@ void mihevc_config_default(mihevc_config *c)
     c->md_white[0] = 15635; c->md_white[1] = 16450; c->md_max_lum = 10000000; c->md_min_lum = 50;
     c->max_cll = 1000; c->max_fall = 400;
     c->me_range = 0; c->gops_in_flight = 0; c->host_threads = 0; c->sao = 1; c->intra_tiles = 1; c->intra_nxn = 0; c->intra_in_p = 0; c->pre_search = 1; c->rdo_zero = 1; c->chroma_modes = 1; c->scenecut = 1; c->gop_balance = 1; c->rdo_cg = 0;
-    c->p_tiles = -1;
+    c->p_tiles = -1; c->b_qp_offset = -1;
 }
 
 // lambda_mode = 0.57 * 2^((qp-12)/3) (the usual HM/x265 relation); SAD/SATD-domain lambda is its square root.

@@ -541,7 +541,6 @@ template <typename T> static int probe_bframes(mihevc_session *s, int n, bool &u
 // last two anchors; the GOP's last picture is always an anchor.  Display position / slice type (2 I, 1 P, 0 B) of step t; without B pictures step = position.
 static inline int pos_of_step(bool bf, int t, int len) { return !bf || t == 0 ? t : (t & 1) ? std::min(t + 1, len - 1) : t - 1; }
 static inline int type_of_step(bool bf, int t) { return t == 0 ? 2 : (bf && !(t & 1)) ? 0 : 1; }
-constexpr int kQpB = 2;      // a B picture takes the QP of the anchors around it + 2 (x265 pbratio 1.3): nothing predicts from it
 
 template <typename T> int encode_chunk(mihevc_session *s)
 {
@@ -659,6 +658,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     // ---- build every step's argument blocks, upload once ----
     const StepLayout<T> lay(gops);
     const size_t flat_off = (size_t)(steps + 1) * lay.total;  // + one block for the rho trial (below)
+    const int kQpB = s->cfg.b_qp_offset >= 0 ? std::min(8, s->cfg.b_qp_offset) : 2;      // a B picture takes the QP of the anchors around it + 2 (x265 pbratio 1.3): nothing predicts from it
     bool bf_decided = s->cfg.bframes > 0;
     if (s->cfg.bframes < 0) { if (int e = probe_bframes<T>(s, n, bf_decided)) return e; }
     const bool bf = bf_decided;

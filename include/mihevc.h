@@ -110,6 +110,7 @@ typedef struct mihevc_config {
                                        * matched by the picture one place and two places before it; B pictures where two places back is nearly as good (static and
                                        * translating content), none where it is not (zoom, fades: there anchors two pictures apart cost more than B pictures save).
                                        * mihevc_stats.reserved[0..2]: the last probe's two costs (1/1000 per CTU) and its decision */
+    int32_t b_qp_offset;              /* QP of a B picture above the anchors around it; -1 (default): 2 (x265 pbratio 1.3) */
     int32_t slice_halo;               /* slice_count > 1 only.  1: the sessions of one picture's slices EXCHANGE rows (they find each other through slice_group and must
                                        * live in one process): the PAD rows of the final reconstruction either side of every seam, so motion vectors cross seams as in a
                                        * whole picture, and 8 rows of the pre-deblock reconstruction + one row of CU records, so deblocking and SAO run across the seams
