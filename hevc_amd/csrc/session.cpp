@@ -485,54 +485,79 @@ static int group_sum(mihevc_session *s, std::vector<double> &v)
 }
 
 // cfg.bframes = -1: are B pictures worth it for this chunk?  With a B picture between every two anchors an anchor predicts from TWO pictures back; that pays when
-// motion stays trackable over two pictures (translation, static content) and costs when it does not (zoom, fades, occlusion: tools/rd_curve.py, profiles/r03).
-// The probe asks the pre-search: for up to 8 pictures spread over the chunk, the smallest low-resolution SAD of every CTU against the SOURCE one place back (c1)
-// and two places back (c2), summed.  B pictures when c2 <= 1.3 c1 + a floor of 6 grey levels per low-resolution sample block (static pictures: both near zero).
-// One launch pair + one small read-back per chunk (~0.3 ms at 1080p).  stats.reserved[0] / [1] keep the last c1 / c2 (in 1/1000 per CTU) for tests and tools.
+// motion stays trackable over two pictures (translation, static content) and costs when it does not (zoom, fades: tools/rd_curve.py, profiles/r03: +7 % bits on
+// the `stress` clip even with B pictures at the anchors' QP).  The probe asks the integer search itself: for up to 4 pictures spread over the chunk, k_me_search
+// of the SOURCE picture against the source one place back and two places back (copied into lane 0's reference buffers, border padded); c1 / c2 = the 32x32 nodes'
+// best costs (SAD << 4 + lambda * mvd bits) summed over all CTUs.  B pictures when c2 <= kProbeRatio x c1.  A 1/4-size search cannot tell (sub-sample
+// motion dominates its SADs: it rated the translating clip WORSE than the zooming one).  ~0.4 ms per chunk at 1080p.  stats.reserved[0] / [1] keep the last
+// c1 / c2 per CTU, [2] the decision (tests and tools read them).
+constexpr double kProbeRatio = 1.12;
 template <typename T> static int probe_bframes(mihevc_session *s, int n, bool &use_b)
 {
     use_b = false;
     if (n < 3) return 0;
-    const int K = std::min(8, (n - 2 + 7) / 8 + 1);
+    if (int e = ensure_lanes(s, 1)) return e;
+    mihevc_session::Lane &L = s->lane[0];
+    const int K = std::min(4, (n - 2 + 15) / 16 + 1);
     std::vector<int> at;
     for (int k = 0; k < K; k++) { const int p = 2 + (int)((long long)(n - 3) * k / std::max(1, K - 1)); if (at.empty() || at.back() != p) at.push_back(p); }
-    const int ne = 4 * (int)at.size();
-    const size_t low_pic = (size_t)(s->w >> 2) * (s->h >> 2), o_low = ((size_t)ne * sizeof(PreArgs<T>) + 255) & ~(size_t)255, o_cen = (o_low + (size_t)ne * low_pic + 255) & ~(size_t)255;
-    const size_t o_cost = (o_cen + (size_t)ne * s->n_ctu * 2 * sizeof(int16_t) + 255) & ~(size_t)255, need = o_cost + (size_t)ne * s->n_ctu * sizeof(unsigned);
-    if (need > s->probe_cap) {
+    const size_t o_inter = 256, o_total = o_inter + 2 * at.size() * sizeof(InterArgs<T>);
+    if (o_total > s->probe_cap) {
         BufferCache &bc = BufferCache::get();
         bc.release(s->device, s->probe_cap, false, s->d_probe);
         s->d_probe = nullptr; s->probe_cap = 0;
-        const size_t cap = (need + 0xffff) & ~(size_t)0xffff;
+        const size_t cap = (o_total + 0xffff) & ~(size_t)0xffff;
         HIPCK(s, bc.alloc(s->device, cap, false, &s->d_probe));
         s->probe_cap = cap;
     }
     uint8_t *base = (uint8_t *)s->d_probe;
-    std::vector<PreArgs<T>> args((size_t)ne);
+    mihevc_cost_params c;
+    mihevc_cost_params_for_qp(s->qp_p, s->cfg.bit_depth, s->me_range, &c);
+    const CostParams P{c.qp, c.qp_c, c.bit_depth, c.lambda_sad_q4, c.lambda_q4, c.me_range, 1, 1, false, false, false, false, false, false, false, 0};
+    SaoArgs<T> pad[2];
+    memset(pad, 0, sizeof pad);
+    for (int k = 0; k < 2; k++) { for (int i = 0; i < 3; i++) pad[k].out[i] = mk<T>(L.rec_p[k][i], L.rec_stride[i]); pad[k].w = s->w; pad[k].h = s->h; }
+    std::vector<InterArgs<T>> ia(2 * at.size());
     for (size_t k = 0; k < at.size(); k++)
-        for (int e = 0; e < 4; e++) {          // 0: picture p against p - 1 (cost c1); 1, 2: the low-resolution pictures of p - 1 and p - 2; 3: p against p - 2 (cost c2)
-            const int i = (int)k * 4 + e, pic = at[k] - (e == 1 ? 1 : e == 2 ? 2 : 0);
-            const mihevc_session::Src &src = s->pending[(size_t)pic];
-            PreArgs<T> &a = args[(size_t)i];
-            a.src = a.ref = mkc<T>(src.p[0], src.stride[0]);
-            a.lsrc = base + o_low + (size_t)i * low_pic;
-            a.lref = base + o_low + (size_t)((int)k * 4 + (e == 0 ? 1 : e == 3 ? 2 : e)) * low_pic;
-            a.w = s->w; a.h = s->h; a.bit_depth = s->cfg.bit_depth;
-            a.centers = (int16_t *)(base + o_cen) + (size_t)i * s->n_ctu * 2;
-            a.cost = (unsigned *)(base + o_cost) + (size_t)i * s->n_ctu;
+        for (int d = 0; d < 2; d++) {
+            InterArgs<T> &a = ia[2 * k + (size_t)d];
+            memset((void *)&a, 0, sizeof a);
+            const mihevc_session::Src &src = s->pending[(size_t)at[k]];
+            for (int i = 0; i < 3; i++) { a.src[i] = mkc<T>(src.p[i], src.stride[i]); a.ref[i] = mkc<T>(L.rec_p[d][i], L.rec_stride[i]); }
+            a.w = s->w; a.h = s->h; a.ctus_w = s->ctus_w; a.prm = P; a.me = d ? L.me1 : L.me;
         }
-    HIPCK(s, hipMemcpyAsync(base, args.data(), (size_t)ne * sizeof(PreArgs<T>), hipMemcpyHostToDevice, s->st_compute));
-    HIPCK(s, launch_pre_search_chunk<T>(s->st_compute, (const PreArgs<T> *)base, s->w, s->h, s->n_ctu, ne));
-    std::vector<unsigned> cost((size_t)ne * s->n_ctu);
-    HIPCK(s, hipMemcpyAsync(cost.data(), base + o_cost, cost.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s->st_compute));
+    HIPCK(s, hipMemcpyAsync(base, pad, sizeof pad, hipMemcpyHostToDevice, s->st_compute));
+    HIPCK(s, hipMemcpyAsync(base + o_inter, ia.data(), ia.size() * sizeof(InterArgs<T>), hipMemcpyHostToDevice, s->st_compute));
+    std::vector<int32_t> me((size_t)2 * at.size() * s->n_ctu * 63);
+    const size_t es = esize(s), me_bytes = (size_t)s->n_ctu * 63 * sizeof(int32_t);
+    for (size_t k = 0; k < at.size(); k++) {
+        for (int d = 0; d < 2; d++) {          // the luma of the pictures one and two places back -> the reference buffers (the search reads luma only)
+            const mihevc_session::Src &r = s->pending[(size_t)(at[k] - 1 - d)];
+            HIPCK(s, hipMemcpy2DAsync(L.rec_p[d][0], L.rec_stride[0] * es, r.p[0], r.stride[0] * es, s->w * es, s->h, hipMemcpyDeviceToDevice, s->st_compute));
+        }
+        HIPCK(s, launch_pad<T>(s->st_compute, (const SaoArgs<T> *)base, s->w, s->h, 2));
+        for (int d = 0; d < 2; d++) {
+            HIPCK(s, launch_me_search<T>(s->st_compute, (const InterArgs<T> *)(base + o_inter) + 2 * k + (size_t)d, s->n_ctu, 1, s->me_range, 0));
+            HIPCK(s, hipMemcpyAsync(me.data() + (2 * k + (size_t)d) * s->n_ctu * 63, d ? L.me1 : L.me, me_bytes, hipMemcpyDeviceToHost, s->st_compute));
+        }
+    }
     HIPCK(s, hipStreamSynchronize(s->st_compute));
     unsigned long long c1 = 0, c2 = 0;
     for (size_t k = 0; k < at.size(); k++)
-        for (int c = 0; c < s->n_ctu; c++) { c1 += cost[(k * 4 + 0) * s->n_ctu + c]; c2 += cost[(k * 4 + 3) * s->n_ctu + c]; }
-    const unsigned long long floor_ = 6ull * 64ull * (unsigned long long)s->n_ctu * at.size();
-    use_b = 10 * c2 <= 13 * c1 + 10 * floor_;
-    s->stats.reserved[0] = (int32_t)std::min<unsigned long long>(0x7fffffff, c1 * 1000 / ((unsigned long long)s->n_ctu * at.size()));
-    s->stats.reserved[1] = (int32_t)std::min<unsigned long long>(0x7fffffff, c2 * 1000 / ((unsigned long long)s->n_ctu * at.size()));
+        for (int ctu = 0; ctu < s->n_ctu; ctu++) {
+            // node 0 (the 32x32 block); CTUs the picture cuts off have no such node: their four 16x16 / sixteen 8x8 nodes stand in
+            for (int d = 0; d < 2; d++) {
+                const int32_t *m = me.data() + ((2 * k + (size_t)d) * s->n_ctu + (size_t)ctu) * 63;
+                unsigned long long v = 0;
+                if (m[2] >= 0) v = (unsigned long long)m[2];
+                else for (int nd = 1; nd < 21; nd++) { if (nd < 5 ? m[3 * nd + 2] >= 0 : m[3 * (1 + ((nd - 5) >> 2)) + 2] < 0 && m[3 * nd + 2] >= 0) v += (unsigned long long)m[3 * nd + 2]; }
+                (d ? c2 : c1) += v;
+            }
+        }
+    use_b = (double)c2 <= kProbeRatio * (double)c1;
+    const unsigned long long per = (unsigned long long)s->n_ctu * at.size();
+    s->stats.reserved[0] = (int32_t)std::min<unsigned long long>(0x7fffffff, c1 / per);
+    s->stats.reserved[1] = (int32_t)std::min<unsigned long long>(0x7fffffff, c2 / per);
     s->stats.reserved[2] = use_b;
     return 0;
 }
