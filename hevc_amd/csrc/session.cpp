@@ -501,7 +501,7 @@ template <typename T> static int probe_bframes(mihevc_session *s, int n, bool &u
     const int K = std::min(4, (n - 2 + 15) / 16 + 1);
     std::vector<int> at;
     for (int k = 0; k < K; k++) { const int p = 2 + (int)((long long)(n - 3) * k / std::max(1, K - 1)); if (at.empty() || at.back() != p) at.push_back(p); }
-    const size_t o_inter = 256, o_total = o_inter + 2 * at.size() * sizeof(InterArgs<T>);
+    const size_t o_inter = (2 * sizeof(SaoArgs<T>) + 255) & ~(size_t)255, o_total = o_inter + 2 * at.size() * sizeof(InterArgs<T>);
     if (o_total > s->probe_cap) {
         BufferCache &bc = BufferCache::get();
         bc.release(s->device, s->probe_cap, false, s->d_probe);
