@@ -491,7 +491,7 @@ static int group_sum(mihevc_session *s, std::vector<double> &v)
 // best costs (SAD << 4 + lambda * mvd bits) summed over all CTUs.  B pictures when c2 <= kProbeRatio x c1.  A 1/4-size search cannot tell (sub-sample
 // motion dominates its SADs: it rated the translating clip WORSE than the zooming one).  ~0.4 ms per chunk at 1080p.  stats.reserved[0] / [1] keep the last
 // c1 / c2 per CTU, [2] the decision (tests and tools read them).
-constexpr double kProbeRatio = 1.12;
+constexpr double kProbeRatio = 1.4;
 template <typename T> static int probe_bframes(mihevc_session *s, int n, bool &use_b)
 {
     use_b = false;

@@ -43,12 +43,12 @@ def gops_of(infos):
     return [(a, b) for a, b in zip(idr, idr[1:] + [len(infos)])]
 
 
-def replay(lib, cfg, frames, infos, recs):
+def replay(lib, cfg, frames, infos, recs, with_b=True):
     """the oracle pipeline in coding order with the session's per-picture QPs"""
     bd = cfg.bit_depth
     for g0, g1 in gops_of(infos):
         rec, last = {}, None
-        for pos, st in coding_order(g1 - g0):
+        for pos, st in (coding_order(g1 - g0) if with_b else [(p, 1 if p else 2) for p in range(g1 - g0)]):
             i = g0 + pos
             assert infos[i][1] == st, (i, infos[i], st)
             prm, _ = session_params(lib, cfg, infos[i][0], st == 2)
@@ -170,7 +170,7 @@ def probe_cost(src, ref, qp, bd, me_range):
 @pytest.mark.parametrize("pattern,w,h,n", [("bars", 640, 352, 24), ("motion", 640, 352, 24), ("stress", 640, 352, 40), ("motion", 200, 104, 9)])
 def test_adaptive_b_decision_follows_the_probe(lib, pattern, w, h, n):
     """cfg.bframes = -1: the session decides per chunk from the integer search of sample SOURCE pictures against the sources one and two places back (the
-    oracle's search is the same arithmetic): the costs it reports equal the oracle's sums, the decision is c2 <= 1.12 c1, the picture types follow it, and
+    oracle's search is the same arithmetic): the costs it reports equal the oracle's sums, the decision is c2 <= 1.4 c1, the picture types follow it, and
     the stream decodes and replays either way."""
     from hevc_amd import _lib
     from hevc_amd.yuvio import SyntheticClip
@@ -185,9 +185,9 @@ def test_adaptive_b_decision_follows_the_probe(lib, pattern, w, h, n):
     per = util.n_ctus(w, h) * len(at)
     print(pattern, "probe", st.reserved[0], st.reserved[1], "oracle", c1 // per, c2 // per, "ratio", round(c2 / max(1, c1), 3))
     assert (st.reserved[0], st.reserved[1]) == (c1 // per, c2 // per)
-    want = c2 <= 1.12 * c1
+    want = c2 <= 1.4 * c1
     assert bool(st.reserved[2]) == want
     assert any(t == 0 for _, t, _ in infos) == want
     dec, info = O.decode(b"".join(p[0] for p in pk))
     assert len(dec) == n and all(d.same(r) for d, r in zip(dec, recs))
-    replay(lib, cfg, frames, infos, recs)
+    replay(lib, cfg, frames, infos, recs, with_b=want)

@@ -110,7 +110,9 @@ def run(args):
             ps = [99.0 if s <= 0 else 10 * np.log10(peak * peak / (s / d)) for s, d in ((st.sse_y, npx), (st.sse_u, npx / 4), (st.sse_v, npx / 4))]
             pts.append({"qp": qp, "kbps": round(nbytes * 8 / (N / 30.0) / 1e3, 2), "psnr_y": round(float(ps[0]), 4), "psnr_u": round(float(ps[1]), 4),
                         "psnr_v": round(float(ps[2]), 4), "fps_host_buffers": round(N / dt, 1)})
-            print(f"{name:7s} qp {qp}: {pts[-1]['kbps']:10.1f} kb/s  {pts[-1]['psnr_y']:.3f} dB  ({pts[-1]['fps_host_buffers']:.0f} fps)", file=sys.stderr)
+            if cfg.bframes < 0:       # the adaptive decision of the last chunk: cost per CTU one / two pictures back, B pictures chosen
+                pts[-1]["b_probe"] = [int(st.reserved[0]), int(st.reserved[1]), int(st.reserved[2])]
+            print(f"{name:7s} qp {qp}: {pts[-1]['kbps']:10.1f} kb/s  {pts[-1]['psnr_y']:.3f} dB  ({pts[-1]['fps_host_buffers']:.0f} fps) {pts[-1].get('b_probe', '')}", file=sys.stderr)
         res["clips"][name] = {"points": pts}
     if args.against:
         base = json.load(open(args.against))
