@@ -42,6 +42,7 @@ template <typename T> hipError_t launch_sao(hipStream_t st, const SaoArgs<T> *d_
 template <typename T> hipError_t launch_pad(hipStream_t st, const SaoArgs<T> *d_args, int w, int h, int batch);
 // per-picture sum of squared error into args.sse[0..2] (u64, accumulated with atomics: zero the targets first)
 template <typename T> hipError_t launch_frame_sse(hipStream_t st, const SaoArgs<T> *d_args, int batch);
+template <typename T> hipError_t launch_sse_fold(hipStream_t st, const SaoArgs<T> *d_args, int n_ctu, int batch);
 constexpr int MAX_LANES = 16;
 struct StepParams { CostParams prm[MAX_LANES]; int p_tile_cols, p_tile_rows; };      // one P step's cost parameters per lane, passed by value; the P pictures' tile grid (intra second pass: availability)
 template <typename T> hipError_t launch_begin_p_step(hipStream_t st, IntraArgs<T> *ia, InterArgs<T> *ea, SaoArgs<T> *sa, const StepParams &p, int batch);

@@ -242,6 +242,28 @@ template <typename T> __global__ __launch_bounds__(256) void k_frame_sse(const S
     if (threadIdx.x < 3 && red[threadIdx.x]) atomicAdd(a.sse + threadIdx.x, red[threadIdx.x]);
 }
 
+// the per-CTU squared errors the SAO programs left (SaoArgs::sse_ctu) -> the picture's three sums: one workgroup per picture, plain stores
+template <typename T> __global__ __launch_bounds__(256) void k_sse_fold(const SaoArgs<T> *args, int n_ctu)
+{
+    const SaoArgs<T> &a = args[blockIdx.x];
+    unsigned long long acc[3] = {0, 0, 0};
+    for (int i = (int)threadIdx.x; i < n_ctu; i += 256)
+        for (int pl = 0; pl < 3; pl++) acc[pl] += a.sse_ctu[3 * i + pl];
+    __shared__ unsigned long long red[3][4];
+    for (int pl = 0; pl < 3; pl++) {
+        unsigned long long v = acc[pl];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((threadIdx.x & 63) == 0) red[pl][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) a.sse[threadIdx.x] = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+template <typename T> hipError_t launch_sse_fold(hipStream_t st, const SaoArgs<T> *d_args, int n_ctu, int batch)
+{
+    hipLaunchKernelGGL(k_sse_fold<T>, dim3((unsigned)batch), dim3(256), 0, st, d_args, n_ctu);
+    return hipGetLastError();
+}
+
 // Start of a P step, one tiny launch for every lane: the step's cost parameters (QP from the rate controller, by value in the kernel
 // arguments) go into the lane's argument blocks — the rest of the blocks was uploaded with the chunk — and the per-picture accumulators
 // (SSE per plane + the rate estimate behind them: four 64-bit words at SaoArgs::sse) are zeroed.
@@ -479,6 +501,7 @@ int gfx950_device_count()
     template hipError_t launch_sao<T>(hipStream_t, const SaoArgs<T> *, int, int, int, bool);                            \
     template hipError_t launch_pad<T>(hipStream_t, const SaoArgs<T> *, int, int, int);                                  \
     template hipError_t launch_frame_sse<T>(hipStream_t, const SaoArgs<T> *, int);                                       \
+    template hipError_t launch_sse_fold<T>(hipStream_t, const SaoArgs<T> *, int, int);                                   \
     template hipError_t launch_begin_p_step<T>(hipStream_t, IntraArgs<T> *, InterArgs<T> *, SaoArgs<T> *, const StepParams &, int); \
     template hipError_t launch_extend_margin<T>(hipStream_t, Plane<T>, int, int, int, int);                             \
     template hipError_t launch_scene_diff<T>(hipStream_t, const ScenePic<T> *, unsigned long long *, int, int, int);            \
@@ -795,7 +818,7 @@ int stage_sao(const void *sy, const void *su, const void *sv, const void *dy, co
     CK(dsao.alloc((size_t)n_ctu * sizeof(mihevc_sao_ctu))); CK(dargs.alloc(sizeof(SaoArgs<T>)));
     SaoArgs<T> a;
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.dbk[i] = {dbk.p[i].pl.p, dbk.p[i].pl.stride}; a.out[i] = out.p[i].pl; }
-    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.sao = dsao.as<mihevc_sao_ctu>(); a.sse = nullptr; a.halo_top = a.halo_bottom = 0;
+    a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.sao = dsao.as<mihevc_sao_ctu>(); a.sse = nullptr; a.sse_ctu = nullptr; a.halo_top = a.halo_bottom = 0;
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_sao<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1, true));
     CK(launch_pad<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1));

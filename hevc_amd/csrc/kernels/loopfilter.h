@@ -114,7 +114,9 @@ template <typename T> struct SaoArgs {
     int w, h, ctus_w;
     CostParams prm;
     mihevc_sao_ctu *sao;
-    unsigned long long *sse;     // optional: 3 x u64 sum of squared error (source vs out), see k_frame_sse
+    unsigned long long *sse;     // optional: 3 x u64 sum of squared error (source vs out), see k_frame_sse / k_sse_fold
+    uint32_t *sse_ctu;           // optional: [n_ctu][3], every CTU program leaves the squared error of its own samples here (it holds source and output: no
+                                 // second pass over the picture); k_sse_fold adds them up.  A CTB plane's sum is < 1024 x 1023^2 < 2^32
     int halo_top, halo_bottom;   // > 0: the picture is one slice (a band of CTU rows) of a picture whose other slices are coded elsewhere and whose filters run
                                  // ACROSS the seams: that many rows above row 0 / below row h - 1 hold the neighbour slices' samples (dbk: deblocked rows, at
                                  // least one; out: up to PAD rows of the final reconstruction, copied in before the border pad, which replicates the outermost
@@ -373,9 +375,22 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             T *dst = a.out[pl].p + (ptrdiff_t)gy * a.out[pl].stride + gx;
             if (N == 4) store4(dst, v[0], v[1], v[2], v[3]);
             else { dst[0] = (T)v[0]; dst[1] = (T)v[1]; }
+            if (a.sse_ctu) {          // squared error of the strip into the lane's private copy (word 52 of a copy is the spare one, zero since phase 1)
+                const T *sp = (const T *)s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
+                unsigned e = 0;
+#pragma unroll
+                for (int i = 0; i < N; i++) { const int d = (int)sp[i] - v[i]; e += (unsigned)(d * d); }
+                if (e) ex.atomic_add(&s.priv[pl][tid & 15][52], e);
+            }
         };
         strip(std::integral_constant<int, 4>{}, 0, (tid & 7) * 4, tid >> 3);
         strip(std::integral_constant<int, 2>{}, 1 + (tid >> 7), (tid & 7) * 2, (tid & 127) >> 3);
+    });
+    if (a.sse_ctu) ex.phase([&](int tid) {
+        if (tid >= 3) return;
+        unsigned e = 0;
+        for (int c = 0; c < 16; c++) e += s.priv[tid][c][52];
+        a.sse_ctu[3 * ctu + tid] = e;
     });
 }
 

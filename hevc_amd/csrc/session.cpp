@@ -154,9 +154,10 @@ struct Packet {
     bool key = false, ready = false;
 };
 
-// symbol block of one picture: [cu | coef Y | coef U | coef V | sao | sse[3] | rate estimate]
+// symbol block of one picture: [cu | coef Y | coef U | coef V | sao | sse[3] | rate estimate]; the device twin carries the per-CTU squared errors behind it
+// (SaoArgs::sse_ctu: never copied to the host, k_sse_fold turns them into sse[3])
 struct SymLayout {
-    size_t cu, cu_bytes, cy, cu_, cv, sao, sse, est, total;
+    size_t cu, cu_bytes, cy, cu_, cv, sao, sse, est, total, sse_ctu, dev_total;
     SymLayout(int w, int h)
     {
         size_t n8 = (size_t)(w / 8) * (h / 8), ny = (size_t)w * h, nctu = (size_t)((w + 31) / 32) * ((h + 31) / 32);
@@ -171,6 +172,8 @@ struct SymLayout {
         sse = al(sao + nctu * sizeof(mihevc_sao_ctu));
         est = sse + 3 * sizeof(unsigned long long);
         total = al(est + sizeof(unsigned long long));
+        sse_ctu = total;
+        dev_total = al(sse_ctu + nctu * 3 * sizeof(uint32_t));
     }
 };
 
@@ -305,7 +308,7 @@ int ensure_lanes(mihevc_session *s, int n)
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, (void **)&L.ip));
         HIPCK(s, BufferCache::get().alloc(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, (void **)&L.plan));
         for (int k = 0; k < s->ring; k++) {
-            HIPCK(s, BufferCache::get().alloc(s->device, sl.total, false, (void **)&L.sym_dev[k]));
+            HIPCK(s, BufferCache::get().alloc(s->device, sl.dev_total, false, (void **)&L.sym_dev[k]));
             HIPCK(s, BufferCache::get().alloc(s->device, sl.total, true, (void **)&L.sym_host[k]));
         }
         s->lane.push_back(L);
@@ -849,6 +852,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.dbk_v.y_org = A.dbk_h.y_org = up ? kSeamRows : 0;
             A.sao.sao = s->cfg.sao ? (mihevc_sao_ctu *)(sym + sl.sao) : nullptr;
             A.sao.sse = (unsigned long long *)(sym + sl.sse);
+            A.sao.sse_ctu = s->cfg.sao ? (uint32_t *)(sym + sl.sse_ctu) : nullptr;
             A.intra.est = A.inter.est = (unsigned long long *)(sym + sl.est);
         }
     HIPCK(s, hipMemcpyAsync(da, ha, need, hipMemcpyHostToDevice, s->st_compute));
@@ -1051,7 +1055,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         mihevc_session::Lane &L = s->lane[g];
                         qp_trial[(size_t)g] = std::min(51, want[(size_t)g] + 3);
                         tv.sao[g] = hv.sao[g];
-                        tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr;
+                        tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr; tv.sao[g].sse_ctu = nullptr;
                         tv.sao[g].halo_top = tv.sao[g].halo_bottom = 0;      // the trial predicts from this band's own unfiltered picture with a replicated border
                         tv.inter[g] = h1.inter[g];
                         for (int i = 0; i < 3; i++) tv.inter[g].rec[i] = mk<T>(L.rec_p[1][i], L.rec_stride[i]);
@@ -1177,10 +1181,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
         }
         HIPCK(s, hipEventRecord(s->ev_compute[slot0], s->st_compute));      // (the border pad of these pictures is part of the next step's first launch)
         HIPCK(s, hipStreamWaitEvent(s->st_copy, s->ev_compute[slot0], 0));
-        // the SSE pass (statistics only) runs on the copy stream, in front of the symbol copies that carry its sums: 14 us per step off the
-        // compute stream's critical path.  It reads the reconstruction this step wrote; the step after next writes that buffer again and waits
-        // for this stream's event first (above).
-        HIPCK(s, launch_frame_sse<T>(s->st_copy, dv.sao, B));
+        // SSE (statistics only): the SAO programs left every CTU's squared error in the symbol block's device tail; one small launch on the copy stream, in
+        // front of the symbol copies that carry its sums, adds them up.  (Until round 3 a pass of its own re-read source and reconstruction here: 7 MB per
+        // picture and 25 us per step beside the compute stream.)  Without SAO that pass still runs: k_sao_apply is a plain copy and has no source.
+        if (s->cfg.sao) HIPCK(s, launch_sse_fold<T>(s->st_copy, dv.sao, s->n_ctu, B));
+        else HIPCK(s, launch_frame_sse<T>(s->st_copy, dv.sao, B));
         for (int g = 0; g < B; g++)
         {   // CU records, then SAO parameters + SSE + rate estimate (the level planes were written to the host block directly)
             uint8_t *hd = s->lane[g].sym_host[lane_slot[g]], *dd = s->lane[g].sym_dev[lane_slot[g]];
@@ -1593,7 +1598,7 @@ void mihevc_close(mihevc_session *s)
         bc.release(s->device, (size_t)s->n_ctu * 63 * sizeof(int32_t), false, L.me1);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IpInfo), false, L.ip);
         bc.release(s->device, (size_t)s->n_ctu * sizeof(IntraPlan), false, L.plan);
-        for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
+        for (int k = 0; k < s->ring; k++) { bc.release(s->device, sl.dev_total, false, L.sym_dev[k]); bc.release(s->device, sl.total, true, L.sym_host[k]); }
     }
     bc.release(s->device, s->args_cap, false, s->d_args);
     bc.release(s->device, s->scene_cap, false, s->d_scene);

@@ -195,3 +195,23 @@ def test_stepped_b_picture_kernels_equal_oracle(emu, w, h, qp, bd, rng, pre):
     gf, gsp = emu.sao(f[1], d, prm_b)
     wf, wsp = O.sao(f[1], d, prm_b)
     assert np.array_equal(gsp, wsp) and gf.same(wf)
+
+
+@pytest.mark.parametrize("w,h,bd", [(136, 104, 8), (96, 72, 10)])
+def test_sao_programs_leave_the_squared_error_of_their_ctu(emu, w, h, bd):
+    """SaoArgs::sse_ctu: every CTU program writes the squared error (source vs final reconstruction) of its own samples, per plane; k_sse_fold adds the table up
+    into the picture's statistics.  Against numpy, CTU by CTU, partial CTUs included."""
+    prm = O.default_params(30, bit_depth=bd, me_range=8)
+    src = util.synth_frame(h, w, seed=21, bit_depth=bd)
+    a = O.analyze_intra(src, prm)
+    dbk = O.deblock(a.rec, a.cu, bd)
+    ref, sp = O.sao(src, dbk, prm)
+    got, gsp, sse = emu.sao_sse(src, dbk, prm)
+    assert ref.same(got) and np.array_equal(sp, gsp)
+    cw = (w + 31) // 32
+    for c in range(sse.shape[0]):
+        x0, y0 = (c % cw) * 32, (c // cw) * 32
+        for pl, (s_, r_, sh) in enumerate(((src.y, ref.y, 0), (src.u, ref.u, 1), (src.v, ref.v, 1))):
+            d = s_[y0 >> sh:(y0 + 32) >> sh, x0 >> sh:(x0 + 32) >> sh].astype(np.int64) - r_[y0 >> sh:(y0 + 32) >> sh, x0 >> sh:(x0 + 32) >> sh].astype(np.int64)
+            assert int(sse[c, pl]) == int((d * d).sum()), (c, pl)
+    assert sse.sum() > 0

@@ -129,6 +129,17 @@ class StageApi:
         self._call("sao", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(d[0]), ptr(d[1]), ptr(d[2]), w, h, C.byref(prm), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(sp))
         return to_frame(o), sp
 
+    def sao_sse(self, src: O.Frame, dbk: O.Frame, prm):
+        """emulator only: SAO with the per-CTU squared-error table the CTU programs leave (SaoArgs::sse_ctu)"""
+        bd = prm.bit_depth
+        h, w = src.shape
+        s, d = planes(src, bd), planes(dbk, bd)
+        o = [np.zeros_like(p) for p in s]
+        sp = np.zeros(n_ctus(w, h), O.SAO_DTYPE)
+        sse = np.full((n_ctus(w, h), 3), 0xffffffff, np.uint32)
+        self._call("sao_sse", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(d[0]), ptr(d[1]), ptr(d[2]), w, h, C.byref(prm), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(sp), ptr(sse))
+        return to_frame(o), sp, sse
+
 
 def same_analysis(a, b):
     return (a.rec.same(b.rec) and np.array_equal(a.cu, b.cu) and np.array_equal(a.coef_y, b.coef_y) and
