@@ -45,7 +45,7 @@ EXPORTS = (
     "mihevc_abi_version", "mihevc_device_count", "mihevc_device_numa_node", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_async", "mihevc_sync_uploads", "mihevc_send_frame_device",
     "mihevc_receive_packet", "mihevc_flush", "mihevc_abort", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
     "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_tile_grid", "mihevc_p_tile_grid", "mihevc_k_transform",
-    "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_b_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_write_parameter_sets",
+    "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_b_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_k_loop_filter", "mihevc_write_parameter_sets",
     "mihevc_encode_picture_host",
 )
 
@@ -99,6 +99,7 @@ def load() -> C.CDLL:
     lib.mihevc_k_b_frame.argtypes = [i32] + [vp] * 9 + [i32, i32, C.POINTER(CostParams)] + [vp] * 12
     lib.mihevc_k_deblock.argtypes = [i32, vp, vp, vp, i32, i32, vp, i32]
     lib.mihevc_k_sao.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, C.POINTER(CostParams), vp, vp, vp, vp]
+    lib.mihevc_k_loop_filter.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp, C.POINTER(CostParams), vp, vp, vp, vp]
     lib.mihevc_write_parameter_sets.argtypes = [C.POINTER(Config), vp, C.c_size_t]
     lib.mihevc_encode_picture_host.argtypes = [C.POINTER(Config), i32, i32, i32, vp, vp, vp, vp, vp, vp, C.c_size_t]
     _lib = lib

@@ -140,7 +140,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_deblock(const Deb
 
 template <typename T> __global__ __launch_bounds__(NT, 4) void k_sao_decide(const SaoArgs<T> *args, int n_ctu)
 {
-    __shared__ SaoShared s;
+    __shared__ SaoShared<T> s;
     const int ctu = xcd_remap(blockIdx.x, n_ctu);
     if (ctu >= n_ctu) return;
     const SaoArgs<T> &a = args[blockIdx.y];
@@ -807,18 +807,25 @@ template <typename T> int stage_deblock(void *ry, void *ru, void *rv, int w, int
 
 template <typename T>
 int stage_sao(const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int h,
-              const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *sao)
+              const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *sao, const mihevc_cu_rec *cu = nullptr)
 {
     Planes3<T> src, dbk, out;
     if (src.alloc(w, h, false) || dbk.alloc(w, h, false) || out.alloc(w, h, true)) return MIHEVC_ENOMEM;
     if (int e = src.upload(sy, su, sv)) return e;
     if (int e = dbk.upload(dy, du, dv)) return e;
     const int ctus_w = (w + CTU - 1) / CTU, n_ctu = ctus_w * ((h + CTU - 1) / CTU);
-    DevBuf dsao, dargs;
+    DevBuf dsao, dargs, dcu;
     CK(dsao.alloc((size_t)n_ctu * sizeof(mihevc_sao_ctu))); CK(dargs.alloc(sizeof(SaoArgs<T>)));
     SaoArgs<T> a;
     for (int i = 0; i < 3; i++) { a.src[i] = {src.p[i].pl.p, src.p[i].pl.stride}; a.dbk[i] = {dbk.p[i].pl.p, dbk.p[i].pl.stride}; a.out[i] = out.p[i].pl; }
     a.w = w; a.h = h; a.ctus_w = ctus_w; a.prm = to_prm(prm); a.sao = dsao.as<mihevc_sao_ctu>(); a.sse = nullptr; a.sse_ctu = nullptr; a.halo_top = a.halo_bottom = 0;
+    a.cu = nullptr;
+    if (cu) {      // the fused loop filter: `dbk` is the pre-deblock reconstruction
+        const size_t n8 = (size_t)(w / 8) * (h / 8);
+        CK(dcu.alloc(n8 * sizeof(mihevc_cu_rec)));
+        CK(hipMemcpy(dcu.p, cu, n8 * sizeof(mihevc_cu_rec), hipMemcpyHostToDevice));
+        a.cu = dcu.as<mihevc_cu_rec>();
+    }
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     CK(launch_sao<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1, true));
     CK(launch_pad<T>(0, dargs.as<SaoArgs<T>>(), w, h, 1));
@@ -935,6 +942,16 @@ int mihevc_k_sao(int device, const void *sy, const void *su, const void *sv, con
     if (int e = select_device(device)) return e;
     if (prm->bit_depth == 8) return stage_sao<uint8_t>(sy, su, sv, dy, du, dv, w, h, prm, oy, ou, ov, sao);
     if (prm->bit_depth == 10) return stage_sao<uint16_t>(sy, su, sv, dy, du, dv, w, h, prm, oy, ou, ov, sao);
+    return MIHEVC_EINVAL;
+}
+
+int mihevc_k_loop_filter(int device, const void *sy, const void *su, const void *sv, const void *ry, const void *ru, const void *rv, int w, int h,
+                         const mihevc_cu_rec *cu, const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *sao)
+{
+    if (!sy || !su || !sv || !ry || !ru || !rv || !cu || !prm || !oy || !ou || !ov || !sao || !geometry_ok(w, h)) return MIHEVC_EINVAL;
+    if (int e = select_device(device)) return e;
+    if (prm->bit_depth == 8) return stage_sao<uint8_t>(sy, su, sv, ry, ru, rv, w, h, prm, oy, ou, ov, sao, cu);
+    if (prm->bit_depth == 10) return stage_sao<uint16_t>(sy, su, sv, ry, ru, rv, w, h, prm, oy, ou, ov, sao, cu);
     return MIHEVC_EINVAL;
 }
 

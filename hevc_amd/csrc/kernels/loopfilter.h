@@ -39,25 +39,20 @@ DEV int edge_bs(const mihevc_cu_rec &p, const mihevc_cu_rec &q)      // 8.7.2.4 
     return 0;
 }
 
-// one thread = one 4-sample luma segment (and the co-located 2 chroma samples per plane when the edge is a chroma edge)
-template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_index)
+// One 4-sample luma segment of an edge between the blocks p (left / above) and q, and the co-located 2 chroma samples per plane when the edge is a chroma
+// edge.  ly / cu / cv point at the segment's first sample on the q side; dir 0: a vertical edge (lines run down the rows), 1: a horizontal one.
+// Works on any sample image: the picture in HBM (k_deblock) or a CTU's tile in LDS (the fused loop filter, sao_ctu_program).
+template <typename T>
+DEV void deblock_lines(T *ly, int ystride, T *cu, T *cv, int cstride, int dir, const mihevc_cu_rec &p, const mihevc_cu_rec &q, int bit_depth, bool chroma_edge)
 {
-    const int w8 = a.w >> 3, segs = w8 * (a.h >> 3) * 2;
-    if (seg_index >= segs) return;
-    const int blk = seg_index >> 1, seg = seg_index & 1, bx = blk % w8, by = blk / w8, x = bx * 8, y = by * 8, dir = a.dir;
-    const mihevc_cu_rec q = a.cu[blk];
-    const int mask = (1 << q.log2_size) - 1;
-    const int yg = y - a.y_org;
-    if (dir == 0 ? (x == 0 || (x & mask)) : (y == 0 || (yg & mask))) return;
-    const mihevc_cu_rec p = a.cu[dir == 0 ? blk - 1 : blk - w8];
     const int bs = edge_bs(p, q);
     if (!bs) return;
-    const int maxv = (1 << a.bit_depth) - 1, sc = 1 << (a.bit_depth - 8);
+    const int maxv = (1 << bit_depth) - 1, sc = 1 << (bit_depth - 8);
     const int qpl = (p.qp + q.qp + 1) >> 1;
     const int beta = g_tab.beta[clip3(0, 51, qpl)] * sc, tc = g_tab.tc[clip3(0, 53, qpl + 2 * (bs - 1))] * sc;
     {
-        const int s = dir == 0 ? 1 : a.rec[0].stride, t = dir == 0 ? a.rec[0].stride : 1;
-        T *e = a.rec[0].p + (ptrdiff_t)y * a.rec[0].stride + x + (ptrdiff_t)seg * 4 * t;
+        const int s = dir == 0 ? 1 : ystride, t = dir == 0 ? ystride : 1;
+        T *e = ly;
         int P[4][4], Q[4][4];      // [distance from edge][line]
         for (int k = 0; k < 4; k++)
             for (int i = 0; i < 4; i++) { P[i][k] = e[-(i + 1) * (ptrdiff_t)s + k * (ptrdiff_t)t]; Q[i][k] = e[i * (ptrdiff_t)s + k * (ptrdiff_t)t]; }
@@ -90,11 +85,11 @@ template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_
             }
         }
     }
-    if (bs == 2 && ((dir == 0 ? x : yg) & 15) == 0) {      // chroma edge on the 8-sample chroma grid (8.7.2.5.5)
+    if (bs == 2 && chroma_edge) {      // chroma edge on the 8-sample chroma grid (8.7.2.5.5)
         const int tcc = g_tab.tc[clip3(0, 53, chroma_qp_of(qpl) + 2)] * sc;
         for (int ci = 1; ci < 3; ci++) {
-            const int s = dir == 0 ? 1 : a.rec[ci].stride, t = dir == 0 ? a.rec[ci].stride : 1;
-            T *e = a.rec[ci].p + (ptrdiff_t)(y >> 1) * a.rec[ci].stride + (x >> 1) + (ptrdiff_t)seg * 2 * t;
+            const int s = dir == 0 ? 1 : cstride, t = dir == 0 ? cstride : 1;
+            T *e = ci == 1 ? cu : cv;
             for (int k = 0; k < 2; k++) {
                 T *c = e + k * (ptrdiff_t)t;
                 int p0 = c[-1 * (ptrdiff_t)s], p1 = c[-2 * (ptrdiff_t)s], q0 = c[0], q1 = c[s];
@@ -104,6 +99,23 @@ template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_
             }
         }
     }
+}
+
+// one thread = one segment of the picture in HBM: both passes of k_deblock walk all (8x8 block, half) pairs
+template <typename T> DEV void deblock_segment(const DeblockArgs<T> &a, int seg_index)
+{
+    const int w8 = a.w >> 3, segs = w8 * (a.h >> 3) * 2;
+    if (seg_index >= segs) return;
+    const int blk = seg_index >> 1, seg = seg_index & 1, bx = blk % w8, by = blk / w8, x = bx * 8, y = by * 8, dir = a.dir;
+    const mihevc_cu_rec q = a.cu[blk];
+    const int mask = (1 << q.log2_size) - 1;
+    const int yg = y - a.y_org;
+    if (dir == 0 ? (x == 0 || (x & mask)) : (y == 0 || (yg & mask))) return;
+    const mihevc_cu_rec p = a.cu[dir == 0 ? blk - 1 : blk - w8];
+    const int ox = dir == 0 ? 0 : 4 * seg, oy = dir == 0 ? 4 * seg : 0;
+    deblock_lines<T>(a.rec[0].p + (ptrdiff_t)(y + oy) * a.rec[0].stride + x + ox, a.rec[0].stride,
+                     a.rec[1].p + (ptrdiff_t)((y + oy) >> 1) * a.rec[1].stride + ((x + ox) >> 1), a.rec[2].p + (ptrdiff_t)((y + oy) >> 1) * a.rec[2].stride + ((x + ox) >> 1),
+                     a.rec[1].stride, dir, p, q, a.bit_depth, ((dir == 0 ? x : yg) & 15) == 0);
 }
 
 // ------------------------------------------------------------------------------------------ SAO
@@ -117,29 +129,34 @@ template <typename T> struct SaoArgs {
     unsigned long long *sse;     // optional: 3 x u64 sum of squared error (source vs out), see k_frame_sse / k_sse_fold
     uint32_t *sse_ctu;           // optional: [n_ctu][3], every CTU program leaves the squared error of its own samples here (it holds source and output: no
                                  // second pass over the picture); k_sse_fold adds them up.  A CTB plane's sum is < 1024 x 1023^2 < 2^32
+    const mihevc_cu_rec *cu;     // non-null: FUSED loop filter — `dbk` holds the PRE-deblock reconstruction and the CTU program deblocks its tile itself (both edge passes,
+                                 // 8.7.2) before the SAO statistics: no deblocking pass over the picture, no in-place picture between the two filters.  One record per 8x8
+                                 // block as DeblockArgs::cu; with halo_top / halo_bottom the record rows -1 / h / 8 and the sample rows -4 .. -1 / h .. h + 3 are the neighbours'
     int halo_top, halo_bottom;   // > 0: the picture is one slice (a band of CTU rows) of a picture whose other slices are coded elsewhere and whose filters run
                                  // ACROSS the seams: that many rows above row 0 / below row h - 1 hold the neighbour slices' samples (dbk: deblocked rows, at
                                  // least one; out: up to PAD rows of the final reconstruction, copied in before the border pad, which replicates the outermost
                                  // of them where the whole picture ends earlier); 0: a picture edge
 };
 
-constexpr int SAO_TS_Y = 40, SAO_TS_C = 24;      // tile row strides in samples
-struct SaoShared {
+// The CTU's tile in LDS: the CTB and a halo of LF_HALO_Y luma / LF_HALO_C chroma samples on every side.  SAO alone needs one deblocked sample around the CTB; the
+// FUSED loop filter (SaoArgs::cu) loads the PRE-deblock reconstruction and filters the tile's own edges first: a deblocked sample of [-1, 32] depends on pre-deblock
+// samples of [-4, 35] only (an edge reads 4 and writes 3 samples either side; the horizontal-edge pass reads vertical-edge-filtered samples of the same range), chroma
+// [-1, 16] on [-2, 17].  Sample (x, y) of the CTB sits at tile index (y + HALO) * stride + x + 2 * HALO: the CTB's quads of four samples are 8-byte aligned.
+constexpr int LF_HALO_Y = 4, LF_HALO_C = 2, SAO_TS_Y = 48, SAO_TS_C = 24, LF_ROWS_Y = 32 + 2 * LF_HALO_Y, LF_ROWS_C = 16 + 2 * LF_HALO_C;
+template <typename T> struct SaoShared {
     int eo_n[3][4][5], eo_s[3][4][5], bo_n[3][32], bo_s[3][32];     // (these four first: zeroed as one int run)
     int8_t bo_off[3][32];
     long long bo_cost[3][32];
     int8_t eo_off[3][4][4];
     long long eo_cost[3][4];
-    // deblocked CTB + 1-sample halo, staged once: every sample's 8 neighbours are then LDS reads.  Tile column tx (picture column x0 - 1 + tx)
-    // sits at index tx + 3 of its row, so the CTB's own aligned quads of four samples are 8-byte aligned LDS stores
-    alignas(8) uint16_t tile_y[34 * SAO_TS_Y];
-    alignas(8) uint16_t tile_c[2][18 * SAO_TS_C];
-    alignas(4) uint16_t src[1536];   // the source CTB (Y, U, V as in the CTU kernels), held as T samples
+    alignas(8) T tile_y[LF_ROWS_Y * SAO_TS_Y];
+    alignas(8) T tile_c[2][LF_ROWS_C * SAO_TS_C];
+    alignas(4) T src[1536];          // the source CTB (Y, U, V as in the CTU kernels)
     // 16 private copies of the statistics (copy = lane & 15, odd stride -> distinct banks): neighbouring samples mostly
     // fall in the same category/band, and 64 lanes hitting one LDS word serialise (SQ_LDS_BANK_CONFLICT, r01 profiles)
     // count and difference sum share one word, (1 << 20) + (d + bias) per sample: half the LDS atomics.  A copy sees at most
     // 64 samples of a plane, so the biased sum (< 64 * 2048) never reaches the count field.
-    unsigned priv[3][16][53];        // per copy: eo[4][5] | bo[32], packed
+    unsigned priv[3][16][53];        // per copy: eo[4][5] | bo[32], packed | the squared error of the copy's lanes (SaoArgs::sse_ctu)
     unsigned long long band_key[3];  // min over the 29 band positions of ((cost + bias) << 8 | position)
     mihevc_sao_ctu chosen;           // the CTU's parameters, for the apply phase
 };
@@ -179,66 +196,69 @@ DEV int sao_offset_rd(int n, int s, int sign_rule, int lam_q4, int band, int max
     return best_o;
 }
 
-template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, const SaoArgs<T> &a, int ctu)
+template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared<T> &s, const SaoArgs<T> &a, int ctu)
 {
     const int cx = ctu % a.ctus_w, cy = ctu / a.ctus_w, bd = a.prm.bit_depth, lam = a.prm.lambda_q4;
     const int maxoff = (1 << (imin(bd, 10) - 5)) - 1;
+    const int x0 = cx * 32, y0 = cy * 32, wc = a.w >> 1, hc = a.h >> 1;
+    // rows above row 0 / below row h - 1 exist when a neighbour slice lies there (the exchange of csrc/slice_group.h put them into the picture's margins)
+    const int ylo = a.halo_top > 0 ? -LF_HALO_Y : 0, yup = a.halo_bottom > 0 ? LF_HALO_Y : 0;
+    constexpr int QY = LF_ROWS_Y * 10, QC = LF_ROWS_C * 6, NQ = QY + 2 * QC;      // quads of four samples: luma columns -4 .. 35, chroma columns -4 .. 19
     ex.phase([&](int tid) {
         int *z = &s.eo_n[0][0][0];
         for (int i = tid; i < 3 * (20 + 20 + 32 + 32); i += NT) z[i] = 0;
         for (int i = tid; i < 3 * 16 * 53; i += NT) (&s.priv[0][0][0])[i] = 0;
-        // deblocked CTB + halo and the source CTB.  The tiles are loaded as whole quads of four samples (the CTB's own columns: 34 x 8 luma and
-        // 2 x 18 x 4 chroma quads) plus the two halo columns sample by sample, at most three items a lane, and all of a lane's loads are issued
-        // before its first LDS store.  Rows and columns outside the picture are read from clamped addresses: the statistics never look at them.
-        // (One sample per item with its plane and position taken by division was half of this kernel's VALU work, profiles/r02_b.)
-        const int x0 = cx * 32, y0 = cy * 32, wc = a.w >> 1, hc = a.h >> 1;
-        const int ylo = a.halo_top > 0 ? -1 : 0, yup = a.halo_bottom > 0 ? 1 : 0;      // rows -1 / h exist when a neighbour slice lies there
-        auto quad_at = [&](int it, int &pl, int &ty, int &q) {       // item -> plane, tile row, quad of the row
-            if (it < 34 * 8) { pl = 0; ty = it >> 3; q = it & 7; return; }
-            it -= 34 * 8;
-            pl = 1 + it / 72; it %= 72; ty = it >> 2; q = it & 3;
+        // the tile (deblocked, or still to be deblocked here) and the source CTB.  Whole quads of four samples, at most three a lane, and all of a lane's loads are
+        // issued before its first LDS store.  Rows and columns outside the picture are read from clamped addresses: nothing ever looks at them.
+        auto quad_at = [&](int it, int &pl, int &ty, int &q) {       // item -> plane, tile row, quad of the row (-1: the one left of the CTB)
+            if (it < QY) { pl = 0; ty = it / 10; q = it % 10 - 1; return; }
+            it -= QY;
+            pl = 1 + it / QC; it %= QC; ty = it / 6; q = it % 6 - 1;
         };
-        auto halo_at = [&](int it, int &pl, int &ty, int &side) {    // item -> plane, tile row, left / right column
-            if (it < 68) { pl = 0; ty = it >> 1; side = it & 1; return; }
-            it -= 68;
-            pl = 1 + it / 36; it %= 36; ty = it >> 1; side = it & 1;
-        };
-        T qv[2][4] = {}, hvl = 0;
+        T qv[3][4] = {};
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             const int it = tid + k * NT;
-            if (it < 34 * 8 + 2 * 72) {
+            if (it < NQ) {
                 int pl, ty, q;
                 quad_at(it, pl, ty, q);
-                const int pw = pl ? wc : a.w, ph = pl ? hc : a.h;
-                const int gx = imin((pl ? x0 >> 1 : x0) + 4 * q, pw - 4), gy = clip3(ylo, ph - 1 + yup, (pl ? y0 >> 1 : y0) + ty - 1);
+                const int pw = pl ? wc : a.w, ph = pl ? hc : a.h, lo = pl ? ylo >> 1 : ylo, up = pl ? yup >> 1 : yup;
+                const int gx = clip3(0, pw - 4, (pl ? x0 >> 1 : x0) + 4 * q), gy = clip3(lo, ph - 1 + up, (pl ? y0 >> 1 : y0) + ty - (pl ? LF_HALO_C : LF_HALO_Y));
                 __builtin_memcpy(qv[k], a.dbk[pl].p + (ptrdiff_t)gy * a.dbk[pl].stride + gx, sizeof qv[k]);
             }
         }
-        if (tid < 68 + 72) {
-            int pl, ty, side;
-            halo_at(tid, pl, ty, side);
-            const int pw = pl ? wc : a.w, ph = pl ? hc : a.h, n = pl ? 16 : 32;
-            const int gx = clip3(0, pw - 1, (pl ? x0 >> 1 : x0) + (side ? n : -1)), gy = clip3(ylo, ph - 1 + yup, (pl ? y0 >> 1 : y0) + ty - 1);
-            hvl = a.dbk[pl].p[(ptrdiff_t)gy * a.dbk[pl].stride + gx];
-        }
-        load_ctu_source<T>((T *)s.src, a.src, x0, y0, a.w, a.h, tid);
+        load_ctu_source<T>(s.src, a.src, x0, y0, a.w, a.h, tid);
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             const int it = tid + k * NT;
-            if (it < 34 * 8 + 2 * 72) {
+            if (it < NQ) {
                 int pl, ty, q;
                 quad_at(it, pl, ty, q);
-                uint16_t *d = pl ? &s.tile_c[pl - 1][ty * SAO_TS_C + 4 + 4 * q] : &s.tile_y[ty * SAO_TS_Y + 4 + 4 * q];
+                T *d = pl ? &s.tile_c[pl - 1][ty * SAO_TS_C + 2 * LF_HALO_C + 4 * q] : &s.tile_y[ty * SAO_TS_Y + 2 * LF_HALO_Y + 4 * q];
                 store4(d, (int)qv[k][0], (int)qv[k][1], (int)qv[k][2], (int)qv[k][3]);
             }
         }
-        if (tid < 68 + 72) {
-            int pl, ty, side;
-            halo_at(tid, pl, ty, side);
-            if (pl) s.tile_c[pl - 1][ty * SAO_TS_C + 3 + (side ? 17 : 0)] = (uint16_t)hvl; else s.tile_y[ty * SAO_TS_Y + 3 + (side ? 33 : 0)] = (uint16_t)hvl;
-        }
     });
+    if (a.cu) {
+        // deblocking of the tile (8.7.2): every vertical edge segment that reaches columns [-4, 35] x rows [-4, 35], then every horizontal one.  A lane owns one
+        // 4-sample segment of one edge: 5 edges (CTB-relative 0, 8, .. 32) x 10 segments along them (-4, 0, .. 32).  Edges 8 apart never touch the same samples.
+        T *ty0 = s.tile_y + LF_HALO_Y * SAO_TS_Y + 2 * LF_HALO_Y, *tu0 = s.tile_c[0] + LF_HALO_C * SAO_TS_C + 2 * LF_HALO_C, *tv0 = s.tile_c[1] + LF_HALO_C * SAO_TS_C + 2 * LF_HALO_C;
+        const int w8 = a.w >> 3;
+        for (int dir = 0; dir < 2; dir++)
+            ex.phase([&](int tid) {
+                if (tid >= 50) return;
+                const int e = 8 * (tid / 10), o = 4 * (tid % 10) - 4;              // position of the edge, position of the segment along it
+                const int x = dir == 0 ? e : o, y = dir == 0 ? o : e, gx = x0 + x, gy = y0 + y;      // the segment's first q-side sample
+                if (gx < 0 || gx >= a.w || gy < ylo || gy >= a.h + yup) return;
+                if (dir == 0 ? gx == 0 : (gy == 0 ? a.halo_top <= 0 : gy >= a.h && a.halo_bottom <= 0)) return;      // a picture edge, not a block edge
+                const ptrdiff_t blk = (ptrdiff_t)(gy >> 3) * w8 + (gx >> 3);            // (gy >> 3 = -1: the neighbour slice's record row)
+                const mihevc_cu_rec q = a.cu[blk];
+                if ((dir == 0 ? gx : gy) & ((1 << q.log2_size) - 1)) return;
+                const mihevc_cu_rec p = a.cu[dir == 0 ? blk - 1 : blk - w8];
+                deblock_lines<T>(ty0 + y * SAO_TS_Y + x, SAO_TS_Y, tu0 + (y >> 1) * SAO_TS_C + (x >> 1), tv0 + (y >> 1) * SAO_TS_C + (x >> 1), SAO_TS_C, dir, p, q, bd,
+                                 ((dir == 0 ? gx : gy) & 15) == 0);
+            });
+    }
     ex.phase([&](int tid) {
         // a lane owns a strip of horizontally adjacent samples: four luma (row tid >> 3, quad tid & 7) and two chroma (plane tid >> 7): the three tile rows
         // around the strip are read once, and the horizontal differences are shared between neighbours
@@ -246,14 +266,14 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             constexpr int N = decltype(count)::value;
             const int pw = pl ? (a.w >> 1) : a.w, ph = pl ? (a.h >> 1) : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
             if (gx >= pw || gy >= ph) return;                      // plane widths are multiples of 4: a strip is inside or outside as a whole
-            const uint16_t *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
-            const int ts = pl ? SAO_TS_C : SAO_TS_Y, ti = (y + 1) * ts + x + 3;      // tile sample left of the strip
+            const T *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
+            const int ts = pl ? SAO_TS_C : SAO_TS_Y, ti = pl ? (y + LF_HALO_C) * ts + x + 2 * LF_HALO_C - 1 : (y + LF_HALO_Y) * ts + x + 2 * LF_HALO_Y - 1;      // tile sample left of the strip
             int up[N + 2], mid[N + 2], dn[N + 2], h[N + 1];
 #pragma unroll
             for (int j = 0; j < N + 2; j++) { up[j] = tp[ti - ts + j]; mid[j] = tp[ti + j]; dn[j] = tp[ti + ts + j]; }
 #pragma unroll
             for (int j = 0; j < N + 1; j++) h[j] = sgn3(mid[j + 1] - mid[j]);
-            const T *sp = (const T *)s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
+            const T *sp = s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
             unsigned *pv = s.priv[pl][tid & 15];
             const bool yin = (gy > 0 || a.halo_top > 0) && (gy < ph - 1 || a.halo_bottom > 0);
 #pragma unroll
@@ -351,8 +371,9 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             constexpr int N = decltype(count)::value;
             const int pw = pl ? (a.w >> 1) : a.w, ph = pl ? (a.h >> 1) : a.h, gx = (pl ? cx * 16 : cx * 32) + x, gy = (pl ? cy * 16 : cy * 32) + y;
             if (gx >= pw || gy >= ph) return;
-            const uint16_t *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
-            const int ts = pl ? SAO_TS_C : SAO_TS_Y, ti = (y + 1) * ts + x + 3, type = o.type[pl ? 1 : 0], cls = o.eo_class[pl ? 1 : 0];
+            const T *tp = pl ? s.tile_c[pl - 1] : s.tile_y;
+            const int ts = pl ? SAO_TS_C : SAO_TS_Y, ti = pl ? (y + LF_HALO_C) * ts + x + 2 * LF_HALO_C - 1 : (y + LF_HALO_Y) * ts + x + 2 * LF_HALO_Y - 1;
+            const int type = o.type[pl ? 1 : 0], cls = o.eo_class[pl ? 1 : 0];
             int v[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int i = 0; i < N; i++) {
@@ -376,7 +397,7 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared &s, c
             if (N == 4) store4(dst, v[0], v[1], v[2], v[3]);
             else { dst[0] = (T)v[0]; dst[1] = (T)v[1]; }
             if (a.sse_ctu) {          // squared error of the strip into the lane's private copy (word 52 of a copy is the spare one, zero since phase 1)
-                const T *sp = (const T *)s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
+                const T *sp = s.src + (pl ? 1024 + ((pl - 1) << 8) + y * 16 + x : y * 32 + x);
                 unsigned e = 0;
 #pragma unroll
                 for (int i = 0; i < N; i++) { const int d = (int)sp[i] - v[i]; e += (unsigned)(d * d); }

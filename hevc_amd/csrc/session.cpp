@@ -762,6 +762,8 @@ template <typename T> int encode_chunk(mihevc_session *s)
             A.intra.cu = A.inter.cu = (mihevc_cu_rec *)(sym + sl.cu);
             A.dbk_v.cu = A.dbk_h.cu = (const mihevc_cu_rec *)(sym + sl.cu);
             A.sao.halo_top = halo_top; A.sao.halo_bottom = halo_bottom;
+            // SAO on: the CTU programs of the SAO kernel deblock their own tile first (one launch for 8.7.2 + 8.7.3, the work picture stays as the analysis left it)
+            A.sao.cu = s->cfg.sao ? (const mihevc_cu_rec *)(sym + sl.cu) : nullptr;
             if (grp) {
                 // deblocking runs over the band EXTENDED by the rows the neighbours hand over (kSeamRows of their pre-deblock reconstruction + one row of CU
                 // records either side): the seams are inner edges of that picture
@@ -1055,7 +1057,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         mihevc_session::Lane &L = s->lane[g];
                         qp_trial[(size_t)g] = std::min(51, want[(size_t)g] + 3);
                         tv.sao[g] = hv.sao[g];
-                        tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr; tv.sao[g].sse_ctu = nullptr;
+                        tv.sao[g].sao = nullptr; tv.sao[g].sse = nullptr; tv.sao[g].sse_ctu = nullptr; tv.sao[g].cu = nullptr;
                         tv.sao[g].halo_top = tv.sao[g].halo_bottom = 0;      // the trial predicts from this band's own unfiltered picture with a replicated border
                         tv.inter[g] = h1.inter[g];
                         for (int i = 0; i < 3; i++) tv.inter[g].rec[i] = mk<T>(L.rec_p[1][i], L.rec_stride[i]);
@@ -1172,7 +1174,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                 }
             if (up + dn) HIPCK(s, launch_copy_rows(s->st_compute, (const RowCopy *)(dj + (size_t)t * jl.total + jl.imp), B * 8, 8));
         }
-        STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h + (grp ? kSeamRows * (up + dn) : 0), B));
+        if (!s->cfg.sao) STAGE(3, B, launch_deblock<T>(s->st_compute, dv.dbk_v, dv.dbk_h, s->w, s->h + (grp ? kSeamRows * (up + dn) : 0), B));
         STAGE(4, B, launch_sao<T>(s->st_compute, dv.sao, s->w, s->h, B, s->cfg.sao != 0));
         if (grp) {
             const long long G = s->gstep + t;

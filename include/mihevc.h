@@ -256,6 +256,11 @@ int mihevc_k_deblock(int device, void *rec_y, void *rec_u, void *rec_v, int widt
 int mihevc_k_sao(int device, const void *src_y, const void *src_u, const void *src_v,
                  const void *dbk_y, const void *dbk_u, const void *dbk_v, int width, int height,
                  const mihevc_cost_params *prm, void *out_y, void *out_u, void *out_v, mihevc_sao_ctu *sao);
+/* K4 in one pass (what a session runs): the CTU programs deblock their own tile of the PRE-deblock reconstruction `rec_*` (halo of 4 luma / 2 chroma samples),
+ * then decide and apply SAO.  Result = mihevc_k_deblock followed by mihevc_k_sao, bit for bit. */
+int mihevc_k_loop_filter(int device, const void *src_y, const void *src_u, const void *src_v,
+                         const void *rec_y, const void *rec_u, const void *rec_v, int width, int height, const mihevc_cu_rec *cu,
+                         const mihevc_cost_params *prm, void *out_y, void *out_u, void *out_v, mihevc_sao_ctu *sao);
 
 /* ---- host-only stages (no device needed): bitstream ---- */
 /* VPS+SPS+PPS (+SEI when hdr10) as Annex-B into buf; returns size or negative error */

@@ -302,18 +302,18 @@ template <typename T> static int deblock(T *y, T *u, T *v, int w, int h, const m
 // (SaoArgs::halo; csrc/slice_group.h): the kernel then sees its band as the picture and finds the neighbour rows where the exchange puts them
 template <typename T>
 static int sao(const T *sy, const T *su, const T *sv, const T *dy, const T *du, const T *dv, int w, int h, const mihevc_cost_params *prm,
-               T *oy, T *ou, T *ov, mihevc_sao_ctu *out, int y0 = 0, int halo = 0, uint32_t *sse_ctu = nullptr)
+               T *oy, T *ou, T *ov, mihevc_sao_ctu *out, int y0 = 0, int halo = 0, uint32_t *sse_ctu = nullptr, const mihevc_cu_rec *cu = nullptr)
 {
     SaoArgs<T> a;
     const ptrdiff_t oy_ = (ptrdiff_t)y0 * w, oc_ = (ptrdiff_t)(y0 / 2) * (w / 2);
     a.src[0] = {sy + oy_, w}; a.src[1] = {su + oc_, w / 2}; a.src[2] = {sv + oc_, w / 2};
     a.dbk[0] = {dy + oy_, w}; a.dbk[1] = {du + oc_, w / 2}; a.dbk[2] = {dv + oc_, w / 2};
     a.out[0] = {oy + oy_, w}; a.out[1] = {ou + oc_, w / 2}; a.out[2] = {ov + oc_, w / 2};
-    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.prm = to_prm(prm); a.sao = out; a.sse = nullptr; a.sse_ctu = sse_ctu; a.halo_top = (halo & 1) ? 1 : 0; a.halo_bottom = (halo & 2) ? 1 : 0;
+    a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.prm = to_prm(prm); a.sao = out; a.sse = nullptr; a.sse_ctu = sse_ctu; a.cu = cu ? cu + (size_t)(y0 / 8) * (w / 8) : nullptr; a.halo_top = (halo & 1) ? 1 : 0; a.halo_bottom = (halo & 2) ? 1 : 0;
     SeqExec ex; ex.order = emu_order();
     int n_ctu = a.ctus_w * ((h + CTU - 1) / CTU);
     for (int c = 0; c < n_ctu; c++) {
-        SaoShared s;
+        SaoShared<T> s;
         if (const char *e = getenv("EMU_WAVES")) { if (!run_waves((unsigned long long)atoll(e) + 131u * (unsigned)c, [&](WaveExec &wx) { sao_ctu_program<T>(wx, s, a, c); })) return -2; }
         else sao_ctu_program<T>(ex, s, a, c);
     }
@@ -368,6 +368,16 @@ int emu_sao_band(const void *sy, const void *su, const void *sv, const void *dy,
                             (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, out, y0, halo);
     return sao<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)dy, (const uint16_t *)du, (const uint16_t *)dv, w, h, prm,
                          (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, out, y0, halo);
+}
+// the fused loop filter (SaoArgs::cu): r* = the PRE-deblock reconstruction; y0 / h / halo as emu_sao_band (cu: the whole picture's records)
+int emu_loop_filter(const void *sy, const void *su, const void *sv, const void *ry, const void *ru, const void *rv, int w, int y0, int h, int halo, const mihevc_cu_rec *cu,
+                    const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *out)
+{
+    if (prm->bit_depth == 8)
+        return sao<uint8_t>((const uint8_t *)sy, (const uint8_t *)su, (const uint8_t *)sv, (const uint8_t *)ry, (const uint8_t *)ru, (const uint8_t *)rv, w, h, prm,
+                            (uint8_t *)oy, (uint8_t *)ou, (uint8_t *)ov, out, y0, halo, nullptr, cu);
+    return sao<uint16_t>((const uint16_t *)sy, (const uint16_t *)su, (const uint16_t *)sv, (const uint16_t *)ry, (const uint16_t *)ru, (const uint16_t *)rv, w, h, prm,
+                         (uint16_t *)oy, (uint16_t *)ou, (uint16_t *)ov, out, y0, halo, nullptr, cu);
 }
 int emu_sao_sse(const void *sy, const void *su, const void *sv, const void *dy, const void *du, const void *dv, int w, int h,
                 const mihevc_cost_params *prm, void *oy, void *ou, void *ov, mihevc_sao_ctu *out, uint32_t *sse_ctu)

@@ -81,6 +81,8 @@ def stage_parity(lib, api, cfg, frames, qp_p):
         gf, gsp = api.sao(src, d, cp)
         assert np.array_equal(gsp, sp), f"sao params picture {i}"
         assert gf.same(f), f"sao picture {i}"
+        lf, lsp = api.loop_filter(src, want.rec, want.cu, cp)
+        assert np.array_equal(lsp, sp) and lf.same(f), f"fused loop filter picture {i}"
         ref = f
 
 

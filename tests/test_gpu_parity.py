@@ -84,6 +84,8 @@ def test_stage_parity_i_p_p(lib, api, w, h, qp, bd, rng):
         gf, gsp = api.sao(src, d, cp)
         assert np.array_equal(gsp, sp), f"sao params picture {i}"
         assert gf.same(f), f"sao picture {i}"
+        lf, lsp = api.loop_filter(src, a.rec, a.cu, cp)       # what a session runs: both filters in one CTU program over the pre-deblock picture
+        assert np.array_equal(lsp, sp) and lf.same(f), f"fused loop filter picture {i}"
         ref = f
 
 

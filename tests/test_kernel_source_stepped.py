@@ -215,3 +215,58 @@ def test_sao_programs_leave_the_squared_error_of_their_ctu(emu, w, h, bd):
             d = s_[y0 >> sh:(y0 + 32) >> sh, x0 >> sh:(x0 + 32) >> sh].astype(np.int64) - r_[y0 >> sh:(y0 + 32) >> sh, x0 >> sh:(x0 + 32) >> sh].astype(np.int64)
             assert int(sse[c, pl]) == int((d * d).sum()), (c, pl)
     assert sse.sum() > 0
+
+
+@pytest.mark.parametrize("w,h,bd,qp", [(136, 104, 8, 30), (96, 72, 10, 26), (200, 136, 8, 38)])
+def test_fused_loop_filter_equals_deblocking_then_sao(emu, w, h, bd, qp):
+    """SaoArgs::cu: the CTU programs deblock their own tile of the PRE-deblock reconstruction (halo of 4 luma / 2 chroma samples, both edge passes) and then decide and
+    apply SAO.  The result must be the two picture passes' (oracle deblock, then oracle SAO) bit for bit: intra pictures (Bs 2, chroma edges), P pictures with
+    skipped / coded CUs of all sizes (Bs 0 / 1 by motion and residual), partial CTUs on the right and at the bottom."""
+    from tests.test_bitstream_cpu import occluded_clip
+    prm = O.default_params(qp, bit_depth=bd, me_range=8)
+    srcs = occluded_clip(w, h, bd) if bd == 8 else [util.synth_frame(h, w, seed=5, shift=(3 * i, 2 * i), bit_depth=bd) for i in range(3)]
+    a = O.analyze_intra(srcs[0], prm)
+    want, wsp = O.sao(srcs[0], O.deblock(a.rec, a.cu, bd), prm)
+    got, gsp = emu.loop_filter(srcs[0], a.rec, a.cu, prm)
+    assert np.array_equal(wsp, gsp) and want.same(got), "intra picture"
+    assert not O.deblock(a.rec, a.cu, bd).same(a.rec)
+    ref = want
+    for i in (1, 2):
+        a = O.analyze_inter(srcs[i], ref, prm)
+        dbk = O.deblock(a.rec, a.cu, bd)
+        want, wsp = O.sao(srcs[i], dbk, prm)
+        got, gsp = emu.loop_filter(srcs[i], a.rec, a.cu, prm)
+        assert np.array_equal(wsp, gsp) and want.same(got), f"P picture {i}"
+        ref = want
+
+
+def test_fused_loop_filter_in_wave_threads_and_any_lane_order(emu, monkeypatch):
+    prm = O.default_params(32, bit_depth=8, me_range=8)
+    src = util.synth_frame(72, 104, seed=8, bit_depth=8)
+    a = O.analyze_intra(src, prm)
+    want, wsp = O.sao(src, O.deblock(a.rec, a.cu, 8), prm)
+    for order in ("1", "2"):
+        monkeypatch.setenv("EMU_ORDER", order)
+        got, gsp = emu.loop_filter(src, a.rec, a.cu, prm)
+        assert np.array_equal(wsp, gsp) and want.same(got), order
+    monkeypatch.delenv("EMU_ORDER")
+    monkeypatch.setenv("EMU_WAVES", "3")
+    got, gsp = emu.loop_filter(src, a.rec, a.cu, prm)
+    assert np.array_equal(wsp, gsp) and want.same(got)
+
+
+def test_fused_loop_filter_of_a_band_filters_across_its_seams(emu):
+    """one slice (a band of CTU rows) of a picture whose other slices are coded elsewhere, filters across the seams (cfg.slice_halo): the band's programs find the
+    neighbours' pre-deblock rows and CU records beyond their first and last row (where the exchange of csrc/slice_group.h puts them) and produce exactly the band's
+    rows of the whole picture's loop filter"""
+    w, h, bd = 136, 160, 8
+    prm = O.default_params(34, bit_depth=bd, me_range=8)
+    src = util.synth_frame(h, w, seed=12, bit_depth=bd)
+    a = O.analyze_intra(src, prm)
+    want, wsp = O.sao(src, O.deblock(a.rec, a.cu, bd), prm)
+    cw = (w + 31) // 32
+    for y0, bh, halo in ((0, 64, 2), (64, 32, 3), (96, 64, 1)):
+        got, gsp = emu.loop_filter(src, a.rec, a.cu, prm, band=(y0, bh, halo))
+        assert np.array_equal(got.y[y0:y0 + bh], want.y[y0:y0 + bh]) and np.array_equal(got.u[y0 // 2:(y0 + bh) // 2], want.u[y0 // 2:(y0 + bh) // 2])
+        assert np.array_equal(got.v[y0 // 2:(y0 + bh) // 2], want.v[y0 // 2:(y0 + bh) // 2])
+        assert np.array_equal(gsp, wsp[(y0 // 32) * cw:((y0 + bh + 31) // 32) * cw])

@@ -129,6 +129,23 @@ class StageApi:
         self._call("sao", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(d[0]), ptr(d[1]), ptr(d[2]), w, h, C.byref(prm), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(sp))
         return to_frame(o), sp
 
+    def loop_filter(self, src: O.Frame, rec: O.Frame, cu, prm, band=None):
+        """deblocking + SAO in one pass over the PRE-deblock reconstruction (the fused CTU program a session runs).  band = (y0, h, halo): emulator only, rows
+        [y0, y0 + h) of the picture as one slice whose filters run across the seams (halo bit 0: a slice above, bit 1: below)"""
+        bd = prm.bit_depth
+        h, w = src.shape
+        s, d = planes(src, bd), planes(rec, bd)
+        o = [np.zeros_like(p) for p in s]
+        cu = np.ascontiguousarray(cu)
+        if band is None and self.prefix != "emu_":
+            sp = np.zeros(n_ctus(w, h), O.SAO_DTYPE)
+            self._call("loop_filter", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(d[0]), ptr(d[1]), ptr(d[2]), w, h, ptr(cu), C.byref(prm), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(sp))
+            return to_frame(o), sp
+        y0, bh, halo = band if band is not None else (0, h, 0)
+        sp = np.zeros(n_ctus(w, bh), O.SAO_DTYPE)
+        self._call("loop_filter", ptr(s[0]), ptr(s[1]), ptr(s[2]), ptr(d[0]), ptr(d[1]), ptr(d[2]), w, y0, bh, halo, ptr(cu), C.byref(prm), ptr(o[0]), ptr(o[1]), ptr(o[2]), ptr(sp))
+        return to_frame(o), sp
+
     def sao_sse(self, src: O.Frame, dbk: O.Frame, prm):
         """emulator only: SAO with the per-CTU squared-error table the CTU programs leave (SaoArgs::sse_ctu)"""
         bd = prm.bit_depth
