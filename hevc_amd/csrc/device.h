@@ -31,7 +31,19 @@ template <typename T> hipError_t launch_inter_ctu_b(hipStream_t st, const InterA
 template <typename T> hipError_t launch_inter_ctu(hipStream_t st, const InterArgs<T> *d_args, int n_ctu, int batch, int me_range);
 // all anti-diagonals of an I picture batch; h_args is the host copy (geometry only), d_args the device array
 // after_plan (optional): recorded between stage A (k_intra_plan, throughput-bound) and the anti-diagonal chain of stage B (latency-bound: other streams' work fits beside it)
-template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows, hipEvent_t after_plan);
+// flow (optional, IntraFlow::order non-null): stage B as ONE launch in which every CTU program waits for the two CTUs its prediction depends on (k_intra_flow) instead of
+// one launch per anti-diagonal
+struct IntraFlowSlot { int cx, cy, dep0, dep1; };      // a CTU and the raster indices of the CTUs to wait for (-1: none)
+struct IntraFlow {
+    const IntraFlowSlot *order = nullptr;              // device: the picture's CTUs, anti-diagonal (x + 2y inside the tile) major: a CTU's dependencies come earlier
+    int *flags = nullptr;                              // device: [batch][n_ctu], a CTU's word holds `gen` once it is coded (any older value: not yet)
+    int *err = nullptr;                                // device: set when a wait gave up (never seen: the bound keeps a bug from hanging the device)
+    int gen = 0;
+};
+// host: the slot table of a picture's tile grid
+void build_intra_flow_order(int ctus_w, int ctus_h, int tile_cols, int tile_rows, IntraFlowSlot *out);
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows, hipEvent_t after_plan,
+                                                      const IntraFlow &flow = IntraFlow());
 template <typename T> hipError_t launch_intra_p(hipStream_t st, const IntraArgs<T> *d_args, int n_ctu, int batch);
 // a whole chunk: d_args[i] = picture i in stream order; its 1/4-size SOURCE picture (lsrc) and its search centres from lsrc against lref (the predecessor's lsrc)
 template <typename T> hipError_t launch_pre_search_chunk(hipStream_t st, const PreArgs<T> *d_args, int w, int h, int n_ctu, int n_pictures);

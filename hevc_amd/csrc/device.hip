@@ -107,6 +107,41 @@ template <typename T> __global__ __launch_bounds__(NT, 2) void k_intra_diag(cons
     intra_code_program<T>(ex, s, a, cx, cy, true);
 }
 
+// Stage B of an I picture in ONE launch.  Inside a tile a CTU predicts from its left, above-left, above and above-right neighbours; coded along anti-diagonals x + 2y
+// the two of them on the diagonal before (left, above-right; above when there is no above-right) finish last, so waiting for those two is waiting for all four.
+// Workgroup ids run through the CTUs in anti-diagonal order (IntraFlow::order; the lanes of a batch interleaved): everything a workgroup waits for has a LOWER id, and
+// the dispatcher hands out ids in order, so the lowest unfinished id is always resident and never waits: no deadlock for any number of resident workgroups.  A
+// workgroup publishes its CTU with a release store at device scope after all of its waves fenced their stores (reconstruction, CU records: the neighbours' reads);
+// the waiting side polls with relaxed device-scope loads and fences once it saw the word.  With one launch per anti-diagonal (k_intra_diag) every step of the chain
+// cost the SLOWEST CTU of the diagonal plus a launch boundary: 24 x 130 us per IDR step at 1080p whatever the content.
+template <typename T> __global__ __launch_bounds__(NT, 2) void k_intra_flow(const IntraArgs<T> *args, int lanes, int n_ctu, IntraFlow f)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int id = (int)blockIdx.x, lane = id % lanes, slot = id / lanes;
+    if (slot >= n_ctu) return;
+    const IntraArgs<T> &a = args[lane];
+    const IntraFlowSlot o = f.order[slot];
+    int *fl = f.flags + (size_t)lane * n_ctu;
+    if (threadIdx.x < 2) {
+        const int dep = threadIdx.x == 0 ? o.dep0 : o.dep1;
+        if (dep >= 0) {
+            int spins = 0;
+            while (__hip_atomic_load(fl + dep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != f.gen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1 << 21)) { atomicExch(f.err, 1); break; }      // ~1 s: a bug, not a wait
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // every wave: nothing it reads from here on may come from before the neighbours' release
+    IntraShared<T> &s = *reinterpret_cast<IntraShared<T> *>(smem);
+    GpuExec ex;
+    intra_code_program<T>(ex, s, a, o.cx, o.cy, true);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // every wave's stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(fl + o.cy * a.ctus_w + o.cx, f.gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T> __global__ __launch_bounds__(256) void k_lowres(const PreArgs<T> *args)
 {
     lowres_sample<T>(args[blockIdx.y], (int)(blockIdx.x * 256 + threadIdx.x));
@@ -368,18 +403,46 @@ template <typename T> hipError_t launch_inter_ctu_b(hipStream_t st, const InterA
     return hipGetLastError();
 }
 
-template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows, hipEvent_t after_plan)
+void build_intra_flow_order(int ctus_w, int ctus_h, int tile_cols, int tile_rows, IntraFlowSlot *out)
+{
+    if (tile_cols < 1) tile_cols = 1;
+    if (tile_rows < 1) tile_rows = 1;
+    const int colw = (ctus_w + tile_cols - 1) / tile_cols, rowh = (ctus_h + tile_rows - 1) / tile_rows;
+    int n = 0;
+    for (int d = 0; d <= (colw - 1) + 2 * (rowh - 1); d++)
+        for (int tile = 0; tile < tile_cols * tile_rows; tile++) {
+            const int tx = tile % tile_cols, ty = tile / tile_cols;
+            const int cx0 = tile_bd(tx, tile_cols, ctus_w), cx1 = tile_bd(tx + 1, tile_cols, ctus_w), cy0 = tile_bd(ty, tile_rows, ctus_h), cy1 = tile_bd(ty + 1, tile_rows, ctus_h);
+            for (int r = 0; r < cy1 - cy0; r++) {
+                const int cy = cy0 + r, cx = cx0 + d - 2 * r;
+                if (cx < cx0 || cx >= cx1) continue;
+                IntraFlowSlot s{cx, cy, -1, -1};
+                if (cx > cx0) s.dep0 = cy * ctus_w + cx - 1;
+                if (cy > cy0) s.dep1 = (cy - 1) * ctus_w + (cx + 1 < cx1 ? cx + 1 : cx);
+                out[n++] = s;
+            }
+        }
+}
+
+template <typename T> hipError_t launch_intra_picture(hipStream_t st, const IntraArgs<T> *d_args, int ctus_w, int ctus_h, int batch, int tile_cols, int tile_rows, hipEvent_t after_plan,
+                                                      const IntraFlow &flow)
 {
     size_t smem = round16(sizeof(IntraShared<T>));
     hipError_t e = ensure_smem(k_intra_plan<T>, smem);
     if (e != hipSuccess) return e;
     e = ensure_smem(k_intra_diag<T>, smem);
     if (e != hipSuccess) return e;
+    e = ensure_smem(k_intra_flow<T>, smem);
+    if (e != hipSuccess) return e;
     if (tile_cols < 1) tile_cols = 1;
     if (tile_rows < 1) tile_rows = 1;
     const int n_ctu = ctus_w * ctus_h;
     hipLaunchKernelGGL(k_intra_plan<T>, dim3((unsigned)(((n_ctu + 7) >> 3) << 3), (unsigned)batch), dim3(NT), smem, st, d_args, n_ctu);      // stage A: every CTU at once
     if (after_plan) { e = hipEventRecord(after_plan, st); if (e != hipSuccess) return e; }      // from here on the stream runs the latency-bound anti-diagonal chain
+    if (flow.order) {      // stage B as one dataflow launch
+        hipLaunchKernelGGL(k_intra_flow<T>, dim3((unsigned)(n_ctu * batch)), dim3(NT), smem, st, d_args, batch, n_ctu, flow);
+        return hipGetLastError();
+    }
     // stage B, per tile one anti-diagonal at a time; uniform spacing: the widest column / tallest row is ceil(n_ctb / n_tiles)
     const int colw = (ctus_w + tile_cols - 1) / tile_cols, rowh = (ctus_h + tile_rows - 1) / tile_rows;
     for (int d = 0; d <= (colw - 1) + 2 * (rowh - 1); d++)
@@ -492,7 +555,7 @@ int gfx950_device_count()
     template hipError_t launch_me_search<T>(hipStream_t, const InterArgs<T> *, int, int, int, int);                     \
     template hipError_t launch_inter_ctu_b<T>(hipStream_t, const InterArgs<T> *, int, int, int);                        \
     template hipError_t launch_inter_ctu<T>(hipStream_t, const InterArgs<T> *, int, int, int);                          \
-    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int, hipEvent_t);     \
+    template hipError_t launch_intra_picture<T>(hipStream_t, const IntraArgs<T> *, int, int, int, int, int, hipEvent_t, const IntraFlow &);     \
     template hipError_t launch_intra_p<T>(hipStream_t, const IntraArgs<T> *, int, int);                                       \
     template hipError_t launch_pre_search<T>(hipStream_t, const PreArgs<T> *, int, int, int, int, bool);                \
     template hipError_t launch_pre_search_chunk<T>(hipStream_t, const PreArgs<T> *, int, int, int, int);                \
@@ -660,8 +723,20 @@ int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, co
     a.w = w; a.h = h; a.ctus_w = (w + CTU - 1) / CTU; a.ctus_h = (h + CTU - 1) / CTU; a.prm = to_prm(prm);
     a.cu = dcu.as<mihevc_cu_rec>(); a.coef[0] = dc0.as<int16_t>(); a.coef[1] = dc1.as<int16_t>(); a.coef[2] = dc2.as<int16_t>(); a.diagonal = 0; a.est = dest.as<unsigned long long>(); a.sparse_coef = 0; a.ip = nullptr; a.plan = dplan.as<IntraPlan>();
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
-    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows, nullptr));
+    IntraFlow flow;
+    DevBuf dorder, dflags;
+    if (!getenv("MIHEVC_INTRA_CHAIN")) {      // (debug switch: stage B as one launch per anti-diagonal, the form of rounds 1 and 2)
+        const int n_ctu = a.ctus_w * a.ctus_h;
+        std::vector<IntraFlowSlot> order((size_t)n_ctu);
+        build_intra_flow_order(a.ctus_w, a.ctus_h, a.prm.tile_cols, a.prm.tile_rows, order.data());
+        CK(dorder.alloc(order.size() * sizeof(IntraFlowSlot))); CK(dflags.alloc(((size_t)n_ctu + 1) * sizeof(int)));
+        CK(hipMemcpy(dorder.p, order.data(), order.size() * sizeof(IntraFlowSlot), hipMemcpyHostToDevice));
+        CK(hipMemset(dflags.p, 0, ((size_t)n_ctu + 1) * sizeof(int)));
+        flow.order = dorder.as<IntraFlowSlot>(); flow.flags = dflags.as<int>(); flow.err = dflags.as<int>() + n_ctu; flow.gen = 1;
+    }
+    CK(launch_intra_picture<T>(0, dargs.as<IntraArgs<T>>(), a.ctus_w, a.ctus_h, 1, a.prm.tile_cols, a.prm.tile_rows, nullptr, flow));
     CK(hipDeviceSynchronize());
+    if (flow.order) { int bad = 0; CK(hipMemcpy(&bad, flow.err, sizeof bad, hipMemcpyDeviceToHost)); if (bad) return MIHEVC_EDEVICE; }
     if (int e = rec.download(ry, ru, rv)) return e;
     CK(hipMemcpy(cu, dcu.p, n8 * sizeof(mihevc_cu_rec), hipMemcpyDeviceToHost));
     CK(hipMemcpy(cy, dc0.p, ny * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cu_, dc1.p, ny / 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(cv, dc2.p, ny / 2, hipMemcpyDeviceToHost));

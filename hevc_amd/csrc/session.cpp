@@ -235,6 +235,7 @@ struct mihevc_session {
     double ratio_i = 1.0, ratio_p = 1.0;      // learned (CABAC bits) / (device estimate); updated once per chunk (deterministic)
     bool rho_measured = false;                // the session's first chunk measures rho with a trial analysis of the GOPs' first P picture
     double rho_pi = 1.0 / 16.0;               // learned (P bits) / (IDR bits) at equal QP: the prior before a GOP's first P estimate lands
+    void *d_flow = nullptr; size_t flow_bytes = 0; int flow_gen = 0;      // IDR pictures' stage B as one dataflow launch (device.h IntraFlow): [slot table | flags[MAX_LANES][n_ctu] | err]
     void *d_probe = nullptr; size_t probe_cap = 0;      // cfg.bframes = -1: the probe's low-resolution pictures, centres and costs
     double beta_bp = 0.45;                    // cfg.bframes: learned (B bits at QP + 2) / (P bits at QP): what a B picture takes of the GOP budget beside a P picture
     int64_t pts_step = 1, first_pts = 0;      // pts distance of the first two frames: with B pictures dts = (pts of the frame at the packet's place in decoding order) - pts_step
@@ -314,6 +315,32 @@ int ensure_lanes(mihevc_session *s, int n)
         s->lane.push_back(L);
     }
     return 0;
+}
+
+// the IDR pictures' dataflow launch (k_intra_flow): slot table and flag words, made once per session.  Buffers come from the process-wide cache with whatever an
+// earlier session left in them, so the flags are zeroed here and generations count from 1.  MIHEVC_INTRA_CHAIN (debug switch): one launch per anti-diagonal instead.
+static int ensure_flow(mihevc_session *s)
+{
+    if (s->d_flow || getenv("MIHEVC_INTRA_CHAIN")) return 0;
+    const size_t o_flags = (size_t)s->n_ctu * sizeof(IntraFlowSlot), bytes = o_flags + ((size_t)MAX_LANES * s->n_ctu + 1) * sizeof(int);
+    HIPCK(s, BufferCache::get().alloc(s->device, bytes, false, &s->d_flow));
+    s->flow_bytes = bytes;
+    std::vector<IntraFlowSlot> order((size_t)s->n_ctu);
+    build_intra_flow_order(s->ctus_w, s->ctus_h, s->tiles.cols, s->tiles.rows, order.data());
+    HIPCK(s, hipMemcpyAsync(s->d_flow, order.data(), o_flags, hipMemcpyHostToDevice, s->st_compute));
+    HIPCK(s, hipMemsetAsync((uint8_t *)s->d_flow + o_flags, 0, bytes - o_flags, s->st_compute));
+    HIPCK(s, hipStreamSynchronize(s->st_compute));      // `order` leaves scope
+    return 0;
+}
+static IntraFlow next_flow(mihevc_session *s)
+{
+    IntraFlow f;
+    if (!s->d_flow) return f;
+    f.order = (const IntraFlowSlot *)s->d_flow;
+    f.flags = (int *)((uint8_t *)s->d_flow + (size_t)s->n_ctu * sizeof(IntraFlowSlot));
+    f.err = f.flags + (size_t)MAX_LANES * s->n_ctu;
+    f.gen = ++s->flow_gen;
+    return f;
 }
 
 // argument blocks of one lock-step step: five arrays of `gops` entries each, so one launch per stage covers all lanes
@@ -637,6 +664,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     }
     s->last_gop_len = len_of(gops - 1);
     if (int e = ensure_lanes(s, gops)) return e;
+    if (int e = ensure_flow(s)) return e;
     SymLayout sl(s->w, s->h);
     const int steps = glen[0];
     // ---- slices that exchange rows: what the neighbours need to know about this band's buffers, then everybody's (csrc/slice_group.h)
@@ -1003,7 +1031,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
         if (t == 0) {
             HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
             for (int g = 0; g < B; g++) HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
-            STAGE(0, B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B, s->tiles.cols, s->tiles.rows, s->cfg.pre_search ? s->ev_args : nullptr));
+            STAGE(0, B, launch_intra_picture<T>(s->st_compute, dv.intra, s->ctus_w, s->ctus_h, B, s->tiles.cols, s->tiles.rows, s->cfg.pre_search ? s->ev_args : nullptr, next_flow(s)));
             if (s->cfg.pre_search) {       // the chunk's search centres: beside the anti-diagonal chain, not beside k_intra_plan (both want the ALUs)
                 HIPCK(s, hipStreamWaitEvent(s->st_pre, s->ev_args, 0));
                 HIPCK(s, launch_pre_search_chunk<T>(s->st_pre, (const PreArgs<T> *)(da + flat_off), s->w, s->h, s->n_ctu, n_pre));
@@ -1106,7 +1134,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
                         HIPCK(s, hipMemsetAsync(s->lane[g].sym_dev[0] + sl.sse, 0, 4 * sizeof(unsigned long long), s->st_compute));
                     }
                     HIPCK(s, hipMemcpyAsync(da + (size_t)t * lay.total, ha + (size_t)t * lay.total, lay.total, hipMemcpyHostToDevice, s->st_compute));
-                    STAGE(0, (int)redo.size(), launch_intra_picture<T>(s->st_compute, dv.intra + B, s->ctus_w, s->ctus_h, (int)redo.size(), s->tiles.cols, s->tiles.rows, nullptr));
+                    STAGE(0, (int)redo.size(), launch_intra_picture<T>(s->st_compute, dv.intra + B, s->ctus_w, s->ctus_h, (int)redo.size(), s->tiles.cols, s->tiles.rows, nullptr, next_flow(s)));
                     HIPCK(s, hipStreamSynchronize(s->st_compute));
                     std::vector<double> v(redo.size(), 0.0);
                     for (size_t k = 0; k < redo.size(); k++) {
@@ -1251,6 +1279,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
     HIPCK(s, hipStreamSynchronize(s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_copy));
     HIPCK(s, hipStreamSynchronize(s->st_pre));        // a chunk without P steps never waited for its pre-search: its buffers are reused by the next chunk
+    if (s->d_flow) {      // a dataflow wait that gave up (a bug: the pictures are garbage, never hand them out)
+        int bad = 0;
+        HIPCK(s, hipMemcpy(&bad, (uint8_t *)s->d_flow + s->flow_bytes - sizeof(int), sizeof bad, hipMemcpyDeviceToHost));
+        if (bad) { s->failed = true; s->err = "k_intra_flow: a CTU waited for a neighbour that never finished"; return MIHEVC_EDEVICE; }
+    }
     float ms = 0;
     (void)hipEventElapsedTime(&ms, t_begin, t_end);
     s->stats.device_ms += ms;
@@ -1613,6 +1646,7 @@ void mihevc_close(mihevc_session *s)
     bc.release(s->device, s->low_cap, false, s->d_low);
     bc.release(s->device, s->jobs_cap, false, s->d_jobs); bc.release(s->device, s->jobs_cap, true, s->h_jobs);
     bc.release(s->device, s->probe_cap, false, s->d_probe);
+    bc.release(s->device, s->flow_bytes, false, s->d_flow);
     for (int k = 0; k < 2; k++) {
         bc.release(s->device, s->x1_bytes, false, s->x1_export[k]);
         if (s->ev_x1[k]) (void)hipEventDestroy(s->ev_x1[k]);
