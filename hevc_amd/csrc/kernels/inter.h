@@ -297,9 +297,16 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
         // earlier raster position, as the 64-bit (cost << 16) | position key ranks them -- and only the winner is widened and goes to the workgroup's
         // LDS minimum (filtered by a plain read first): no per-thread table of 21 running minima stays in registers across the unrolled SAD code,
         // and the 84 candidates of an item cost two VALU operations each instead of six with 64-bit compares
+#ifdef MIHEVC_EXP_DPP_MIN
+        for (int it0 = 0; it0 < quads * spany; it0 += NT) {             // (every lane of a wave takes part in the DPP reduction: lanes without an item redo item 0 and never win)
+            const int item = it0 + tid < quads * spany ? it0 + tid : 0;
+            const int q = item % quads, dyi = item / quads;
+            const unsigned ok = it0 + tid < quads * spany ? s.nodeok[dyi] : 0u, pos0 = (unsigned)(dyi * spanx + 4 * q);
+#else
         for (int item = tid; item < quads * spany; item += NT) {        // item = (quad of 4 dx, one dy)
             const int q = item % quads, dyi = item / quads;
             const unsigned ok = s.nodeok[dyi], pos0 = (unsigned)(dyi * spanx + 4 * q);
+#endif
             const int by = mvd_bits(4 * (dyi - R)), ksh = 6 + msb;
             const uint8_t *srcp = s.src + opaque_zero();      // keep the 1 KiB source tile in LDS (hoisted into 256 VGPRs otherwise)
             unsigned bitsj[4], s32[4] = {0, 0, 0, 0};
@@ -309,9 +316,31 @@ DEV void me_search_program(Ex &ex, MeShared<T> &s, uint8_t *win, const InterArgs
                 unsigned k = (sad[0] << ksh) + bitsj[0];
 #pragma unroll
                 for (int j = 1; j < 4; j++) { const unsigned kj = (sad[j] << ksh) + bitsj[j]; k = kj < k ? kj : k; }
+#ifdef MIHEVC_EXP_DPP_MIN
+                // A/B of round 3: the wave's minimum by DPP (row_shr 1, 2, 4, 8, row_bcast 15 / 31: lane 63 ends with it), ONE LDS atomic per wave
+                // and node instead of the filtered per-lane atomic below (build device.hip with -DMIHEVC_EXP_DPP_MIN; parity-green).  Measured on one box, two runs each
+                // (profiles/r03/README.md): integer search 0.0386 -> 0.0400 ms per 1080p picture (+3.5 %): the 12 DPP moves + 6 64-bit compare / selects per node
+                // are 21 x ~40 VALU operations a lane against ~4 for "read, compare, rarely an atomic", in a kernel that is VALU-bound.  The LDS form stays.
+                unsigned long long key = ((ok >> node) & 1) ? (((unsigned long long)(k >> 2) << 16) | (pos0 + (k & 3))) : ~0ull;
+                auto step = [&](auto ctrl, auto row_mask) {
+                    const unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+                    const unsigned tl = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+                    const unsigned th = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false);
+                    const unsigned long long t = ((unsigned long long)th << 32) | tl;
+                    key = t < key ? t : key;
+                };
+                step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+                step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+                step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+                step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+                step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+                step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+                if ((tid & 63) == 63 && key < ex.peek(&s.best[node])) ex.atomic_min(&s.best[node], key);
+#else
                 if (!((ok >> node) & 1)) return;
                 const unsigned long long key = ((unsigned long long)(k >> 2) << 16) | (pos0 + (k & 3));
                 if (key < ex.peek(&s.best[node])) ex.atomic_min(&s.best[node], key);
+#endif
             };
 #pragma unroll
             for (int half = 0; half < 2; half++) {
