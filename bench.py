@@ -570,8 +570,30 @@ def main():
             for _ in range(n_p):
                 step(host=True, frames=pinned, use_async=True)
             out["value_pcie_inclusive_pinned"] = round(n_p * N / (time.perf_counter() - t1), 2)
+            # ... and as a batch runs it (hevc_amd/batch.py: two sessions per device): two host threads, each feeding its own session clip after clip from the pinned
+            # planes — one session's uploads (DMA) run under the other's kernels.  A single session cannot hide them: its four GOP lanes step together, so the first
+            # step needs frame 225 of 300 on the device.  Whole-device throughput, frames of both sessions / wall time.
+            import threading
+            reps, errs = max(2, n_p), []
+
+            def feed():
+                try:
+                    for _ in range(reps):
+                        step(host=True, frames=pinned, use_async=True)
+                except Exception as e:       # noqa: BLE001 -- reported below
+                    errs.append(repr(e))
+            step(host=True, frames=pinned, use_async=True)
+            th = [threading.Thread(target=feed) for _ in range(2)]
+            t1 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            out["value_pcie_inclusive_pinned_two_sessions"] = None if errs else round(2 * reps * N / (time.perf_counter() - t1), 2)
             out["pcie_inclusive_note"] = ("value_pcie_inclusive: mihevc_send_frame (synchronous copy per frame, pageable planes); value_pcie_inclusive_pinned: "
-                                          "mihevc_send_frame_async from page-locked planes (uploads run as DMA beside the caller, the chunk waits for the last one)")
+                                          "mihevc_send_frame_async from page-locked planes (uploads run as DMA beside the caller, the chunk waits for the last one); "
+                                          "value_pcie_inclusive_pinned_two_sessions: the same from two host threads with a session each (a batch's two workers per device): "
+                                          "one session's uploads run under the other's kernels")
             del pinned
             out["configs"] = {"1080p30_sdr_8bit": {"fps_hbm_resident": round(fps / world, 2), "fps_pcie_inclusive": out["value_pcie_inclusive"],
                                                     "fps_pcie_inclusive_pinned": out["value_pcie_inclusive_pinned"], "bitrate_kbps": out["quality"]["bitrate_kbps"], "psnr_y_db": out["quality"]["psnr_y_db"]}}
