@@ -66,6 +66,9 @@ def load() -> C.CDLL:
         return _lib
     if not LIB_PATH.exists():
         raise OSError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950)")
+    # several sessions in one process (threads of a batch, SlicedEncoder's bands) are 3 HIP streams each; by default the runtime maps all of a process's streams onto 4
+    # hardware queues, and streams sharing one serialise (one session's uploads then wait behind the other's kernels: DESIGN.md §5).  Only read when the HIP runtime starts.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(str(LIB_PATH))
     for name in EXPORTS:
         getattr(lib, name)          # AttributeError if the ABI is incomplete
