@@ -173,7 +173,8 @@ template <typename T> __global__ __launch_bounds__(256) void k_deblock(const Deb
     deblock_segment<T>(args[blockIdx.y], blockIdx.x * 256 + threadIdx.x);
 }
 
-template <typename T> __global__ __launch_bounds__(NT, 4) void k_sao_decide(const SaoArgs<T> *args, int n_ctu)
+// 8 workgroups per CU = every wave slot (49 / 55 VGPRs, 17 / 21 KB of LDS at 8 / 10 bit: the 10-bit form fits 7)
+template <typename T> __global__ __launch_bounds__(NT, (sizeof(T) == 1 ? 8 : 7)) void k_sao_decide(const SaoArgs<T> *args, int n_ctu)
 {
     __shared__ SaoShared<T> s;
     const int ctu = xcd_remap(blockIdx.x, n_ctu);
