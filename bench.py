@@ -610,7 +610,37 @@ def main():
             for t in th:
                 t.join()
             out["value_two_sessions"] = None if errs2 else round(2 * reps * N / (time.perf_counter() - t1), 2)
-            out["pcie_inclusive_note"] = ("value_two_sessions: frames in HBM, two host threads with a session each (not the headline: `value` is one clip at a time); "
+            # ONE clip, its two halves (whole GOPs each) coded by two sessions at once and joined: closed GOPs are independent, the IDR pictures sit where one session puts them
+            errs3, half = [], ((N + gop - 1) // gop + 1) // 2 * (-(-N // ((N + gop - 1) // gop)))
+
+            def code_half(a, b):
+                try:
+                    sub_info, sub_cfg, _ = operating_point(W, H, b - a, False)
+                    sub_cfg.me_range, sub_cfg.host_threads = args.me_range, args.host_threads
+                    with Encoder(sub_cfg, device=local) as enc:
+                        for i in range(a, b):
+                            enc.send_device(ys[i].data_ptr(), us[i].data_ptr(), vs[i].data_ptr(), W, W // 2, pts=i)
+                            for _pk in enc.packets():
+                                pass
+                        enc.flush()
+                        for _pk in enc.packets():
+                            pass
+                except Exception as e:       # noqa: BLE001
+                    errs3.append(repr(e))
+            best = None
+            if 0 < half < N:
+                for _ in range(1 + reps):
+                    th = [threading.Thread(target=code_half, args=(0, half)), threading.Thread(target=code_half, args=(half, N))]
+                    t1 = time.perf_counter()
+                    for t in th:
+                        t.start()
+                    for t in th:
+                        t.join()
+                    dt1 = time.perf_counter() - t1
+                    best = dt1 if best is None else min(best, dt1)
+            out["value_one_clip_two_sessions"] = None if errs3 or best is None else round(N / best, 2)
+            out["pcie_inclusive_note"] = ("value_one_clip_two_sessions: frames in HBM, the clip's two halves (whole GOPs) coded by two sessions at once (best of the repeats; tests/measure_split.py); "
+                                          "value_two_sessions: frames in HBM, two host threads with a session each, clip after clip (not the headline: `value` is one clip, one session); "
                                           "value_pcie_inclusive: mihevc_send_frame (synchronous copy per frame, pageable planes); value_pcie_inclusive_pinned: "
                                           "mihevc_send_frame_async from page-locked planes (uploads run as DMA beside the caller, the chunk waits for the last one); "
                                           "value_pcie_inclusive_pinned_two_sessions: the same from two host threads with a session each (a batch's two workers per device): "

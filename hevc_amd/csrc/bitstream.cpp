@@ -278,6 +278,7 @@ TileGrid p_tile_grid(const mihevc_config &cfg)
     CodedSize cs = coded_size(cfg.width, cfg.height);
     g.wc = (cs.w + kCtu - 1) >> kCtuLog2; g.hc = (cs.h + kCtu - 1) >> kCtuLog2;
     if (cfg.p_tiles == 0 || sliced(cfg)) return g;        // the slices of a sliced picture already are one job each
+    if (cs.w < 256 || cs.h < 64) return g;                // A.4.1 bounds EVERY tile once tiles are on — a single column too: small pictures stay untiled
     int max_cols, max_rows;
     level_tile_limits(cfg.level_idc, max_cols, max_rows);
     const int floor_ = cfg.p_tiles > 0 ? 2 : 1;

@@ -57,6 +57,8 @@ def one_case(rng, it):
         for name in ("intra_nxn", "intra_in_p", "chroma_modes", "rdo_zero", "pre_search", "intra_tiles", "sao", "aud", "hrd", "repeat_headers", "gop_balance", "scenecut"):
             setattr(cfg, name, int(rng.random() < 0.5))
         cfg.rdo_cg = int(rng.choice([0, 2, 5, 8]))
+        cfg.bframes = int(rng.choice([0, 0, 1, -1]))          # round 3: B pictures (fixed / decided by the probe), P pictures as tiles (forced: at least 2 x 2 where the level allows)
+        cfg.p_tiles = int(rng.choice([-1, 0, 1]))
         if rng.random() < 0.5:
             cfg.qp = int(rng.integers(10, 45))
         else:
@@ -70,7 +72,7 @@ def one_case(rng, it):
             frames.append((f.y[:h, :w].copy(), f.u[:h // 2, :w // 2].copy(), f.v[:h // 2, :w // 2].copy()))
         dev_path, extra_y, extra_c = bool(rng.random() < 0.3) and torch is not None, int(rng.integers(0, 9)), int(rng.integers(0, 5))
         desc = f"#{it} {'dev ' if dev_path else ''}{w}x{h} bd{bd} keyint{keyint} lanes{lanes} n{n} qp{cfg.qp} crf{cfg.crf} vbv{cfg.vbv_maxrate_kbps} R{cfg.me_range} lvl{cfg.level_idc} " \
-               f"nxn{cfg.intra_nxn} ip{cfg.intra_in_p} cm{cfg.chroma_modes} rz{cfg.rdo_zero} cg{cfg.rdo_cg} ps{cfg.pre_search} tiles{cfg.intra_tiles} sao{cfg.sao} aud{cfg.aud} hrd{cfg.hrd}"
+               f"nxn{cfg.intra_nxn} ip{cfg.intra_in_p} cm{cfg.chroma_modes} rz{cfg.rdo_zero} cg{cfg.rdo_cg} ps{cfg.pre_search} tiles{cfg.intra_tiles} sao{cfg.sao} aud{cfg.aud} hrd{cfg.hrd} b{cfg.bframes} pt{cfg.p_tiles}"
         only = os.environ.get("FUZZ_ONLY")               # "23,27": run just these cases (the generator still draws every case)
         if only and it not in [int(x) for x in only.split(",")]:
             return desc, True

@@ -22,7 +22,7 @@ EMU_WAVES=7 EMU_LIB=$tmp/libemu_tsan.so LD_PRELOAD=$gccdir/libtsan.so TSAN_OPTIO
 grep -E "^ok|SUMMARY: ThreadSanitizer" $tmp/2.log | cut -c1-160 | sort | uniq -c
 grep -q "WARNING: ThreadSanitizer" $tmp/2.log && fail=1
 echo "== 3. oracle + decoder + host coder, ASAN + UBSAN"
-gcc -O1 -g -fPIC -shared -fsanitize=address,undefined -o $tmp/liboracle.so oracle/hevc_oracle.c oracle/hevc_dec.c -lm 2>/dev/null
+gcc -O1 -g -fPIC -shared -fsanitize=address,undefined -o $tmp/liboracle.so oracle/hevc_oracle.c oracle/hevc_dec.c oracle/hevc_dec_recon.c -lm
 python3 - "$tmp" <<'PY'
 import subprocess, sys
 sys.path.insert(0, '.')
@@ -45,7 +45,7 @@ sys.path.insert(0, '$root')
 import oracle.oracle as O
 O.build = lambda force=False: Path('$tmp/liboracle.so')
 import pytest
-sys.exit(int(pytest.main(['$root/tests/test_oracle_kat.py', '$root/tests/test_bitstream_cpu.py', '$root/tests/test_sliced_cpu.py', '-x', '-q', '-p', 'no:cacheprovider'])))
+sys.exit(int(pytest.main(['$root/tests/test_oracle_kat.py', '$root/tests/test_bitstream_cpu.py', '$root/tests/test_sliced_cpu.py', '$root/tests/test_decoder_second_opinion.py', '-x', '-q', '-p', 'no:cacheprovider'])))
 PY
 MIHEVC_LIBRARY=$tmp/libmihevc_host_asan.so LD_PRELOAD=$asan ASAN_OPTIONS=detect_leaks=0 python3 $tmp/run3.py > $tmp/3.log 2>&1 || fail=1
 tail -2 $tmp/3.log

@@ -320,6 +320,11 @@ def test_default_p_tile_grid_is_one_tile_per_1080p_area():
         assert _lib.p_tile_grid(make_cfg(w, h, level_idc=level)) == want, (w, h)
     sl = make_cfg(7680, 544, 10, level_idc=180, pic_height=4320, slice_count=8, slice_index=0)
     assert _lib.p_tile_grid(sl) == (1, 1)              # a sliced picture's slices already are one host job each
+    # A.4.1 bounds every tile once tiles are on, a single column or row too: pictures narrower than 256 or lower than 64 luma samples stay untiled even when
+    # cfg.p_tiles asks for tiles (found by tests/fuzz_sessions.py in round 3: 146x126 with p_tiles = 1 came out as 1 x 2 tiles with a 146-sample column)
+    for w, h in [(146, 126), (128, 216), (502, 24), (248, 512)]:
+        assert _lib.p_tile_grid(make_cfg(w, h, level_idc=150, p_tiles=1)) == (1, 1), (w, h)
+    assert _lib.p_tile_grid(make_cfg(256, 128, level_idc=150, p_tiles=1)) == (1, 2)
 
 
 def coding_order(n):
