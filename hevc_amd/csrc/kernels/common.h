@@ -198,6 +198,38 @@ DEV uint32_t sad_row8(const uint16_t *a, const uint16_t *b, uint32_t acc)
     return acc;
 }
 
+// v_perm_b32: byte i of the result is byte (sel >> 8i) & 7 of the eight bytes {a (4 .. 7), b (0 .. 3)}
+DEV uint32_t perm_bytes(uint32_t a, uint32_t b, uint32_t sel)
+{
+#if MIHEVC_GPU
+    return __builtin_amdgcn_perm(a, b, sel);
+#else
+    const uint64_t ab = ((uint64_t)a << 32) | b;
+    uint32_t r = 0;
+    for (int i = 0; i < 4; i++) r |= (uint32_t)((ab >> (8 * ((sel >> (8 * i)) & 7))) & 255u) << (8 * i);
+    return r;
+#endif
+}
+// 4 x 4 bytes transposed: r[k] = four bytes of row k -> c[i] = byte i of rows 0 .. 3
+DEV void transpose_bytes4(const uint32_t (&r)[4], uint32_t (&c)[4])
+{
+    const uint32_t t0 = perm_bytes(r[1], r[0], 0x05010400u), t1 = perm_bytes(r[1], r[0], 0x07030602u);
+    const uint32_t t2 = perm_bytes(r[3], r[2], 0x05010400u), t3 = perm_bytes(r[3], r[2], 0x07030602u);
+    c[0] = perm_bytes(t2, t0, 0x05040100u); c[1] = perm_bytes(t2, t0, 0x07060302u);
+    c[2] = perm_bytes(t3, t1, 0x05040100u); c[3] = perm_bytes(t3, t1, 0x07060302u);
+}
+
+// true when the predicate holds in every ACTIVE lane of the wave: lets a function pick a cheaper, value-identical path without diverging (a wave executes both sides of a branch its
+// lanes disagree on).  Stepped on the CPU a lane stands alone; the paths give the same values, so any choice is right there.
+DEV bool wave_all(bool p)
+{
+#if MIHEVC_GPU
+    return __all(p) != 0;
+#else
+    return p;
+#endif
+}
+
 // v_qsad_pk_u16_u8: four SADs of 4 packed bytes `cur` against the 4-byte windows of `ref8` at byte offsets 0..3,
 // each accumulated into its own 16-bit field of `acc` (the instruction motion estimation was given on GCN/CDNA)
 DEV uint64_t qsad_u8(uint64_t ref8, uint32_t cur, uint64_t acc)

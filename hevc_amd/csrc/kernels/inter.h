@@ -47,6 +47,9 @@ template <typename T> DEV InterArgs<T> list1_view(const InterArgs<T> &a)
 
 // candidate 0 = centre, 1..8 = the ring (same order as oracle kFracOff)
 DEVCONST int8_t kOff[9][2] = {{0, 0}, {-1, -1}, {0, -1}, {1, -1}, {-1, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+// which ring position the lanes of slot (lane >> 5) work on: a wave holds two slots, and the order gives wave 0 the two positions with no vertical fraction, wave 1 the two with no
+// horizontal one (luma_half_diff's one-pass forms then run without divergence); positions keep their numbers, so nothing about the result changes
+DEVCONST int8_t kRingSlot[8] = {4, 5, 2, 7, 1, 3, 6, 8};
 
 // ------------------------------------------------------------------------------------------ search centres (pre-search)
 // 1/4-size 8-bit pictures (rounded mean of every 4x4 luma block, reduced to 8 bits) of the source and of the reference; every
@@ -591,6 +594,57 @@ DEV int luma_tile(const uint16_t *win, int i00, int ws, int fx, int fy, int bit_
 DEV void luma_half_diff(const uint8_t *win, int i00, int ws, int fx, int fy, int, const uint8_t *src, int src_stride, int (&m)[8][4])
 {
     const uint32_t tlo = load_u32(&g_tab.luma_tap[fx][0]), thi = load_u32(&g_tab.luma_tap[fx][4]);
+    // A zero fraction makes that direction's 8-tap filter the identity tap {0, 0, 0, 64, 0, 0, 0, 0}, and the general form below then multiplies by 64 and shifts by 6 again:
+    // the same values come out of one filter pass.  Worth a branch only when the whole wave takes it (inter_ctu_program orders the ring so that a wave's two candidates
+    // share their zero fraction: half of the first ring's waves, and the second ring's wherever the vectors stayed on whole samples).
+    if (wave_all(fy == 0)) {          // horizontal filter only: rows 0 .. 7 of the block, no vertical pass
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int idx = i00 + j * ws - 3, off = idx & 3;
+            const uint8_t *p = win + (idx - off);
+            uint32_t d[4], q[3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) d[k] = load_u32_aligned(p + 4 * k);
+#pragma unroll
+            for (int k = 0; k < 3; k++) q[k] = align_bytes(d[k + 1], d[k], off) ^ 0x80808080u;
+            int hv[4];
+            hv[0] = dot4_i8(q[0], tlo, dot4_i8(q[1], thi, 128 * 64));
+#pragma unroll
+            for (int i = 1; i < 4; i++) hv[i] = dot4_i8(align_bytes(q[1], q[0], i), tlo, dot4_i8(align_bytes(q[2], q[1], i), thi, 128 * 64));
+            const uint32_t w = load_u32_aligned(src + j * src_stride);
+#pragma unroll
+            for (int i = 0; i < 4; i++) m[j][i] = (int)((w >> (8 * i)) & 255) - clip3(0, 255, (hv[i] + 32) >> 6);      // ((64 hv >> 6) + 32) >> 6
+        }
+        return;
+    }
+    if (wave_all(fx == 0)) {          // vertical filter only: the block's own 4 columns of rows -3 .. 11, no horizontal pass
+        const uint32_t vlo = load_u32(&g_tab.luma_tap[fy][0]), vhi = load_u32(&g_tab.luma_tap[fy][4]);
+        const int idx = i00 - 3 * ws, off = idx & 3;
+        uint32_t rows[15];           // four samples of every row, as signed bytes
+#pragma unroll
+        for (int r = 0; r < 15; r++) {
+            const uint8_t *p = win + (idx - off) + r * ws;
+            rows[r] = align_bytes(load_u32_aligned(p + 4), load_u32_aligned(p), off) ^ 0x80808080u;
+        }
+        uint32_t col[4][4];          // [rows 4g .. 4g + 3][column]: the rows' bytes transposed (row 15 does not exist: zero)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const uint32_t r4[4] = {rows[4 * g], rows[4 * g + 1], rows[4 * g + 2], g < 3 ? rows[4 * g + 3] : 0u};
+            transpose_bytes4(r4, col[g]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int g = j >> 2, sh = j & 3;
+            const uint32_t w = load_u32_aligned(src + j * src_stride);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {       // output row j of column i: rows j .. j + 7 against the taps
+                const uint32_t lo = align_bytes(col[g + 1][i], col[g][i], sh), hi = align_bytes(col[g + 2][i], col[g + 1][i], sh);
+                const int v = dot4_i8(lo, vlo, dot4_i8(hi, vhi, 128 * 64));      // sum of tap x sample: what (64 x sample, filtered) >> 6 is
+                m[j][i] = (int)((w >> (8 * i)) & 255) - clip3(0, 255, (v + 32) >> 6);
+            }
+        }
+        return;
+    }
     uint32_t typ[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) typ[k] = pack_lo16(g_tab.luma_tap[fy][2 * k], g_tab.luma_tap[fy][2 * k + 1]);
@@ -917,7 +971,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         const int step = round == 0 ? 2 : 1;
         // 16 tiles x 8 ring positions x 2 column halves = the whole workgroup.  Wave-local steps: both lanes of a pair sit in one wave.
         ex.wave_step([&](int tid) {
-            const int u = tid >> 1, half = tid & 1, k = 1 + (u >> 4), t = u & 15;
+            const int u = tid >> 1, half = tid & 1, k = kRingSlot[u >> 4], t = u & 15;
             if (!s.rs.tu_log2[t]) return;
             const int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
             const int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
@@ -956,7 +1010,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.rs.scratch[4096 + tid] = sum;
         });
         ex.phase([&](int tid) {
-            const int u = tid >> 1, k = 1 + (u >> 4), t = u & 15;
+            const int u = tid >> 1, k = kRingSlot[u >> 4], t = u & 15;
             if ((tid & 1) || !s.rs.tu_log2[t]) return;
             const unsigned satd = (s.rs.scratch[4096 + tid] + s.rs.scratch[4096 + tid + 1] + 2) >> 2;
             ex.atomic_add(&s.fsum[k - 1][s.tile_node[t]], satd);      // the CU's candidate sum, one LDS atomic per tile
