@@ -198,6 +198,36 @@ DEV uint32_t sad_row8(const uint16_t *a, const uint16_t *b, uint32_t acc)
     return acc;
 }
 
+// two 16-bit lanes per dword (VOP3P v_pk_add_u16 / v_pk_sub_i16 / v_pk_max_i16): the callers keep every value inside 16 bits
+DEV uint32_t pk_add16(uint32_t a, uint32_t b)
+{
+#if MIHEVC_GPU
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (v2s)(__builtin_bit_cast(v2s, a) + __builtin_bit_cast(v2s, b)));
+#else
+    return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
+#endif
+}
+DEV uint32_t pk_sub16(uint32_t a, uint32_t b)
+{
+#if MIHEVC_GPU
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, (v2s)(__builtin_bit_cast(v2s, a) - __builtin_bit_cast(v2s, b)));
+#else
+    return ((a - b) & 0xffffu) | (((a >> 16) - (b >> 16)) << 16);
+#endif
+}
+DEV uint32_t pk_max_i16(uint32_t a, uint32_t b)
+{
+#if MIHEVC_GPU
+    typedef short v2s __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b)));
+#else
+    const int al = (int16_t)(a & 0xffffu), ah = (int16_t)(a >> 16), bl = (int16_t)(b & 0xffffu), bh = (int16_t)(b >> 16);
+    return (uint32_t)((al > bl ? al : bl) & 0xffff) | ((uint32_t)((ah > bh ? ah : bh) & 0xffff) << 16);
+#endif
+}
+
 // v_perm_b32: byte i of the result is byte (sel >> 8i) & 7 of the eight bytes {a (4 .. 7), b (0 .. 3)}
 DEV uint32_t perm_bytes(uint32_t a, uint32_t b, uint32_t sel)
 {

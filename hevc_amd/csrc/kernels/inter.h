@@ -978,6 +978,31 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             const int px = x0 + txp * 8 + 4 * half + (mx >> 2) - wox, py = y0 + typ * 8 + (my >> 2) - woy;
             int m[8][4];
             luma_half_diff((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8 + 4 * half), 32, m);
+            if constexpr (sizeof(T) == 1) {
+                // 8 bit: differences are 9 bits, the 8x8 Hadamard transform grows them by 6: everything fits 16 bits, two values a dword (v_pk_add / sub_i16).  Rows 2r and
+                // 2r + 1 of a column share a dword: the butterflies between rows 2 and 4 apart and between columns 1 and 2 apart are whole-dword operations (4 stages x 16
+                // packed operations; the one-value form took 160), the stage across the halves follows the exchange, and the stage INSIDE a dword is never computed:
+                // it is the last one, and |a + b| + |a - b| = 2 max(|a|, |b|).
+                uint32_t P[4][4];
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) P[r2][c] = perm_bytes((uint32_t)m[2 * r2 + 1][c], (uint32_t)m[2 * r2][c], 0x05040100u);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t a0 = pk_add16(P[0][c], P[1][c]), a1 = pk_sub16(P[0][c], P[1][c]), a2 = pk_add16(P[2][c], P[3][c]), a3 = pk_sub16(P[2][c], P[3][c]);
+                    P[0][c] = pk_add16(a0, a2); P[1][c] = pk_add16(a1, a3); P[2][c] = pk_sub16(a0, a2); P[3][c] = pk_sub16(a1, a3);
+                }
+                uint32_t *x = s.rs.scratch + tid * 16;
+                const int sw = tid >> 2;
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    const uint32_t p0 = pk_add16(P[r2][0], P[r2][1]), p1 = pk_sub16(P[r2][0], P[r2][1]), p2 = pk_add16(P[r2][2], P[r2][3]), p3 = pk_sub16(P[r2][2], P[r2][3]);
+                    const uint32_t o[4] = {pk_add16(p0, p2), pk_add16(p1, p3), pk_sub16(p0, p2), pk_sub16(p1, p3)};
+                    store_x4(x + 4 * ((r2 + sw) & 3), o);        // chunk r2 = rows 2 r2, 2 r2 + 1 of the four columns; rotated as below
+                }
+                return;
+            }
             hadamard_half(m);
             // |values| <= 32 x the sample range: they fit 16 bits.  A lane's block is 16 dwords = four 16-byte chunks; chunk c goes to place (c + (lane >> 2)) & 3
             // of the block: with the plain order lanes i and i + 4 hit the same banks in every 128-bit store and load (16 dwords x 4 = all 64 banks: a
@@ -996,6 +1021,28 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16, *xb = xa + 16;      // the pair's two blocks (both lanes of a pair share lane >> 2)
             const int sw = tid >> 2;
             unsigned sum = 0;
+            if constexpr (sizeof(T) == 1) {
+                // packed form: the stage across the halves on whole dwords, then 2 max(|lo|, |hi|) per dword for the stage inside it + the absolute sum.  |values| <= 255 x 32
+                // here, so eight maxima still fit the 16-bit lanes of an accumulator
+                uint32_t acc[2] = {0, 0};
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    uint32_t va[4], vb[4];
+                    const int at = 4 * ((2 * half + c + sw) & 3);
+                    load_x4(xa + at, va); load_x4(xb + at, vb);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+#pragma unroll
+                        for (int sgn = 0; sgn < 2; sgn++) {
+                            const uint32_t v = sgn ? pk_sub16(va[i], vb[i]) : pk_add16(va[i], vb[i]);
+                            const uint32_t av = pk_max_i16(v, pk_sub16(0u, v));                  // |lo|, |hi|
+                            acc[c] = pk_add16(acc[c], pk_max_i16(av, (av >> 16) | (av << 16)));    // both lanes: max(|lo|, |hi|)
+                        }
+                    }
+                }
+                s.rs.scratch[4096 + tid] = 2u * ((acc[0] & 0xffffu) + (acc[1] & 0xffffu));
+                return;
+            }
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 uint32_t va[4], vb[4];
