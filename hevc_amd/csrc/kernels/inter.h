@@ -392,6 +392,7 @@ template <typename T> struct InterShared {
     int satd[3][1][16];          // [level][0][tile]: tile SATDs at the integer vectors
     unsigned nsum[21];           // per node: sum of its tiles' integer-vector SATDs
     unsigned fsum[8][21];        // per ring candidate and chosen node: sum of its tiles' SATDs (LDS atomics from the tile lanes)
+    unsigned long long rbest[21];     // per chosen node: min over the ring of (cost << 4 | position), position 0 = the centre
     unsigned j16[4];
     int use16[4], use32;
     uint8_t alias[3][16];        // level whose SATDs stand for (level, tile): a coarser node with the SAME vector as a finer one is not recomputed
@@ -1058,28 +1059,31 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         });
         ex.phase([&](int tid) {
             const int u = tid >> 1, k = kRingSlot[u >> 4], t = u & 15;
+            if (tid >= 1 && tid < 43 && (tid & 1)) s.rbest[tid >> 1] = (unsigned long long)s.cost[tid >> 1] << 4;      // the centre: candidate 0 of every node (odd lanes are free here)
             if ((tid & 1) || !s.rs.tu_log2[t]) return;
             const unsigned satd = (s.rs.scratch[4096 + tid] + s.rs.scratch[4096 + tid + 1] + 2) >> 2;
             ex.atomic_add(&s.fsum[k - 1][s.tile_node[t]], satd);      // the CU's candidate sum, one LDS atomic per tile
         });
+        // one lane per (CU, ring position) prices its candidate and bids with an LDS minimum (cost, then position: the order a walk over the positions finds); 21 lanes
+        // walking 8 positions each was a serial stretch of wave 0 with the other three waves idle at the barrier
+        ex.phase([&](int tid) {
+            const int node = tid >> 3, k = 1 + (tid & 7);
+            if (node >= 21 || !s.valid[node] || !s.chosen[node]) return;
+            const unsigned satd = s.fsum[k - 1][node];
+            s.fsum[k - 1][node] = 0;                                      // ready for the next round
+            const int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
+            if (mct || mcb) {                    // a slice: candidates whose filter taps would reach across its edge are out
+                int nx, ny, nl;
+                node_geom(node, nx, ny, nl);
+                if (!mv_rows_ok(y0 + ny, 1 << nl, my, a.h, mct, mcb)) return;
+            }
+            const unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * csx) + mvd_bits(my - 4 * csy)));
+            ex.atomic_min(&s.rbest[node], ((unsigned long long)c << 4) | (unsigned)k);
+        });
         ex.phase([&](int tid) {
             if (tid >= 21 || !s.valid[tid] || !s.chosen[tid]) return;
-            unsigned long long best = (unsigned long long)s.cost[tid] << 4;
-#pragma unroll
-            for (int k = 1; k < 9; k++) {
-                const unsigned satd = s.fsum[k - 1][tid];
-                s.fsum[k - 1][tid] = 0;                                   // ready for the next round
-                int mx = s.mvx[tid] + kOff[k][0] * step, my = s.mvy[tid] + kOff[k][1] * step;
-                if (mct || mcb) {                    // a slice: candidates whose filter taps would reach across its edge are out
-                    int nx, ny, nl;
-                    node_geom(tid, nx, ny, nl);
-                    if (!mv_rows_ok(y0 + ny, 1 << nl, my, a.h, mct, mcb)) continue;
-                }
-                unsigned c = (satd << 4) + (unsigned)(lam * (mvd_bits(mx - 4 * csx) + mvd_bits(my - 4 * csy)));
-                unsigned long long key = ((unsigned long long)c << 4) | (unsigned)k;
-                if (key < best) best = key;
-            }
-            int k = (int)(best & 15);
+            const unsigned long long best = s.rbest[tid];
+            const int k = (int)(best & 15);
             s.mvx[tid] += kOff[k][0] * step; s.mvy[tid] += kOff[k][1] * step;
             s.cost[tid] = (unsigned)(best >> 4);
         });
