@@ -598,17 +598,6 @@ DEV void luma_half_diff(const uint8_t *win, int i00, int ws, int fx, int fy, int
     // A zero fraction makes that direction's 8-tap filter the identity tap {0, 0, 0, 64, 0, 0, 0, 0}, and the general form below then multiplies by 64 and shifts by 6 again:
     // the same values come out of one filter pass.  Worth a branch only when the whole wave takes it (inter_ctu_program orders the ring so that a wave's two candidates
     // share their zero fraction: half of the first ring's waves, and the second ring's wherever the vectors stayed on whole samples).
-    if (wave_all((fx | fy) == 0)) {   // whole samples: the prediction is the window itself
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int idx = i00 + j * ws, off = idx & 3;
-            const uint8_t *p = win + (idx - off);
-            const uint32_t r = align_bytes(load_u32_aligned(p + 4), load_u32_aligned(p), off), w = load_u32_aligned(src + j * src_stride);
-#pragma unroll
-            for (int i = 0; i < 4; i++) m[j][i] = (int)((w >> (8 * i)) & 255) - (int)((r >> (8 * i)) & 255);
-        }
-        return;
-    }
     if (wave_all(fy == 0)) {          // horizontal filter only: rows 0 .. 7 of the block, no vertical pass
 #pragma unroll
         for (int j = 0; j < 8; j++) {
@@ -701,13 +690,6 @@ DEV void luma_half_diff(const uint8_t *win, int i00, int ws, int fx, int fy, int
 }
 DEV void luma_half_diff(const uint16_t *win, int i00, int ws, int fx, int fy, int bit_depth, const uint16_t *src, int src_stride, int (&m)[8][4])
 {
-    if (wave_all((fx | fy) == 0)) {   // whole samples: the prediction is the window itself
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) m[j][i] = (int)src[j * src_stride + i] - (int)win[i00 + j * ws + i];
-        return;
-    }
     uint32_t txp[4], typ[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -924,128 +906,26 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             s.mvx[tid] = m[0]; s.mvy[tid] = m[1]; s.valid[tid] = m[2] >= 0; s.cost[tid] = 0; s.nsum[tid] = 0;
         }
     });
-    // 8x8 Hadamard SATD of (source tile - prediction at a luma vector) on TWO lanes per tile, each owning 4 of its 8 columns (luma_half_diff): wave-local steps, both lanes of
-    // a pair sit in one wave.  unit(u, half, so, i00, fx, fy): is pair u at work, and where — source offset, window element of the half's first whole sample, fractions.  The
-    // pair's sums end in scratch[4096 + 2u] and [4096 + 2u + 1]: SATD = (their sum + 2) >> 2.  The lanes of a pair must agree on `unit`.
-    auto pair_satd = [&](auto &&unit) {
-        ex.wave_step([&](int tid) {
-            int so, i00, fx, fy;
-            if (!unit(tid >> 1, tid & 1, so, i00, fx, fy)) return;
-            int m[8][4];
-            luma_half_diff((const T *)win_y, i00, wys, fx, fy, bd, (const T *)(s.src + so), 32, m);
-            if constexpr (sizeof(T) == 1) {
-                // 8 bit: differences are 9 bits, the 8x8 Hadamard transform grows them by 6: everything fits 16 bits, two values a dword (v_pk_add / sub_i16).  Rows 2r and
-                // 2r + 1 of a column share a dword: the butterflies between rows 2 and 4 apart and between columns 1 and 2 apart are whole-dword operations (4 stages x 16
-                // packed operations; the one-value form took 160), the stage across the halves follows the exchange, and the stage INSIDE a dword is never computed:
-                // it is the last one, and |a + b| + |a - b| = 2 max(|a|, |b|).
-                uint32_t P[4][4];
-#pragma unroll
-                for (int r2 = 0; r2 < 4; r2++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) P[r2][c] = perm_bytes((uint32_t)m[2 * r2 + 1][c], (uint32_t)m[2 * r2][c], 0x05040100u);
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const uint32_t a0 = pk_add16(P[0][c], P[1][c]), a1 = pk_sub16(P[0][c], P[1][c]), a2 = pk_add16(P[2][c], P[3][c]), a3 = pk_sub16(P[2][c], P[3][c]);
-                    P[0][c] = pk_add16(a0, a2); P[1][c] = pk_add16(a1, a3); P[2][c] = pk_sub16(a0, a2); P[3][c] = pk_sub16(a1, a3);
-                }
-                uint32_t *x = s.rs.scratch + tid * 16;
-                const int sw = tid >> 2;
-#pragma unroll
-                for (int r2 = 0; r2 < 4; r2++) {
-                    const uint32_t p0 = pk_add16(P[r2][0], P[r2][1]), p1 = pk_sub16(P[r2][0], P[r2][1]), p2 = pk_add16(P[r2][2], P[r2][3]), p3 = pk_sub16(P[r2][2], P[r2][3]);
-                    const uint32_t o[4] = {pk_add16(p0, p2), pk_add16(p1, p3), pk_sub16(p0, p2), pk_sub16(p1, p3)};
-                    store_x4(x + 4 * ((r2 + sw) & 3), o);        // chunk r2 = rows 2 r2, 2 r2 + 1 of the four columns; rotated as below
-                }
-                return;
-            }
-            hadamard_half(m);
-            // |values| <= 32 x the sample range: they fit 16 bits.  A lane's block is 16 dwords = four 16-byte chunks; chunk c goes to place (c + (lane >> 2)) & 3
-            // of the block: with the plain order lanes i and i + 4 hit the same banks in every 128-bit store and load (16 dwords x 4 = all 64 banks: a
-            // 4-way conflict, 41 % of this kernel's LDS cycles in profiles/r02_d); rotated, any 16 consecutive lanes cover the 64 banks once
-            uint32_t *x = s.rs.scratch + tid * 16;
-            const int sw = tid >> 2;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const uint32_t o[4] = {pack_lo16(m[j][0], m[j][1]), pack_lo16(m[j][2], m[j][3]), pack_lo16(m[j + 1][0], m[j + 1][1]), pack_lo16(m[j + 1][2], m[j + 1][3])};
-                store_x4(x + 4 * (((j >> 1) + sw) & 3), o);
-            }
-        });
-        ex.wave_step([&](int tid) {      // the last butterfly stage across the halves: this lane takes rows 4 half .. 4 half + 3
-            int so, i00, fx, fy;
-            const int half = tid & 1;
-            if (!unit(tid >> 1, half, so, i00, fx, fy)) return;
-            const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16, *xb = xa + 16;      // the pair's two blocks (both lanes of a pair share lane >> 2)
-            const int sw = tid >> 2;
-            unsigned sum = 0;
-            if constexpr (sizeof(T) == 1) {
-                // packed form: the stage across the halves on whole dwords, then 2 max(|lo|, |hi|) per dword for the stage inside it + the absolute sum.  |values| <= 255 x 32
-                // here, so eight maxima still fit the 16-bit lanes of an accumulator
-                uint32_t acc[2] = {0, 0};
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    uint32_t va[4], vb[4];
-                    const int at = 4 * ((2 * half + c + sw) & 3);
-                    load_x4(xa + at, va); load_x4(xb + at, vb);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-#pragma unroll
-                        for (int sgn = 0; sgn < 2; sgn++) {
-                            const uint32_t v = sgn ? pk_sub16(va[i], vb[i]) : pk_add16(va[i], vb[i]);
-                            const uint32_t av = pk_max_i16(v, pk_sub16(0u, v));                  // |lo|, |hi|
-                            acc[c] = pk_add16(acc[c], pk_max_i16(av, (av >> 16) | (av << 16)));    // both lanes: max(|lo|, |hi|)
-                        }
-                    }
-                }
-                s.rs.scratch[4096 + tid] = 2u * ((acc[0] & 0xffffu) + (acc[1] & 0xffffu));
-                return;
-            }
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                uint32_t va[4], vb[4];
-                const int at = 4 * ((2 * half + c + sw) & 3);
-                load_x4(xa + at, va); load_x4(xb + at, vb);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int a0 = (int)(int16_t)(va[i] & 0xffff), a1 = (int)(int16_t)(va[i] >> 16), b0 = (int)(int16_t)(vb[i] & 0xffff), b1 = (int)(int16_t)(vb[i] >> 16);
-                    sum += (unsigned)(iabs(a0 + b0) + iabs(a0 - b0) + iabs(a1 + b1) + iabs(a1 - b1));
-                }
-            }
-            s.rs.scratch[4096 + tid] = sum;
-        });
-    };
     // SATD of every node at its INTEGER vector: the quadtree is decided on these (+ lambda * mvd bits), the fractional search then
     // runs for the chosen CUs only — 16 tiles x 8 ring positions = 128 lanes = two full waves per round, instead of one
     // pass per tree level (the search was 43 % of this kernel: profiles/r01)
-    {
-        // (level, tile) pairs: 48 of them, lanes 0 .. 95 (until round 3 one lane per pair took the whole 8x8 transform: 48 lanes of wave 0 at work, three waves idle).  Identical vectors give identical tile SATDs: the finest level that shares the vector does the work (alias)
-        auto int_unit = [&](int u, int half, int &so, int &i00, int &fx, int &fy) {
-            if (u >= 3 * 16) return false;
-            const int level = u >> 4, t = u & 15, txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
-            if (!s.valid[node]) return false;
-            for (int fl = 2; fl > level; fl--) {
-                const int fn = node_of_tile(fl, txp, typ);
-                if (s.valid[fn] && s.mvx[fn] == s.mvx[node] && s.mvy[fn] == s.mvy[node]) return false;
-            }
-            so = typ * 8 * 32 + txp * 8 + 4 * half;
-            i00 = (y0 + typ * 8 + (s.mvy[node] >> 2) - oy_y) * wys + x0 + txp * 8 + 4 * half + (s.mvx[node] >> 2) - oy_x;
-            fx = fy = 0;
-            return true;
-        };
-        pair_satd(int_unit);
-        ex.phase([&](int tid) {
-            const int u = tid >> 1;
-            if ((tid & 1) || u >= 3 * 16) return;
-            const int level = u >> 4, t = u & 15, txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
-            if (!s.valid[node]) return;
+    ex.phase([&](int tid) {
+        for (int u = tid; u < 3 * 16; u += NT) {
+            int level = u >> 4, t = u & 15;
+            int txp = t & 3, typ = t >> 2, node = node_of_tile(level, txp, typ);
+            if (!s.valid[node]) continue;
+            // identical vectors give identical tile SATDs: let the finest level that shares the vector do the work
             int al = level;
             for (int fl = 2; fl > level; fl--) {
-                const int fn = node_of_tile(fl, txp, typ);
+                int fn = node_of_tile(fl, txp, typ);
                 if (s.valid[fn] && s.mvx[fn] == s.mvx[node] && s.mvy[fn] == s.mvy[node]) { al = fl; break; }
             }
             s.alias[level][t] = (uint8_t)al;
-            if (al == level) s.satd[level][0][t] = (int)((s.rs.scratch[4096 + tid] + s.rs.scratch[4096 + tid + 1] + 2) >> 2);
-        });
-    }
+            if (al != level) continue;
+            int px = x0 + txp * 8 + (s.mvx[node] >> 2) - oy_x, py = y0 + typ * 8 + (s.mvy[node] >> 2) - oy_y;
+            s.satd[level][0][t] = luma_tile_int<T>(win_y, py * wys + px, wys, s.src + typ * 8 * 32 + txp * 8, 32);
+        }
+    });
     // every (level, tile) lane adds its tile's SATD (its own or the finer level's it aliases) to the node's sum
     ex.phase([&](int tid) {
         if (tid < 3 * 16) {
@@ -1090,16 +970,92 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     auto refine = [&](const int csx, const int csy, const int wox, const int woy) {
     for (int round = 0; round < 2; round++) {
         const int step = round == 0 ? 2 : 1;
-        // 16 tiles x 8 ring positions x 2 column halves = the whole workgroup
-        pair_satd([&](int u, int half, int &so, int &i00, int &fx, int &fy) {
-            const int k = kRingSlot[u >> 4], t = u & 15;
-            if (!s.rs.tu_log2[t]) return false;
+        // 16 tiles x 8 ring positions x 2 column halves = the whole workgroup.  Wave-local steps: both lanes of a pair sit in one wave.
+        ex.wave_step([&](int tid) {
+            const int u = tid >> 1, half = tid & 1, k = kRingSlot[u >> 4], t = u & 15;
+            if (!s.rs.tu_log2[t]) return;
             const int txp = t & 3, typ = t >> 2, node = s.tile_node[t];
             const int mx = s.mvx[node] + kOff[k][0] * step, my = s.mvy[node] + kOff[k][1] * step;
-            so = typ * 8 * 32 + txp * 8 + 4 * half;
-            i00 = (y0 + typ * 8 + (my >> 2) - woy) * wys + x0 + txp * 8 + 4 * half + (mx >> 2) - wox;
-            fx = mx & 3; fy = my & 3;
-            return true;
+            const int px = x0 + txp * 8 + 4 * half + (mx >> 2) - wox, py = y0 + typ * 8 + (my >> 2) - woy;
+            int m[8][4];
+            luma_half_diff((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8 + 4 * half), 32, m);
+            if constexpr (sizeof(T) == 1) {
+                // 8 bit: differences are 9 bits, the 8x8 Hadamard transform grows them by 6: everything fits 16 bits, two values a dword (v_pk_add / sub_i16).  Rows 2r and
+                // 2r + 1 of a column share a dword: the butterflies between rows 2 and 4 apart and between columns 1 and 2 apart are whole-dword operations (4 stages x 16
+                // packed operations; the one-value form took 160), the stage across the halves follows the exchange, and the stage INSIDE a dword is never computed:
+                // it is the last one, and |a + b| + |a - b| = 2 max(|a|, |b|).
+                uint32_t P[4][4];
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) P[r2][c] = perm_bytes((uint32_t)m[2 * r2 + 1][c], (uint32_t)m[2 * r2][c], 0x05040100u);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t a0 = pk_add16(P[0][c], P[1][c]), a1 = pk_sub16(P[0][c], P[1][c]), a2 = pk_add16(P[2][c], P[3][c]), a3 = pk_sub16(P[2][c], P[3][c]);
+                    P[0][c] = pk_add16(a0, a2); P[1][c] = pk_add16(a1, a3); P[2][c] = pk_sub16(a0, a2); P[3][c] = pk_sub16(a1, a3);
+                }
+                uint32_t *x = s.rs.scratch + tid * 16;
+                const int sw = tid >> 2;
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    const uint32_t p0 = pk_add16(P[r2][0], P[r2][1]), p1 = pk_sub16(P[r2][0], P[r2][1]), p2 = pk_add16(P[r2][2], P[r2][3]), p3 = pk_sub16(P[r2][2], P[r2][3]);
+                    const uint32_t o[4] = {pk_add16(p0, p2), pk_add16(p1, p3), pk_sub16(p0, p2), pk_sub16(p1, p3)};
+                    store_x4(x + 4 * ((r2 + sw) & 3), o);        // chunk r2 = rows 2 r2, 2 r2 + 1 of the four columns; rotated as below
+                }
+                return;
+            }
+            hadamard_half(m);
+            // |values| <= 32 x the sample range: they fit 16 bits.  A lane's block is 16 dwords = four 16-byte chunks; chunk c goes to place (c + (lane >> 2)) & 3
+            // of the block: with the plain order lanes i and i + 4 hit the same banks in every 128-bit store and load (16 dwords x 4 = all 64 banks: a
+            // 4-way conflict, 41 % of this kernel's LDS cycles in profiles/r02_d); rotated, any 16 consecutive lanes cover the 64 banks once
+            uint32_t *x = s.rs.scratch + tid * 16;
+            const int sw = tid >> 2;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const uint32_t o[4] = {pack_lo16(m[j][0], m[j][1]), pack_lo16(m[j][2], m[j][3]), pack_lo16(m[j + 1][0], m[j + 1][1]), pack_lo16(m[j + 1][2], m[j + 1][3])};
+                store_x4(x + 4 * (((j >> 1) + sw) & 3), o);
+            }
+        });
+        ex.wave_step([&](int tid) {      // the last butterfly stage across the halves: this lane takes rows 4 half .. 4 half + 3
+            const int u = tid >> 1, half = tid & 1, t = u & 15;
+            if (!s.rs.tu_log2[t]) return;
+            const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16, *xb = xa + 16;      // the pair's two blocks (both lanes of a pair share lane >> 2)
+            const int sw = tid >> 2;
+            unsigned sum = 0;
+            if constexpr (sizeof(T) == 1) {
+                // packed form: the stage across the halves on whole dwords, then 2 max(|lo|, |hi|) per dword for the stage inside it + the absolute sum.  |values| <= 255 x 32
+                // here, so eight maxima still fit the 16-bit lanes of an accumulator
+                uint32_t acc[2] = {0, 0};
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    uint32_t va[4], vb[4];
+                    const int at = 4 * ((2 * half + c + sw) & 3);
+                    load_x4(xa + at, va); load_x4(xb + at, vb);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+#pragma unroll
+                        for (int sgn = 0; sgn < 2; sgn++) {
+                            const uint32_t v = sgn ? pk_sub16(va[i], vb[i]) : pk_add16(va[i], vb[i]);
+                            const uint32_t av = pk_max_i16(v, pk_sub16(0u, v));                  // |lo|, |hi|
+                            acc[c] = pk_add16(acc[c], pk_max_i16(av, (av >> 16) | (av << 16)));    // both lanes: max(|lo|, |hi|)
+                        }
+                    }
+                }
+                s.rs.scratch[4096 + tid] = 2u * ((acc[0] & 0xffffu) + (acc[1] & 0xffffu));
+                return;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                uint32_t va[4], vb[4];
+                const int at = 4 * ((2 * half + c + sw) & 3);
+                load_x4(xa + at, va); load_x4(xb + at, vb);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int a0 = (int)(int16_t)(va[i] & 0xffff), a1 = (int)(int16_t)(va[i] >> 16), b0 = (int)(int16_t)(vb[i] & 0xffff), b1 = (int)(int16_t)(vb[i] >> 16);
+                    sum += (unsigned)(iabs(a0 + b0) + iabs(a0 - b0) + iabs(a1 + b1) + iabs(a1 - b1));
+                }
+            }
+            s.rs.scratch[4096 + tid] = sum;
         });
         ex.phase([&](int tid) {
             const int u = tid >> 1, k = kRingSlot[u >> 4], t = u & 15;
