@@ -42,7 +42,7 @@ class CostParams(C.Structure):
 
 # every symbol include/mihevc.h declares; tests/test_abi.py checks the header against this list and the .so
 EXPORTS = (
-    "mihevc_abi_version", "mihevc_device_count", "mihevc_device_numa_node", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_async", "mihevc_sync_uploads", "mihevc_send_frame_device",
+    "mihevc_abi_version", "mihevc_device_count", "mihevc_device_numa_node", "mihevc_config_default", "mihevc_open", "mihevc_send_frame", "mihevc_send_frame_async", "mihevc_sync_uploads", "mihevc_send_frame_device", "mihevc_send_frames_device",
     "mihevc_receive_packet", "mihevc_flush", "mihevc_abort", "mihevc_close", "mihevc_get_stats", "mihevc_get_headers", "mihevc_set_keep_recon",
     "mihevc_get_recon", "mihevc_coded_size", "mihevc_get_frame_info", "mihevc_strerror", "mihevc_last_error", "mihevc_cost_params_for_qp", "mihevc_tile_grid", "mihevc_p_tile_grid", "mihevc_k_transform",
     "mihevc_k_intra_frame", "mihevc_k_inter_frame", "mihevc_k_b_frame", "mihevc_k_deblock", "mihevc_k_sao", "mihevc_k_loop_filter", "mihevc_write_parameter_sets",
@@ -82,6 +82,7 @@ def load() -> C.CDLL:
     lib.mihevc_send_frame.argtypes = [vp, vp, vp, vp, i32, i32, i64]
     lib.mihevc_send_frame_device.argtypes = [vp, vp, vp, vp, i32, i32, i64]
     lib.mihevc_send_frame_async.argtypes = [vp, vp, vp, vp, i32, i32, i64]
+    lib.mihevc_send_frames_device.argtypes = [vp, i32, vp, vp, vp, i32, i32, i64]
     lib.mihevc_sync_uploads.argtypes = [vp]
     lib.mihevc_receive_packet.argtypes = [vp, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(i64), C.POINTER(i64), C.POINTER(i32)]
     lib.mihevc_flush.argtypes = [vp]

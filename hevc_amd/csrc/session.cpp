@@ -1505,6 +1505,13 @@ int mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, co
 {
     return ingest(s, y, u, v, pitch_y, pitch_c, pts, true, false);
 }
+int mihevc_send_frames_device(mihevc_session *s, int n, const void *const *y, const void *const *u, const void *const *v, int pitch_y, int pitch_c, int64_t first_pts)
+{
+    if (!s || n < 0 || (n && (!y || !u || !v))) return MIHEVC_EINVAL;
+    for (int i = 0; i < n; i++)
+        if (int e = ingest(s, y[i], u[i], v[i], pitch_y, pitch_c, first_pts + i, true, false)) return e;
+    return MIHEVC_OK;
+}
 int mihevc_sync_uploads(mihevc_session *s)
 {
     if (!s) return MIHEVC_EINVAL;

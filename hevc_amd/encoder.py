@@ -155,6 +155,15 @@ class Encoder:
         self._pts = pts + 1
         self._check(self._lib.mihevc_send_frame_device(self._s, y_ptr, u_ptr, v_ptr, pitch_y, pitch_c, pts), "send_frame_device")
 
+    def send_device_batch(self, y_ptrs, u_ptrs, v_ptrs, pitch_y: int, pitch_c: int, first_pts: Optional[int] = None):
+        """mihevc_send_frames_device: len(y_ptrs) pictures already in device memory in ONE call.  The pointer lists may be ctypes arrays of c_void_p made once
+        for frames that stay where they are (device_pointer_arrays)."""
+        n = len(y_ptrs)
+        arrs = [p if isinstance(p, C.Array) else (C.c_void_p * n)(*p) for p in (y_ptrs, u_ptrs, v_ptrs)]
+        pts = self._pts if first_pts is None else first_pts
+        self._pts = pts + n
+        self._check(self._lib.mihevc_send_frames_device(self._s, n, arrs[0], arrs[1], arrs[2], pitch_y, pitch_c, pts), "send_frames_device")
+
     def flush(self):
         self._check(self._lib.mihevc_flush(self._s), "flush")
 

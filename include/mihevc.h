@@ -162,6 +162,11 @@ int  mihevc_sync_uploads(mihevc_session *s);         /* every frame handed over 
  * already is the coded size (multiples of 8) and planes / pitches are 4-byte aligned the session codes straight from the caller's planes. */
 int  mihevc_send_frame_device(mihevc_session *s, const void *y, const void *u, const void *v,
                               int pitch_y, int pitch_c, int64_t pts);
+/* n pictures that are ALREADY in device memory in one call (pts = first_pts, first_pts + 1, ...): mihevc_send_frame_device n times, for a caller that holds the pointers
+ * in arrays anyway — a host language's call overhead (ctypes: ~3.5 us per call, 1 ms per 300-frame clip at 5000 fps) stays out of the loop.  Same ownership rules; stops
+ * at the first error.  Chunks that fill up on the way are coded inside the call, as with the one-picture form. */
+int  mihevc_send_frames_device(mihevc_session *s, int n, const void *const *y, const void *const *u, const void *const *v,
+                               int pitch_y, int pitch_c, int64_t first_pts);
 /* One access unit (Annex-B NAL units) in session-owned memory, valid until the next receive/close. */
 int  mihevc_receive_packet(mihevc_session *s, const uint8_t **data, size_t *size,
                            int64_t *pts, int64_t *dts, int *keyframe);

@@ -255,3 +255,29 @@ def test_scene_cuts_start_a_gop_and_min_keyint_holds(lib):
     assert bytes_on < 0.95 * bytes_off
     psnr = lambda recs: float(np.mean([util.psnr(r.y, f.y) for r, f in zip(recs, frames)]))     # noqa: E731
     assert psnr(recs_on) > psnr(recs_off) - 0.1
+
+
+def test_resident_frames_handed_over_in_one_call_give_the_same_stream(lib):
+    """mihevc_send_frames_device (n pictures already in HBM, one call) against mihevc_send_frame_device n times: the same bytes, packet by packet, with the clip spanning
+    several chunks (chunks that fill up are coded inside the call)"""
+    import torch
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder
+    from hevc_amd.yuvio import SyntheticClip
+    w, h, n = 320, 192, 23
+    cfg = _lib.default_config()
+    cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits, cfg.level_idc = w, h, 5, 2, 2, 22, -1, 800, 960, 93
+    frames = [[torch.from_numpy(p).cuda() for p in f] for f in SyntheticClip("motion", 3, w, h, n).frames()]
+    torch.cuda.synchronize()
+    out = []
+    for batch in (False, True):
+        with Encoder(cfg, device=0) as enc:
+            if batch:
+                enc.send_device_batch([f[0].data_ptr() for f in frames], [f[1].data_ptr() for f in frames], [f[2].data_ptr() for f in frames], w, w // 2)
+            else:
+                for i, f in enumerate(frames):
+                    enc.send_device(f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), w, w // 2, pts=i)
+            enc.flush()
+            out.append(list(enc.packets()))
+            assert enc.stats().frames_out == n
+    assert len(out[0]) == n and out[0] == out[1]
