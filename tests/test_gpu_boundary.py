@@ -14,6 +14,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def lib():
+    try:                       # a test below keeps frames in torch tensors: torch's HIP runtime has to come up before libmihevc's
+        import torch
+        torch.cuda.init()
+    except Exception:          # noqa: BLE001 -- no torch / no device: that test says so itself
+        pass
     from hevc_amd import _lib
     L = _lib.load()
     assert L.mihevc_device_count() >= 1, "no gfx950 device visible: the GPU tests need an MI355X"
