@@ -895,8 +895,8 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     const int oy_x = x0 + sx - R - 4, oy_y = y0 + sy - R - 4;                                  // luma window origin
     const int oc_x = (x0 >> 1) + ((4 * sx - 4 * R - 3) >> 3) - 1, oc_y = (y0 >> 1) + ((4 * sy - 4 * R - 3) >> 3) - 1;
 
-    residual_init(ex, s.rs);
     ex.phase([&](int tid) {
+        residual_init_lane(s.rs, tid);          // (transform tables and flags: nothing else in this phase touches them; a phase of their own was one more barrier)
         load_ctu_source<T>(s.src, a.src, x0, y0, a.w, a.h, tid);
         copy_window<T>(win_y, wys, a.ref[0].p, a.ref[0].stride, oy_x, oy_y, wy, wy, -PAD_Y, a.w + PAD_Y - 1, -PAD_Y, a.h + PAD_Y - 1, tid);
         copy_window<T>(win_u, wcs, a.ref[1].p, a.ref[1].stride, oc_x, oc_y, wc, wc, -PAD_C, (a.w >> 1) + PAD_C - 1, -PAD_C, (a.h >> 1) + PAD_C - 1, tid);
@@ -1211,13 +1211,11 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             }
         });
     }
-    if constexpr (!BI)
+    // (the tiles' vectors for the CU records are written by the motion compensation phase below: a phase of its own for 16 lanes was one more barrier for every CTU)
+    if (!BI && a.ip)
     ex.phase([&](int tid) {
-        if (tid < 16) { s.tile_mvx[tid] = s.mvx[s.tile_node[tid]]; s.tile_mvy[tid] = s.mvy[s.tile_node[tid]]; }
-        if (a.ip) {
-            if (tid >= 64 && tid < 85 && s.valid[tid - 64] && s.chosen[tid - 64]) ex.atomic_add(&s.ip_cost, s.cost[tid - 64]);
-            if (tid >= 128 && tid < 144 && s.rs.tu_log2[tid - 128]) ex.atomic_add(&s.ip_tiles, 1u);
-        }
+        if (tid >= 64 && tid < 85 && s.valid[tid - 64] && s.chosen[tid - 64]) ex.atomic_add(&s.ip_cost, s.cost[tid - 64]);
+        if (tid >= 128 && tid < 144 && s.rs.tu_log2[tid - 128]) ex.atomic_add(&s.ip_tiles, 1u);
     });
     // intra second-pass candidate (oracle: orc_analyze_inter_frame): the inter cost is above 4 per sample AND above the source's
     // own AC activity (8x8 Hadamard without the DC term).  The activity is only computed when the first test passes.
@@ -1236,10 +1234,11 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
     // motion compensation of the chosen CUs: every lane predicts 4 luma samples and 2 chroma samples
     if constexpr (!BI)
     ex.phase([&](int tid) {
+        if (tid < 16) { s.tile_mvx[tid] = s.mvx[s.tile_node[tid]]; s.tile_mvy[tid] = s.mvy[s.tile_node[tid]]; }      // read by the output phase, behind barriers
         {
             const int t = tid >> 4, j = (tid >> 1) & 7, hx = (tid & 1) * 4, txp = t & 3, typ = t >> 2;
             if (s.rs.tu_log2[t]) {
-                int mx = s.tile_mvx[t], my = s.tile_mvy[t];
+                int mx = s.mvx[s.tile_node[t]], my = s.mvy[s.tile_node[t]];
                 int px = x0 + txp * 8 + hx + (mx >> 2) - oy_x, py = y0 + typ * 8 + j + (my >> 2) - oy_y;
                 luma_quad(win_y, py * wys + px, wys, mx & 3, my & 3, bd, s.pred + (typ * 8 + j) * 32 + txp * 8 + hx);
             }
@@ -1247,7 +1246,7 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
         for (int i = tid; i < 512; i += NT) {
             int pl = i >> 8, k = i & 255, x = k & 15, y = k >> 4, t = (y >> 2) * 4 + (x >> 2);
             if (!s.rs.tu_log2[t]) continue;
-            int mx = s.tile_mvx[t], my = s.tile_mvy[t];
+            int mx = s.mvx[s.tile_node[t]], my = s.mvy[s.tile_node[t]];
             int px = (x0 >> 1) + x + (mx >> 3) - oc_x, py = (y0 >> 1) + y + (my >> 3) - oc_y;
             s.pred[1024 + i] = (T)chroma_sample<T>((pl ? win_v : win_u) + py * wcs + px, wcs, mx & 7, my & 7, bd);
         }
@@ -1299,8 +1298,8 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                 SampleLoc l = locate(s.rs, i);
                 if (l.log2n && ((s.tu_zero[l.plane] >> l.tile0) & 1)) { s.rs.lvl[i] = 0; s.rs.res[i] = 0; }
             }
+            if (tid < 3) s.rs.cbf[tid] &= ~s.tu_zero[tid];       // (nothing in this phase reads cbf)
         });
-        ex.phase([&](int tid) { if (tid < 3) s.rs.cbf[tid] &= ~s.tu_zero[tid]; });
     }
     // reconstruction + outputs
     ex.phase([&](int tid) {

@@ -328,14 +328,17 @@ constexpr PairTables make_pair_tables()
 }
 DEVCONST PairTables g_pair = make_pair_tables();
 
+// one lane's share of the set-up, for a caller that folds it into a phase of its own (nothing else may touch the fields in that phase)
+DEV void residual_init_lane(ResidualShared &s, int tid)
+{
+    for (int i = tid; i < 680; i += NT) { s.mp[i] = g_pair.mp[i]; s.mq[i] = g_pair.mq[i]; }
+    if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
+    if (tid < 6) { s.quant_scale[tid] = g_tab.quant_scale[tid]; s.level_scale[tid] = g_tab.level_scale[tid]; }
+    if (tid < 3) s.cbf[tid] = 0;
+}
 template <class Ex> DEV void residual_init(Ex &ex, ResidualShared &s)
 {
-    ex.phase([&](int tid) {
-        for (int i = tid; i < 680; i += NT) { s.mp[i] = g_pair.mp[i]; s.mq[i] = g_pair.mq[i]; }
-        if (tid < 16) { s.tu_log2[tid] = 0; s.tu_intra[tid] = 0; }
-        if (tid < 6) { s.quant_scale[tid] = g_tab.quant_scale[tid]; s.level_scale[tid] = g_tab.level_scale[tid]; }
-        if (tid < 3) s.cbf[tid] = 0;
-    });
+    ex.phase([&](int tid) { residual_init_lane(s, tid); });
 }
 
 // coefficient-rate estimate of one 4x4 sub-block of levels, in 1/16 bit (oracle/hevc_oracle.c code_tu)
