@@ -315,12 +315,9 @@ template <typename T, class Ex> DEV void sao_ctu_program(Ex &ex, SaoShared<T> &s
             long long cost = (long long)lam * 4;
             for (int k = 1; k <= 4; k++) s.eo_off[pl][c][k - 1] = (int8_t)sao_offset_rd(s.eo_n[pl][c][k], s.eo_s[pl][c][k], k <= 2 ? 1 : -1, lam, 0, maxoff, cost);
             s.eo_cost[pl][c] = cost;
-        }
+        } else if (tid >= 128 && tid < 131) s.band_key[tid - 128] = ~0ull;      // for the next phase's minimum (a phase of its own was one more barrier)
     });
     ex.phase([&](int tid) {          // best band position per plane: 87 lanes, ties -> lowest position
-        if (tid < 3) s.band_key[tid] = ~0ull;
-    });
-    ex.phase([&](int tid) {
         if (tid < 87) {
             int pl = tid / 29, p = tid % 29;
             long long c = s.bo_cost[pl][p] + s.bo_cost[pl][p + 1] + s.bo_cost[pl][p + 2] + s.bo_cost[pl][p + 3];
