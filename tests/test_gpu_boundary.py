@@ -14,11 +14,6 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def lib():
-    try:                       # a test below keeps frames in torch tensors: torch's HIP runtime has to come up before libmihevc's
-        import torch
-        torch.cuda.init()
-    except Exception:          # noqa: BLE001 -- no torch / no device: that test says so itself
-        pass
     from hevc_amd import _lib
     L = _lib.load()
     assert L.mihevc_device_count() >= 1, "no gfx950 device visible: the GPU tests need an MI355X"
@@ -264,25 +259,44 @@ def test_scene_cuts_start_a_gop_and_min_keyint_holds(lib):
 
 def test_resident_frames_handed_over_in_one_call_give_the_same_stream(lib):
     """mihevc_send_frames_device (n pictures already in HBM, one call) against mihevc_send_frame_device n times: the same bytes, packet by packet, with the clip spanning
-    several chunks (chunks that fill up are coded inside the call)"""
-    import torch
+    several chunks (chunks that fill up are coded inside the call).  The frames are put into device memory with the HIP runtime libmihevc itself links (hipMalloc /
+    hipMemcpy through ctypes): no second runtime in the process, whatever test ran before."""
+    import ctypes as C
     from hevc_amd import _lib
     from hevc_amd.encoder import Encoder
     from hevc_amd.yuvio import SyntheticClip
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
     w, h, n = 320, 192, 23
     cfg = _lib.default_config()
     cfg.width, cfg.height, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.crf, cfg.qp, cfg.vbv_maxrate_kbps, cfg.vbv_bufsize_kbits, cfg.level_idc = w, h, 5, 2, 2, 22, -1, 800, 960, 93
-    frames = [[torch.from_numpy(p).cuda() for p in f] for f in SyntheticClip("motion", 3, w, h, n).frames()]
-    torch.cuda.synchronize()
-    out = []
-    for batch in (False, True):
-        with Encoder(cfg, device=0) as enc:
-            if batch:
-                enc.send_device_batch([f[0].data_ptr() for f in frames], [f[1].data_ptr() for f in frames], [f[2].data_ptr() for f in frames], w, w // 2)
-            else:
-                for i, f in enumerate(frames):
-                    enc.send_device(f[0].data_ptr(), f[1].data_ptr(), f[2].data_ptr(), w, w // 2, pts=i)
-            enc.flush()
-            out.append(list(enc.packets()))
-            assert enc.stats().frames_out == n
-    assert len(out[0]) == n and out[0] == out[1]
+    assert hip.hipSetDevice(0) == 0
+    ptrs = []
+    for f in SyntheticClip("motion", 3, w, h, n).frames():
+        row = []
+        for pl in f:
+            pl = np.ascontiguousarray(pl)
+            d = C.c_void_p()
+            assert hip.hipMalloc(C.byref(d), pl.nbytes) == 0
+            assert hip.hipMemcpy(d, pl.ctypes.data_as(C.c_void_p), pl.nbytes, 1) == 0      # hipMemcpyHostToDevice
+            row.append(d.value)
+        ptrs.append(row)
+    try:
+        out = []
+        for batch in (False, True):
+            with Encoder(cfg, device=0) as enc:
+                if batch:
+                    enc.send_device_batch([f[0] for f in ptrs], [f[1] for f in ptrs], [f[2] for f in ptrs], w, w // 2)
+                else:
+                    for i, f in enumerate(ptrs):
+                        enc.send_device(f[0], f[1], f[2], w, w // 2, pts=i)
+                enc.flush()
+                out.append(list(enc.packets()))
+                assert enc.stats().frames_out == n
+        assert len(out[0]) == n and out[0] == out[1]
+    finally:
+        for row in ptrs:
+            for d in row:
+                hip.hipFree(d)
