@@ -549,7 +549,8 @@ def main():
             "stages_ms_per_picture": {_lib.STAGE_NAMES[i]: round(stage_ms[i] / max(1.0, stage_pics[i]), 4) for i in range(8)},
             "host": {"entropy_ms_per_frame_sum_over_threads": round(st.entropy_ms / max(1, st.frames_out), 4), "cpus": os.cpu_count(), "numa_node": numa_node, "cpus_bound": len(os.sched_getaffinity(0)),
                      "step_phases_ms": dict(zip(("open", "send", "flush_drain", "close"), [round(x / args.steps * 1e3, 2) for x in phase_s])),
-                     "device_ms_per_step": round(st.device_ms, 2)},
+                     "device_ms_per_step": round(st.device_ms, 2),
+                     "chunk_host_ms": {"before_first_launch": round(st.reserved[3] / 1e3, 2), "after_last_kernel": round(st.reserved[4] / 1e3, 2), "chunk_wall": round(st.reserved[5] / 1e3, 2)}},
             "roofline": {"bound": "hbm", "kernel": _lib.STAGE_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),

@@ -601,6 +601,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
 {
     const int n = (int)s->pending.size();
     if (!n) return 0;
+    const auto wall0 = std::chrono::steady_clock::now();      // stats.reserved[3..5]: host time of the chunk in front of its first launch / behind its last kernel / in all (us, summed)
     // ---- GOP layout of the chunk.  Scene cuts (x265 scenecut + min-keyint, reference core/transcoder.py:401) divide the chunk into segments; every
     //      segment is coded as the FEWEST closed GOPs keyint allows (the IDR count of an IDR-every-keyint layout), of near-equal length when
     //      cfg.gop_balance is set: the lanes of the lock-step pipeline then run out together instead of idling behind a short last GOP (a 300-picture
@@ -972,6 +973,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
     hipEvent_t t_begin, t_end;
     HIPCK(s, hipEventCreate(&t_begin)); HIPCK(s, hipEventCreate(&t_end));
     HIPCK(s, hipEventRecord(t_begin, s->st_compute));
+    const auto wall1 = std::chrono::steady_clock::now();
     auto mark = [&](int stage, int pictures, bool begin) -> int {       // bracket a stage with events when profiling
         if (!s->cfg.profile_stages || (s->cfg.profile_stages == 2 && stage != 2)) return 0;      // 2: the dominant stage (inter_ctu) only
         size_t need_ev = s->marks.size() * 2 + 2;
@@ -1277,6 +1279,7 @@ template <typename T> int encode_chunk(mihevc_session *s)
 #undef STAGE
     HIPCK(s, hipEventRecord(t_end, s->st_compute));
     HIPCK(s, hipStreamSynchronize(s->st_compute));
+    const auto wall2 = std::chrono::steady_clock::now();
     HIPCK(s, hipStreamSynchronize(s->st_copy));
     HIPCK(s, hipStreamSynchronize(s->st_pre));        // a chunk without P steps never waited for its pre-search: its buffers are reused by the next chunk
     if (s->d_flow) {      // a dataflow wait that gave up (a bug: the pictures are garbage, never hand them out)
@@ -1339,6 +1342,11 @@ template <typename T> int encode_chunk(mihevc_session *s)
     }
     for (auto &src : s->pending) if (!src.borrowed) s->free_src.push_back(src);
     s->pending.clear();
+    {
+        const auto wall3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return (int32_t)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count(); };
+        s->stats.reserved[3] += us(wall0, wall1); s->stats.reserved[4] += us(wall2, wall3); s->stats.reserved[5] += us(wall0, wall3);
+    }
     return 0;
 }
 

@@ -127,7 +127,8 @@ typedef struct mihevc_stats {
     double  sse_y, sse_u, sse_v;      /* encoder reconstruction vs source (summed over frames_out), for PSNR */
     double  device_ms, entropy_ms;    /* accumulated device time (HIP events) and host CABAC time (sum over threads) */
     int32_t last_qp;
-    int32_t reserved[7];
+    int32_t reserved[7];              /* [0..2]: cfg.bframes = -1, the last probe; [3..5]: host microseconds of the chunks in front of their first launch, behind their last
+                                       * kernel (last symbol copies + the entropy coding still open), and in all: where wall time that is not device time goes */
     /* per-stage device time, filled when cfg.profile_stages: sum of HIP-event intervals and number of launches.
      * index: 0 intra (all anti-diagonals of a step), 1 me_search (incl. the pre-search), 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
      * 5 border pad, 6 unused since ABI 2 (the SSE pass runs on the copy stream, beside the next step), 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
