@@ -130,8 +130,9 @@ typedef struct mihevc_stats {
     int32_t reserved[7];              /* [0..2]: cfg.bframes = -1, the last probe; [3..5]: host microseconds of the chunks in front of their first launch, behind their last
                                        * kernel (last symbol copies + the entropy coding still open), and in all: where wall time that is not device time goes */
     /* per-stage device time, filled when cfg.profile_stages: sum of HIP-event intervals and number of launches.
-     * index: 0 intra (all anti-diagonals of a step), 1 me_search (incl. the pre-search), 2 inter_ctu, 3 deblock (V+H), 4 sao (decide+apply),
-     * 5 border pad, 6 unused since ABI 2 (the SSE pass runs on the copy stream, beside the next step), 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
+     * index: 0 intra (plan + the dataflow launch of a step), 1 me_search, 2 inter_ctu, 3 deblock (V+H; only without SAO: with SAO the loop filter is one kernel, counted
+     * under 4), 4 sao (the whole loop filter: deblock of the CTU's tile + decide + apply + squared error), 5 border pad, 6 unused since ABI 2 (the SSE fold runs on the copy
+     * stream), 7 intra second pass of P pictures (two rounds).  One launch covers `pictures` pictures (the lock-step batch). */
     double  stage_ms[8];
     int64_t stage_launches[8];
     int64_t stage_pictures[8];
@@ -148,7 +149,7 @@ int  mihevc_open(const mihevc_config *cfg, int device, mihevc_session **out);
 /* Caller-owned host planes (8-bit: 1 byte/sample, 10-bit: 2 bytes little endian), copied/uploaded before return. */
 int  mihevc_send_frame(mihevc_session *s, const void *y, const void *u, const void *v,
                        int pitch_y, int pitch_c, int64_t pts);
-/* The same without waiting for the upload: the copies are enqueued on the session's upload stream and the call returns.  The caller's planes must stay
+/* The same without waiting for the upload: the copies are enqueued on the session's side stream and the call returns.  The caller's planes must stay
  * valid and unmodified until mihevc_sync_uploads() or mihevc_flush() has returned (a decoder that feeds the session from a ring of N frame buffers calls
  * mihevc_sync_uploads before it reuses the oldest).  For the copies to run as DMA beside the caller the planes have to be page-locked host memory
  * (hipHostMalloc / hipHostRegister; torch: pin_memory()); with pageable memory the call is correct but as slow as mihevc_send_frame. */
@@ -255,7 +256,7 @@ int mihevc_k_b_frame(int device, const void *src_y, const void *src_u, const voi
                      const void *ref0_y, const void *ref0_u, const void *ref0_v, const void *ref1_y, const void *ref1_u, const void *ref1_v, int width, int height,
                      const mihevc_cost_params *prm, const int16_t *centers0, const int16_t *centers1, void *rec_y, void *rec_u, void *rec_v,
                      mihevc_cu_rec *cu, int16_t *coef_y, int16_t *coef_u, int16_t *coef_v, int32_t *me_dump0, int32_t *me_dump1, uint64_t *est_bits_q4);
-/* K4a: deblocking in place */
+/* K4a: deblocking in place (the picture passes: a session runs them only without SAO, see mihevc_k_loop_filter) */
 int mihevc_k_deblock(int device, void *rec_y, void *rec_u, void *rec_v, int width, int height,
                      const mihevc_cu_rec *cu, int bit_depth);
 /* K4b: SAO statistics + decision + apply */
