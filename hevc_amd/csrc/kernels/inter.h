@@ -697,13 +697,8 @@ DEV void luma_half_diff(const uint16_t *win, int i00, int ws, int fx, int fy, in
         typ[k] = pack_lo16(g_tab.luma_tap[fy][2 * k], g_tab.luma_tap[fy][2 * k + 1]);
     }
     const int shift1 = bit_depth - 8, shift3 = 14 - bit_depth, maxv = (1 << bit_depth) - 1, off3 = 1 << (shift3 - 1);
-    int acc[8][4], prev[4];
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) acc[j][i] = 0;
-#pragma unroll
-    for (int r = 0; r < 15; r++) {
+    // the horizontal 8-tap filter of intermediate row r (reference row r - 3): four 14-bit values
+    auto row_h = [&](int r, int (&hv)[4]) {
         const int idx = i00 + (r - 3) * ws - 3, off = idx & 1;
         const uint16_t *p = win + (idx - off);
         uint32_t d[7], e[6], o[5];
@@ -713,7 +708,6 @@ DEV void luma_half_diff(const uint16_t *win, int i00, int ws, int fx, int fy, in
         for (int k = 0; k < 6; k++) e[k] = align_bytes(d[k + 1], d[k], 2 * off);     // samples (2k, 2k+1) of the row
 #pragma unroll
         for (int k = 0; k < 5; k++) o[k] = align_bytes(e[k + 1], e[k], 2);           // samples (2k+1, 2k+2)
-        int hv[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int v = 0;
@@ -721,6 +715,31 @@ DEV void luma_half_diff(const uint16_t *win, int i00, int ws, int fx, int fy, in
             for (int k = 0; k < 4; k++) v = dot2_i16((i & 1) ? o[(i >> 1) + k] : e[(i >> 1) + k], txp[k], v);
             hv[i] = v >> shift1;
         }
+    };
+    // a zero fraction makes that direction's filter the identity (see the 8-bit form): one pass gives the same values; taken when the whole wave has it
+    if (wave_all(fy == 0)) {          // horizontal only: the block's own 8 rows; 64 hv >> 6 = hv
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            int hv[4];
+            row_h(j + 3, hv);
+#pragma unroll
+            for (int i = 0; i < 4; i++) m[j][i] = (int)src[j * src_stride + i] - clip3(0, maxv, (hv[i] + off3) >> shift3);
+        }
+        return;
+    }
+    const bool v_only = wave_all(fx == 0);      // vertical only: the horizontal pass of a whole-sample column is the sample x 64 >> shift1
+    int acc[8][4], prev[4];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[j][i] = 0;
+#pragma unroll
+    for (int r = 0; r < 15; r++) {
+        int hv[4];
+        if (v_only) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) hv[i] = (int)win[i00 + (r - 3) * ws + i] << (6 - shift1);
+        } else row_h(r, hv);
         if (r > 0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
