@@ -114,6 +114,7 @@ template <typename T> __global__ __launch_bounds__(NT, 2) void k_intra_diag(cons
 // workgroup publishes its CTU with a release store at device scope after all of its waves fenced their stores (reconstruction, CU records: the neighbours' reads);
 // the waiting side polls with relaxed device-scope loads and fences once it saw the word.  With one launch per anti-diagonal (k_intra_diag) every step of the chain
 // cost the SLOWEST CTU of the diagonal plus a launch boundary: 24 x 130 us per IDR step at 1080p whatever the content.
+// OPT-IN (MIHEVC_INTRA_FLOW): safe for one such kernel on the device, not for several at once (session.cpp ensure_flow).
 template <typename T> __global__ __launch_bounds__(NT, 2) void k_intra_flow(const IntraArgs<T> *args, int lanes, int n_ctu, IntraFlow f)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -726,7 +727,7 @@ int stage_intra(const void *sy, const void *su, const void *sv, int w, int h, co
     CK(hipMemcpy(dargs.p, &a, sizeof a, hipMemcpyHostToDevice));
     IntraFlow flow;
     DevBuf dorder, dflags;
-    if (!getenv("MIHEVC_INTRA_CHAIN")) {      // (debug switch: stage B as one launch per anti-diagonal, the form of rounds 1 and 2)
+    if (getenv("MIHEVC_INTRA_FLOW")) {        // (opt-in: stage B as one dataflow launch; default: one launch per anti-diagonal — session.cpp ensure_flow says why)
         const int n_ctu = a.ctus_w * a.ctus_h;
         std::vector<IntraFlowSlot> order((size_t)n_ctu);
         build_intra_flow_order(a.ctus_w, a.ctus_h, a.prm.tile_cols, a.prm.tile_rows, order.data());

@@ -317,11 +317,15 @@ int ensure_lanes(mihevc_session *s, int n)
     return 0;
 }
 
-// the IDR pictures' dataflow launch (k_intra_flow): slot table and flag words, made once per session.  Buffers come from the process-wide cache with whatever an
-// earlier session left in them, so the flags are zeroed here and generations count from 1.  MIHEVC_INTRA_CHAIN (debug switch): one launch per anti-diagonal instead.
+// the IDR pictures' dataflow launch (k_intra_flow), OPT-IN through MIHEVC_INTRA_FLOW: slot table and flag words, made once per session.  Buffers come from the process-wide
+// cache with whatever an earlier session left in them, so the flags are zeroed here and generations count from 1.  Default: one launch per anti-diagonal (k_intra_diag).
+// Why opt-in: the no-deadlock argument (a wait only points at lower workgroup ids, ids are dispatched in order) holds for ONE such kernel on the device.  Several at once
+// (sessions sharing a device: a sliced picture's bands, a batch's workers) can fill an XCD's workgroup slots with each other's waiting workgroups while the one workgroup
+// every chain waits for has no slot: seen once in four runs of the 4320p picture as 8 sessions on one device — the bounded wait turned it into an error instead of a hang.
+// The gain (intra stage -7 %, 0.6 % of a clip) does not pay for that.
 static int ensure_flow(mihevc_session *s)
 {
-    if (s->d_flow || getenv("MIHEVC_INTRA_CHAIN")) return 0;
+    if (s->d_flow || !getenv("MIHEVC_INTRA_FLOW")) return 0;
     const size_t o_flags = (size_t)s->n_ctu * sizeof(IntraFlowSlot), bytes = o_flags + ((size_t)MAX_LANES * s->n_ctu + 1) * sizeof(int);
     HIPCK(s, BufferCache::get().alloc(s->device, bytes, false, &s->d_flow));
     s->flow_bytes = bytes;

@@ -502,3 +502,34 @@ def test_fractional_search_at_the_limits_of_the_16_bit_packed_transform(lib, api
         want, got = O.analyze_inter(src, ref, prm, dump_me=True), api.inter(src, ref, cp)
         assert np.array_equal(want.me, got.me)
         assert util.same_analysis(want, got), util.describe_diff(want, got)
+
+
+def test_idr_dataflow_launch_is_opt_in_and_equals_the_diagonal_chain(lib, api, monkeypatch):
+    """MIHEVC_INTRA_FLOW: stage B of an I picture as ONE launch in which CTUs wait for their neighbours (k_intra_flow) instead of one launch per anti-diagonal.  Off by
+    default (several such kernels at once on one device can starve each other: csrc/session.cpp ensure_flow); with the switch on, one picture through the stage entry
+    and a session on its own must give what the default gives — the oracle's picture, the same stream."""
+    from hevc_amd import _lib
+    from hevc_amd.encoder import Encoder
+    w, h, bd, qp = 544, 320, 8, 27
+    prm, cp = lib_params(lib, qp, bd, 8)
+    prm.tile_cols = cp.tile_cols = 2
+    prm.tile_rows = cp.tile_rows = 2
+    src = util.synth_frame(h, w, seed=17, bit_depth=bd)
+    want = O.analyze_intra(src, prm)
+    streams = []
+    for on in (False, True):
+        if on:
+            monkeypatch.setenv("MIHEVC_INTRA_FLOW", "1")
+        else:
+            monkeypatch.delenv("MIHEVC_INTRA_FLOW", raising=False)
+        got = api.intra(src, cp)
+        assert util.same_analysis(want, got), ("flow" if on else "chain") + ": " + util.describe_diff(want, got)
+        cfg = _lib.default_config()
+        cfg.width, cfg.height, cfg.bit_depth, cfg.keyint, cfg.min_keyint, cfg.gops_in_flight, cfg.qp, cfg.level_idc = w, h, bd, 4, 2, 2, qp, 120
+        frames = [util.synth_frame(h, w, seed=17, shift=(2 * i, i), bit_depth=bd) for i in range(9)]
+        with Encoder(cfg, device=0) as enc:
+            for f in frames:
+                enc.send(*util.planes(f, bd))
+            enc.flush()
+            streams.append(b"".join(p[0] for p in enc.packets()))
+    assert streams[0] == streams[1] and len(streams[0]) > 1000
