@@ -136,3 +136,30 @@ def test_config4_batch_of_eight_1080p_clips_two_worker_processes(lib, tmp_path):
     for f in files:
         top = mp4.parse_boxes((out / (f.stem + ".mp4")).read_bytes())
         assert [b[0] for b in top] == ["ftyp", "moov", "mdat"]
+
+
+@pytest.mark.parametrize("w,h,hdr,qp", [(1920, 1080, False, 27), (3840, 2160, True, 29)])
+def test_b_picture_stage_parity_at_full_size(lib, api, w, h, hdr, qp):
+    """cfg.bframes at the reference's picture sizes: I0, P2 (predicted over two pictures) and b1 between their reconstructions on the bench clip — k_inter_ctu_b with both
+    integer searches, the list-1 refinement and the bi-prediction trial against orc_analyze_b_frame, at 1920x1080 8 bit and 3840x2160 Main10 (the small-size B tests:
+    tests/test_gpu_parity.py, tests/test_gpu_bframes.py)"""
+    from tests.test_gpu_configs import session_params
+    cfg, _ = operating_point(w, h, hdr, 60)
+    bd = cfg.bit_depth
+    frames = [f for _, f in clip_frames(w, h, bd, 3)]
+    prm_i, cp_i = session_params(lib, cfg, qp - 3, True)
+    prm_p, cp_p = session_params(lib, cfg, qp, False)
+    prm_b, cp_b = session_params(lib, cfg, qp + 2, False)
+    a0 = O.analyze_intra(frames[0], prm_i)
+    r0, _ = O.sao(frames[0], O.deblock(a0.rec, a0.cu, bd), prm_i)
+    c2 = O.search_centres(frames[2], frames[0], bd) if cfg.pre_search else None
+    a2 = O.analyze_inter(frames[2], r0, prm_p, centers=c2)
+    g2 = api.inter(frames[2], r0, cp_p, centers=c2)
+    assert util.same_analysis(a2, g2), "anchor over two pictures: " + util.describe_diff(a2, g2)
+    r2, _ = O.sao(frames[2], O.deblock(a2.rec, a2.cu, bd), prm_p)
+    c0, c1 = (O.search_centres(frames[1], frames[0], bd), O.search_centres(frames[1], frames[2], bd)) if cfg.pre_search else (None, None)
+    want = O.analyze_b(frames[1], r0, r2, prm_b, c0, c1, dump_me=True)
+    got = api.b(frames[1], r0, r2, cp_b, c0, c1)
+    assert np.array_equal(want.me[0], got.me[0]) and np.array_equal(want.me[1], got.me[1]), "integer searches differ"
+    assert util.same_analysis(want, got), "B picture: " + util.describe_diff(want, got)
+    assert (want.cu["flags"] & 32).any() and ((want.cu["flags"] & 96) == 32).any(), "no bi-predicted CU: the case is not exercised"
