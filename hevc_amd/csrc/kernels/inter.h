@@ -998,8 +998,9 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             const int px = x0 + txp * 8 + 4 * half + (mx >> 2) - wox, py = y0 + typ * 8 + (my >> 2) - woy;
             int m[8][4];
             luma_half_diff((const T *)win_y, py * wys + px, wys, mx & 3, my & 3, bd, (const T *)(s.src + typ * 8 * 32 + txp * 8 + 4 * half), 32, m);
-            if constexpr (sizeof(T) == 1) {
-                // 8 bit: differences are 9 bits, the 8x8 Hadamard transform grows them by 6: everything fits 16 bits, two values a dword (v_pk_add / sub_i16).  Rows 2r and
+            {
+                // Differences are 9 bits at 8 bit, 11 at 10 bit; the five butterfly stages computed here grow them by 5: 255 x 32 and 1023 x 32 = 32736 both fit 16 bits, two values
+                // a dword (v_pk_add / sub_i16).  Rows 2r and
                 // 2r + 1 of a column share a dword: the butterflies between rows 2 and 4 apart and between columns 1 and 2 apart are whole-dword operations (4 stages x 16
                 // packed operations; the one-value form took 160), the stage across the halves follows the exchange, and the stage INSIDE a dword is never computed:
                 // it is the last one, and |a + b| + |a - b| = 2 max(|a|, |b|).
@@ -1021,18 +1022,6 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                     const uint32_t o[4] = {pk_add16(p0, p2), pk_add16(p1, p3), pk_sub16(p0, p2), pk_sub16(p1, p3)};
                     store_x4(x + 4 * ((r2 + sw) & 3), o);        // chunk r2 = rows 2 r2, 2 r2 + 1 of the four columns; rotated as below
                 }
-                return;
-            }
-            hadamard_half(m);
-            // |values| <= 32 x the sample range: they fit 16 bits.  A lane's block is 16 dwords = four 16-byte chunks; chunk c goes to place (c + (lane >> 2)) & 3
-            // of the block: with the plain order lanes i and i + 4 hit the same banks in every 128-bit store and load (16 dwords x 4 = all 64 banks: a
-            // 4-way conflict, 41 % of this kernel's LDS cycles in profiles/r02_d); rotated, any 16 consecutive lanes cover the 64 banks once
-            uint32_t *x = s.rs.scratch + tid * 16;
-            const int sw = tid >> 2;
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const uint32_t o[4] = {pack_lo16(m[j][0], m[j][1]), pack_lo16(m[j][2], m[j][3]), pack_lo16(m[j + 1][0], m[j + 1][1]), pack_lo16(m[j + 1][2], m[j + 1][3])};
-                store_x4(x + 4 * (((j >> 1) + sw) & 3), o);
             }
         });
         ex.wave_step([&](int tid) {      // the last butterfly stage across the halves: this lane takes rows 4 half .. 4 half + 3
@@ -1041,9 +1030,9 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
             const uint32_t *xa = s.rs.scratch + (tid & ~1) * 16, *xb = xa + 16;      // the pair's two blocks (both lanes of a pair share lane >> 2)
             const int sw = tid >> 2;
             unsigned sum = 0;
-            if constexpr (sizeof(T) == 1) {
-                // packed form: the stage across the halves on whole dwords, then 2 max(|lo|, |hi|) per dword for the stage inside it + the absolute sum.  |values| <= 255 x 32
-                // here, so eight maxima still fit the 16-bit lanes of an accumulator
+            {
+                // packed form: the stage across the halves on whole dwords, then 2 max(|lo|, |hi|) per dword for the stage inside it + the absolute sum.  At 8 bit |values| <= 255 x 32
+                // here, so eight maxima still fit the 16-bit lanes of an accumulator; at 10 bit (1023 x 32) every maximum is widened
                 uint32_t acc[2] = {0, 0};
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -1056,25 +1045,14 @@ DEV void inter_ctu_program(Ex &ex, InterShared<T> &s, T *win_y, T *win_u, T *win
                         for (int sgn = 0; sgn < 2; sgn++) {
                             const uint32_t v = sgn ? pk_sub16(va[i], vb[i]) : pk_add16(va[i], vb[i]);
                             const uint32_t av = pk_max_i16(v, pk_sub16(0u, v));                  // |lo|, |hi|
-                            acc[c] = pk_add16(acc[c], pk_max_i16(av, (av >> 16) | (av << 16)));    // both lanes: max(|lo|, |hi|)
+                            const uint32_t mx = pk_max_i16(av, (av >> 16) | (av << 16));          // both lanes: max(|lo|, |hi|)
+                            if constexpr (sizeof(T) == 1) acc[c] = pk_add16(acc[c], mx); else sum += mx & 0xffffu;
                         }
                     }
                 }
-                s.rs.scratch[4096 + tid] = 2u * ((acc[0] & 0xffffu) + (acc[1] & 0xffffu));
-                return;
+                if constexpr (sizeof(T) == 1) sum = (acc[0] & 0xffffu) + (acc[1] & 0xffffu);
+                s.rs.scratch[4096 + tid] = 2u * sum;
             }
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                uint32_t va[4], vb[4];
-                const int at = 4 * ((2 * half + c + sw) & 3);
-                load_x4(xa + at, va); load_x4(xb + at, vb);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int a0 = (int)(int16_t)(va[i] & 0xffff), a1 = (int)(int16_t)(va[i] >> 16), b0 = (int)(int16_t)(vb[i] & 0xffff), b1 = (int)(int16_t)(vb[i] >> 16);
-                    sum += (unsigned)(iabs(a0 + b0) + iabs(a0 - b0) + iabs(a1 + b1) + iabs(a1 - b1));
-                }
-            }
-            s.rs.scratch[4096 + tid] = sum;
         });
         ex.phase([&](int tid) {
             const int u = tid >> 1, k = kRingSlot[u >> 4], t = u & 15;

@@ -477,26 +477,28 @@ def test_b_picture_stage_equals_oracle(api, w, h, qp, bd, rng, pre):
     assert api.deblock(want.rec, want.cu, bd).same(O.deblock(want.rec, want.cu, bd))
 
 
+@pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("kind", ["flat_extremes", "checkerboard", "noise_extremes"])
-def test_fractional_search_at_the_limits_of_the_16_bit_packed_transform(lib, api, kind):
+def test_fractional_search_at_the_limits_of_the_16_bit_packed_transform(lib, api, kind, bd):
     """the 8-bit fractional search's Hadamard stages on 16-bit pairs (v_pk_add / sub / max_i16) with differences of +-255 everywhere: the device's packed arithmetic
     against the oracle's 32-bit one (the CPU twin of this test steps the kernel source with emulated packed operations)"""
     w, h = 96, 64
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:h, 0:w]
+    top, dt = (1 << bd) - 1, np.uint8 if bd == 8 else np.uint16        # (10 bit: +-1023, the transform's 16-bit lanes reach 1023 x 32 = 32736 of 32767)
     if kind == "flat_extremes":
-        a, b = np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8)
+        a, b = np.zeros((h, w), dt), np.full((h, w), top, dt)
     elif kind == "checkerboard":
-        a = (((xx + yy) & 1) * 255).astype(np.uint8)
-        b = 255 - a
+        a = (((xx + yy) & 1) * top).astype(dt)
+        b = (top - a).astype(dt)
     else:
-        a = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
-        b = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+        a = (rng.integers(0, 2, (h, w)) * top).astype(dt)
+        b = (rng.integers(0, 2, (h, w)) * top).astype(dt)
 
     def frame(y):
         c = np.ascontiguousarray(y[::2, ::2])
-        return O.Frame(y.copy(), c.copy(), (255 - c).copy())
-    prm, cp = lib_params(lib, 30, 8, 8)
+        return O.Frame(y.copy(), c.copy(), (top - c).astype(dt))
+    prm, cp = lib_params(lib, 30, bd, 8)
     prm.rdo_zero = cp.rdo_zero = 1
     for src, ref in ((frame(a), frame(b)), (frame(b), frame(a))):
         want, got = O.analyze_inter(src, ref, prm, dump_me=True), api.inter(src, ref, cp)

@@ -272,27 +272,29 @@ def test_fused_loop_filter_of_a_band_filters_across_its_seams(emu):
         assert np.array_equal(gsp, wsp[(y0 // 32) * cw:((y0 + bh + 31) // 32) * cw])
 
 
+@pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("kind", ["flat_extremes", "checkerboard", "noise_extremes"])
-def test_fractional_search_at_the_limits_of_the_16_bit_packed_transform(emu, kind):
+def test_fractional_search_at_the_limits_of_the_16_bit_packed_transform(emu, kind, bd):
     """8 bit: the fractional search's Hadamard stages run on 16-bit pairs (v_pk_add / sub / max_i16).  Differences of +-255 in every sample drive the transform to its
     largest coefficients (255 x 32 before the last stage, 255 x 64 after it) and the packed sums to 65280 of 65535: black against white, a checkerboard of extremes,
     and random extremes must still equal the oracle's 32-bit arithmetic."""
     w, h = 96, 64
     rng = np.random.default_rng(5)
     yy, xx = np.mgrid[0:h, 0:w]
+    top, dt = (1 << bd) - 1, np.uint8 if bd == 8 else np.uint16        # (10 bit: +-1023, the transform's 16-bit lanes reach 1023 x 32 = 32736 of 32767)
     if kind == "flat_extremes":
-        a, b = np.zeros((h, w), np.uint8), np.full((h, w), 255, np.uint8)
+        a, b = np.zeros((h, w), dt), np.full((h, w), top, dt)
     elif kind == "checkerboard":
-        a = (((xx + yy) & 1) * 255).astype(np.uint8)
-        b = 255 - a
+        a = (((xx + yy) & 1) * top).astype(dt)
+        b = (top - a).astype(dt)
     else:
-        a = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
-        b = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+        a = (rng.integers(0, 2, (h, w)) * top).astype(dt)
+        b = (rng.integers(0, 2, (h, w)) * top).astype(dt)
 
     def frame(y):
         c = np.ascontiguousarray(y[::2, ::2])
-        return O.Frame(y.copy(), c.copy(), (255 - c).copy())
-    prm = O.default_params(30, bit_depth=8, me_range=8)
+        return O.Frame(y.copy(), c.copy(), (top - c).astype(dt))
+    prm = O.default_params(30, bit_depth=bd, me_range=8)
     prm.rdo_zero = 1
     for src, ref in ((frame(a), frame(b)), (frame(b), frame(a))):
         want, got = O.analyze_inter(src, ref, prm, dump_me=True), emu.inter(src, ref, prm)
